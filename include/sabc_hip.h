@@ -1,0 +1,185 @@
+/*
+ * sabc_hip.h -- C-ABI of libsabc_hip.so, the MI355X-native (gfx950) engine for the
+ * particle-population update loop of SimulatedAnnealingABC.jl.
+ *
+ * The reference has no FFI: its hot path is reached through the
+ * Julia functions `sabc` and `update_population!`.  The entry points below are what a
+ * Julia wrapper binds with `ccall` in place of those function bodies (INTEGRATION.md
+ * shows the binding); the Python host mirror in simulatedannealingabc.jl_amd/ binds the
+ * same symbols with ctypes.  Citations are file:line under the reference checkout.
+ *
+ * Conventions
+ *   - return 0 on success, a negative SABC_ERR_* otherwise; never throws across the ABI;
+ *     sabc_last_error(h) holds the message the reference would have raised.
+ *   - the caller owns every host buffer it passes; the library owns all device memory
+ *     behind the opaque handle.  One host thread drives a handle; calls are not re-entrant.
+ *   - matrices are column-major n x k (Julia layout) == SoA [k][n]: theta[k*n+i].
+ *   - the product has no CPU path: every compute entry point fails with
+ *     SABC_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef SABC_HIP_H
+#define SABC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SABC_ABI_VERSION 1
+#define SABC_MAX_PARA 8
+#define SABC_MAX_STATS 8
+#define SABC_MAX_MODEL_PARAMS 32
+
+#if defined(__GNUC__)
+#define SABC_API __attribute__((visibility("default")))
+#else
+#define SABC_API
+#endif
+
+/* device-coded simulators: the `f_dist` argument of sabc() (SimulatedAnnealingABC.jl:451)
+   as data; definitions in DESIGN.md "Simulators" */
+enum { SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4 };
+/* `prior` argument as data: product of univariate Normal / Uniform */
+enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1 };
+/* `proposal` argument (proposals.jl:24 RandomWalk, :85 DifferentialEvolution, :132 StretchMove) */
+enum { SABC_PROP_RANDOMWALK = 0, SABC_PROP_DIFFEVO = 1, SABC_PROP_STRETCH = 2 };
+/* `algorithm` argument (SimulatedAnnealingABC.jl:453,462) */
+enum { SABC_ALG_SINGLE_EPS = 0, SABC_ALG_MULTI_EPS = 1 };
+
+enum {
+  SABC_OK = 0,
+  SABC_ERR_NSIM_TOO_SMALL = -1,  /* SimulatedAnnealingABC.jl:155-156 */
+  SABC_ERR_NEG_DISTANCE = -2,    /* :185 */
+  SABC_ERR_BAD_V = -3,           /* :261 */
+  SABC_ERR_BAD_DELTA = -4,       /* :262 */
+  SABC_ERR_BAD_ALGORITHM = -5,   /* :462-464 */
+  SABC_ERR_BAD_BETA = -6,        /* proposals.jl:30 */
+  SABC_ERR_ZERO_MEAN_U = -7,     /* SimulatedAnnealingABC.jl:107-109 */
+  SABC_ERR_BAD_CONFIG = -8,
+  SABC_ERR_NOT_POSDEF = -9,      /* Cholesky inside MvNormal(...), proposals.jl:42 */
+  SABC_ERR_EMPTY_CDF = -10,      /* maximum() of empty collection, cdf_estimators.jl:33 */
+  SABC_ERR_ROOT = -11,
+  SABC_ERR_NO_DEVICE = -20,
+  SABC_ERR_HIP = -21,
+  SABC_ERR_COMM = -22,
+  SABC_ERR_STATE = -23
+};
+
+typedef struct sabc_handle sabc_handle;
+
+/* Everything sabc() fixes for the lifetime of a result (SimulatedAnnealingABC.jl:451-460). */
+typedef struct {
+  int32_t abi_version;            /* SABC_ABI_VERSION */
+  int32_t device;                 /* HIP device ordinal */
+  int64_t n_particles;            /* GLOBAL particle count (kw n_particles) */
+  int32_t n_para;                 /* d = length(prior) */
+  int32_t n_stats;                /* s = length(f_dist(theta)) */
+  int32_t model_id;               /* SABC_MODEL_* */
+  int32_t n_model_params;
+  double  model_params[SABC_MAX_MODEL_PARAMS];
+  int32_t prior_kind[SABC_MAX_PARA];
+  double  prior_a[SABC_MAX_PARA]; /* Normal: mu    | Uniform: lower */
+  double  prior_b[SABC_MAX_PARA]; /* Normal: sigma | Uniform: upper */
+  int32_t algorithm;              /* SABC_ALG_* */
+  int32_t rank;                   /* this process' shard (0 when world == 1) */
+  int32_t world;                  /* number of shards (GPUs) */
+  int32_t reserved;
+  double  v;                      /* kw v, used for eps_0 (:200-204) */
+  double  delta;                  /* kw delta, used by the initial resample (:197) */
+  uint64_t seed;                  /* Philox key */
+} sabc_config;
+
+/* Keyword arguments of update_population! (SimulatedAnnealingABC.jl:251-259). */
+typedef struct {
+  int64_t n_simulation;           /* budget; n_population_updates = n_simulation / n_particles (:275) */
+  double  v;
+  double  delta;
+  double  resample;               /* kw resample (default 2 n_particles) */
+  int64_t checkpoint_history;
+  int32_t proposal_kind;          /* SABC_PROP_* */
+  int32_t reserved;
+  double  proposal_p0;            /* RandomWalk beta | DifferentialEvolution gamma0 | StretchMove a */
+  double  proposal_p1;            /* DifferentialEvolution sigma_gamma */
+} sabc_update_args;
+
+/* Collective hooks for world > 1 (one process per GPU).  `buf` is a device pointer when
+   device_buffers != 0 (RCCL / torch.distributed "nccl"), a host pointer otherwise ("gloo").
+   `stream` is the hipStream_t the library enqueues its kernels on. */
+typedef int (*sabc_allreduce_fn)(void *ctx, void *buf, int64_t count_f64, void *stream);
+typedef int (*sabc_allgather_fn)(void *ctx, const void *send, void *recv, int64_t count_f64_per_rank, void *stream);
+
+SABC_API int         sabc_abi_version(void);
+SABC_API const char *sabc_last_global_error(void);          /* for failures with no handle */
+SABC_API int         sabc_device_count(void);
+
+/* ---- lifetime ---- */
+SABC_API int         sabc_create(const sabc_config *cfg, sabc_handle **out);
+SABC_API void        sabc_destroy(sabc_handle *h);
+SABC_API const char *sabc_last_error(const sabc_handle *h);
+SABC_API int         sabc_set_stream(sabc_handle *h, void *hip_stream);
+SABC_API int         sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx,
+                                          int device_buffers);
+SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
+SABC_API int         sabc_comm_unique_id(void *out_128b);
+
+/* ---- the hot path ---- */
+/* initialization(), SimulatedAnnealingABC.jl:151-227.  n_simulation is sabc()'s budget (:155). */
+SABC_API int sabc_initialize(sabc_handle *h, int64_t n_simulation);
+/* update_population!(), SimulatedAnnealingABC.jl:251-402: proposals.jl call + update_proposal!,
+   per-particle body :308-331, resample :124-137, eps schedules :92-117, histories :367-382. */
+SABC_API int sabc_update(sabc_handle *h, const sabc_update_args *args);
+
+/* ---- result / state (SABCresult :55-60, SABCstate :28-42) ---- */
+SABC_API int64_t sabc_n_local(const sabc_handle *h);          /* particles held by this shard */
+SABC_API int64_t sabc_local_offset(const sabc_handle *h);     /* global id of the first local particle */
+/* local shard, column-major: theta n_local x d, u n_local x s, rho n_local x s; NULL skips */
+SABC_API int sabc_get_population(sabc_handle *h, double *theta, double *u, double *rho);
+SABC_API int sabc_set_population(sabc_handle *h, const double *theta, const double *u, const double *rho);
+/* out[4] = n_simulation, n_accept, n_resampling, n_population_updates */
+SABC_API int sabc_get_counters(const sabc_handle *h, int64_t out[4]);
+SABC_API int sabc_set_counters(sabc_handle *h, const int64_t in[4]);
+SABC_API int sabc_get_epsilon(const sabc_handle *h, double *eps, int32_t *len);
+SABC_API int sabc_set_epsilon(sabc_handle *h, const double *eps, int32_t len);
+SABC_API int64_t sabc_history_len(const sabc_handle *h);
+/* row-major [len][eps_len], [len][s], [len][s] */
+SABC_API int sabc_get_history(const sabc_handle *h, double *eps_hist, double *u_hist, double *rho_hist);
+SABC_API int sabc_clear_history(sabc_handle *h);
+/* state.cdfs_dist_prior (SimulatedAnnealingABC.jl:37): knots of the prior-predictive ECDF per
+   statistic (cdf_estimators.jl:33) and its evaluation on device (cdf_estimators.jl:68-70) */
+SABC_API int64_t sabc_cdf_len(const sabc_handle *h, int32_t stat);
+SABC_API int sabc_get_cdf_knots(sabc_handle *h, int32_t stat, double *out);
+SABC_API int sabc_set_cdf_knots(sabc_handle *h, int32_t stat, const double *knots, int64_t len);
+/* rho: column-major m x s; u_out likewise */
+SABC_API int sabc_cdf_apply(sabc_handle *h, const double *rho, int64_t m, double *u_out);
+SABC_API int sabc_get_proposal_sigma(const sabc_handle *h, double *sigma_dxd);
+SABC_API double sabc_last_ess(const sabc_handle *h);
+
+/* ---- operators of the path, callable on their own (mirrors of the reference's internal
+        functions so that its unit tests can be restated against the device code) ---- */
+/* build_cdf(x)(q): cdf_estimators.jl:23-44; test/runtests.jl:9-29 */
+SABC_API int sabc_op_build_cdf(int32_t device, const double *x, int64_t n, double *knots_out, int64_t *len_out);
+SABC_API int sabc_op_cdf_eval(int32_t device, const double *knots, int64_t len, const double *q, int64_t m,
+                              double *out);
+/* update_epsilon_single_eps / update_epsilon_multi_eps: SimulatedAnnealingABC.jl:92-117 (host code of the engine) */
+SABC_API int sabc_op_eps_single(double ubar, double v, double *eps_out);
+SABC_API int sabc_op_eps_multi(const double *ubar, int32_t s, double v, double *eps_out);
+/* f_dist(theta) on device for m parameter vectors (column-major m x d -> m x s), RNG stream of
+   particle ids pid0..pid0+m-1 at iteration `iter` */
+SABC_API int sabc_op_simulate(sabc_handle *h, const double *theta, int64_t m, uint64_t pid0, uint64_t iter,
+                              double *rho_out);
+/* Philox4x32-10 block and the Box-Muller pair derived from it, evaluated on device */
+SABC_API int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
+                            uint32_t out_words[4], double out_normals[2]);
+
+/* ---- measurement ---- */
+enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
+       SABC_KERNEL_COUNT = 4 };
+/* HIP-event timing of the named kernel on the library's stream, accumulated since enable */
+SABC_API int sabc_profile_enable(sabc_handle *h, int32_t on);
+SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,23 @@
+"""MI355X-native engine for the particle-population update loop of SimulatedAnnealingABC.jl.
+
+Public surface = the reference's exports (`sabc`, `update_population!` -> `update_population_`,
+`RandomWalk`, `DifferentialEvolution`, `StretchMove`) plus the descriptors a device path needs
+(`DeviceDistance` simulators and priors as data).  Everything runs in libsabc_hip.so
+(hand-written gfx950 HIP kernels behind the C-ABI of include/sabc_hip.h); there is no CPU path.
+"""
+from ._lib import SABCError, build, lib  # noqa: F401
+from .api import SABCresult, SABCstate, initialization, is_logging, sabc, update_population_  # noqa: F401
+from .distributions import Normal, Product, Uniform, product_distribution  # noqa: F401
+from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
+                     op_philox)
+from .models import DeviceDistance, GandK, Gaussian2D, GaussianIID, LotkaVolterra  # noqa: F401
+from .proposals import DifferentialEvolution, Proposal, RandomWalk, StretchMove  # noqa: F401
+
+__all__ = [
+    "sabc", "update_population_", "initialization", "SABCresult", "SABCstate", "SABCError",
+    "RandomWalk", "DifferentialEvolution", "StretchMove", "Proposal",
+    "Normal", "Uniform", "Product", "product_distribution",
+    "DeviceDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",
+    "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox",
+    "build", "lib", "is_logging",
+]

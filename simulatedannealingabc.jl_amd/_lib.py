@@ -1,0 +1,153 @@
+"""ctypes binding of libsabc_hip.so (include/sabc_hip.h) and its in-tree build.
+
+There is no CPU path: if the library is missing or no gfx950 device is usable, every
+compute call raises.  torch is imported first on purpose -- it maps its own HIP runtime
+(libamdhip64.so.7) and the library must bind to that one copy, not to a second one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
+HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
+
+ABI_VERSION = 1
+MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
+MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 1, 2, 3, 4
+PRIOR_NORMAL, PRIOR_UNIFORM = 0, 1
+PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
+ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
+KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT = 0, 1, 2, 3
+
+ERR_NAMES = {
+    -1: "NSIM_TOO_SMALL", -2: "NEG_DISTANCE", -3: "BAD_V", -4: "BAD_DELTA", -5: "BAD_ALGORITHM", -6: "BAD_BETA",
+    -7: "ZERO_MEAN_U", -8: "BAD_CONFIG", -9: "NOT_POSDEF", -10: "EMPTY_CDF", -11: "ROOT", -20: "NO_DEVICE",
+    -21: "HIP", -22: "COMM", -23: "STATE",
+}
+
+
+class SABCError(RuntimeError):
+    """Counterpart of the reference's `error(...)` (ErrorException) sites."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"{msg} [SABC_ERR_{ERR_NAMES.get(code, code)}]")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32), ("n_particles", C.c_int64),
+        ("n_para", C.c_int32), ("n_stats", C.c_int32), ("model_id", C.c_int32), ("n_model_params", C.c_int32),
+        ("model_params", C.c_double * MAX_MODEL_PARAMS),
+        ("prior_kind", C.c_int32 * MAX_PARA), ("prior_a", C.c_double * MAX_PARA), ("prior_b", C.c_double * MAX_PARA),
+        ("algorithm", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32),
+        ("v", C.c_double), ("delta", C.c_double), ("seed", C.c_uint64),
+    ]
+
+
+class UpdateArgs(C.Structure):
+    _fields_ = [
+        ("n_simulation", C.c_int64), ("v", C.c_double), ("delta", C.c_double), ("resample", C.c_double),
+        ("checkpoint_history", C.c_int64), ("proposal_kind", C.c_int32), ("reserved", C.c_int32),
+        ("proposal_p0", C.c_double), ("proposal_p1", C.c_double),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+def sources_newer_than_lib() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp", "Makefile"))]
+    srcs.append(HEADER)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of every HIP translation unit (csrc/Makefile)."""
+    if force or sources_newer_than_lib():
+        cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if verbose or r.returncode:
+            print(r.stdout)
+        if r.returncode:
+            raise RuntimeError("building libsabc_hip.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libsabc_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (maps the HIP runtime first; see module docstring)
+
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the SABC update loop."
+        )
+    L = C.CDLL(LIB_PATH)
+    dp, ip64 = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    vp = C.c_void_p
+    sig = {
+        "sabc_abi_version": ([], C.c_int),
+        "sabc_last_global_error": ([], C.c_char_p),
+        "sabc_device_count": ([], C.c_int),
+        "sabc_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
+        "sabc_destroy": ([vp], None),
+        "sabc_last_error": ([vp], C.c_char_p),
+        "sabc_set_stream": ([vp, vp], C.c_int),
+        "sabc_set_collectives": ([vp, ALLREDUCE_FN, ALLGATHER_FN, vp, C.c_int], C.c_int),
+        "sabc_comm_init_rccl": ([vp, vp], C.c_int),
+        "sabc_comm_unique_id": ([vp], C.c_int),
+        "sabc_initialize": ([vp, C.c_int64], C.c_int),
+        "sabc_update": ([vp, C.POINTER(UpdateArgs)], C.c_int),
+        "sabc_n_local": ([vp], C.c_int64),
+        "sabc_local_offset": ([vp], C.c_int64),
+        "sabc_get_population": ([vp, dp, dp, dp], C.c_int),
+        "sabc_set_population": ([vp, dp, dp, dp], C.c_int),
+        "sabc_get_counters": ([vp, ip64], C.c_int),
+        "sabc_set_counters": ([vp, ip64], C.c_int),
+        "sabc_get_epsilon": ([vp, dp, C.POINTER(C.c_int32)], C.c_int),
+        "sabc_set_epsilon": ([vp, dp, C.c_int32], C.c_int),
+        "sabc_history_len": ([vp], C.c_int64),
+        "sabc_get_history": ([vp, dp, dp, dp], C.c_int),
+        "sabc_clear_history": ([vp], C.c_int),
+        "sabc_cdf_len": ([vp, C.c_int32], C.c_int64),
+        "sabc_get_cdf_knots": ([vp, C.c_int32, dp], C.c_int),
+        "sabc_set_cdf_knots": ([vp, C.c_int32, dp, C.c_int64], C.c_int),
+        "sabc_cdf_apply": ([vp, dp, C.c_int64, dp], C.c_int),
+        "sabc_get_proposal_sigma": ([vp, dp], C.c_int),
+        "sabc_last_ess": ([vp], C.c_double),
+        "sabc_op_build_cdf": ([C.c_int32, dp, C.c_int64, dp, ip64], C.c_int),
+        "sabc_op_cdf_eval": ([C.c_int32, dp, C.c_int64, dp, C.c_int64, dp], C.c_int),
+        "sabc_op_eps_single": ([C.c_double, C.c_double, dp], C.c_int),
+        "sabc_op_eps_multi": ([dp, C.c_int32, C.c_double, dp], C.c_int),
+        "sabc_op_simulate": ([vp, dp, C.c_int64, C.c_uint64, C.c_uint64, dp], C.c_int),
+        "sabc_op_philox": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                            C.POINTER(C.c_uint32), dp], C.c_int),
+        "sabc_profile_enable": ([vp, C.c_int32], C.c_int),
+        "sabc_profile_get": ([vp, C.c_int32, dp, ip64], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = a symbol the header declares is missing
+        fn.argtypes, fn.restype = args, res
+    if L.sabc_abi_version() != ABI_VERSION:
+        raise ImportError("libsabc_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def global_error() -> str:
+    return lib().sabc_last_global_error().decode("utf-8", "replace")

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's public API for the hot path: `sabc`,
+`update_population!` (here `update_population_`, Python has no `!`), `SABCresult`, `SABCstate`
+-- same names, keyword sets, result fields and error behaviour as
+/root/reference/src/SimulatedAnnealingABC.jl:28-60,251-259,451-460.  Everything numerical
+happens behind the C-ABI (include/sabc_hip.h) on the GPU; this file only marshals arguments,
+exactly what the Julia wrapper in julia/ does with `ccall`.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import secrets
+import sys
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from ._lib import SABCError
+from .distributions import Distribution
+from .handle import SabcHandle
+from .models import DeviceDistance
+from .proposals import DifferentialEvolution, Proposal, RandomWalk
+
+log = logging.getLogger("SimulatedAnnealingABC")
+
+_ALGORITHMS = {"single_eps": _lib.ALG_SINGLE_EPS, "multi_eps": _lib.ALG_MULTI_EPS}
+
+
+def is_logging(io=sys.stderr):
+    """SimulatedAnnealingABC.jl:500."""
+    import os
+    return (not io.isatty()) or os.environ.get("CI") == "true"
+
+
+class CdfTransform:
+    """`state.cdfs_dist_prior`: ρ -> u, evaluated on the device (cdf_estimators.jl:68-70)."""
+
+    def __init__(self, handle: SabcHandle):
+        self._h = handle
+
+    def __call__(self, ρ):
+        r = np.atleast_1d(np.asarray(ρ, dtype=np.float64))
+        if r.shape != (self._h.s,):
+            raise ValueError(f"expected {self._h.s} distances")
+        return self._h.cdf_apply(r.reshape(self._h.s, 1))[:, 0]
+
+    def knots(self, stat):
+        return self._h.cdf_knots(stat)
+
+
+class SABCstate:
+    """Mirror of `mutable struct SABCstate` (SimulatedAnnealingABC.jl:28-42)."""
+
+    def __init__(self):
+        self.ϵ = np.zeros(1)
+        self.algorithm = "single_eps"
+        self.ϵ_history, self.ρ_history, self.u_history = [], [], []
+        self.cdfs_dist_prior = None
+        self.n_simulation = 0
+        self.n_accept = 0
+        self.n_resampling = 0
+        self.n_population_updates = 0
+
+
+class SABCresult:
+    """Mirror of `struct SABCresult{T,S}` (SimulatedAnnealingABC.jl:55-60): `population`
+    (length-n vector for a univariate prior, n×d otherwise), `u` and `ρ` (n×s), `state`.
+    On a sharded run these hold the LOCAL shard; `local_offset` is the first global id."""
+
+    def __init__(self, population, u, ρ, state, handle, model, prior, seed):
+        self.population, self.u, self.ρ, self.state = population, u, ρ, state
+        self._handle, self._model, self._prior, self.seed = handle, model, prior, seed
+
+    @property
+    def local_offset(self):
+        return self._handle.local_offset
+
+    def __repr__(self):   # show(), SimulatedAnnealingABC.jl:65-82
+        n = len(self.population)
+        st = self.state
+        denom = st.n_simulation - self._handle.cfg.n_particles
+        acc = st.n_accept / denom if denom else float("nan")
+        return (
+            f"Approximate posterior sample with {n} particles:\n"
+            f"  - algorithm: :{st.algorithm}\n"
+            f"  - simulations used: {st.n_simulation}\n"
+            f"  - number of population updates: {st.n_population_updates}\n"
+            f"  - average transformed distance: {float(np.mean(self.u)):.4g}\n"
+            f"  - ϵ: {np.array2string(np.asarray(st.ϵ), precision=4)}\n"
+            f"  - number of population resamplings: {st.n_resampling}\n"
+            f"  - acceptance rate: {acc:.4g}\n"
+            "The sample can be accessed with the field `population`.\n"
+            "The history of ϵ can be accessed with the field `state.ϵ_history`.\n"
+            "The history of ρ can be accessed with the field `state.ρ_history`.\n"
+            "The history of u can be accessed with the field `state.u_history`."
+        )
+
+
+def _refresh(res: SABCresult, first=False):
+    """Write the device state back into the result (`.=` at SimulatedAnnealingABC.jl:387-397)."""
+    h = res._handle
+    th, u, rho = h.get_population()
+    pop = th[0].copy() if res._prior.univariate else np.ascontiguousarray(th.T)
+    if first:
+        res.population, res.u, res.ρ = pop, u.T.copy(order="F"), rho.T.copy(order="F")
+    else:
+        res.population[...] = pop
+        res.u[...] = u.T
+        res.ρ[...] = rho.T
+    st = res.state
+    st.ϵ = h.eps
+    c = h.counters
+    st.n_simulation, st.n_accept = c["n_simulation"], c["n_accept"]
+    st.n_resampling, st.n_population_updates = c["n_resampling"], c["n_population_updates"]
+    e, uh, rh = h.history
+    st.ϵ_history = [row.copy() for row in e]
+    st.u_history = [row.copy() for row in uh]
+    st.ρ_history = [row.copy() for row in rh]
+
+
+def _dist_env(distributed):
+    """rank / world / device under torch.distributed (one process per GPU)."""
+    if distributed is False:
+        return 0, 1, None
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return 0, 1, None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_rank(), dist.get_world_size(), dist
+    if distributed is True:
+        raise RuntimeError("distributed=True needs an initialised torch.distributed process group")
+    return 0, 1, None
+
+
+def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.1, algorithm="single_eps",
+                   seed=None, device=None, distributed=None, **kwargs):
+    """SimulatedAnnealingABC.jl:151-227 -> SABCresult."""
+    if n_simulation < n_particles:                                            # :155-156
+        raise SABCError(-1, f"`n_simulation = {n_simulation}` is too small for {n_particles} particles.")
+    alg = str(algorithm).lstrip(":")
+    if alg not in _ALGORITHMS:                                                # :462-464
+        raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
+    if not isinstance(prior, Distribution):
+        raise TypeError("prior must be Normal, Uniform or product_distribution([...]) of those")
+    if not isinstance(f_dist, DeviceDistance):
+        raise NotImplementedError(
+            "f_dist must be a device-coded DeviceDistance (models.py); running an arbitrary host callable "
+            "through the GPU loop is the next item of SURVEY.md section 8f and is not built"
+        )
+    if args or kwargs:
+        raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
+    if len(prior) not in f_dist.n_para:
+        raise ValueError(f"{type(f_dist).__name__} needs a prior with {f_dist.n_para} parameters, got {len(prior)}")
+    log.info("Initialization for '%s'", alg)                                  # :158
+    rank, world, dist = _dist_env(distributed)
+    if device is None:
+        import os
+        device = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    if seed is None:
+        seed = secrets.randbits(63)
+        if dist is not None:   # every shard must use the same Philox key
+            import torch
+            t = torch.tensor([seed], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                t = t.cuda(device)
+            dist.broadcast(t, 0)
+            seed = int(t.item())
+    h = SabcHandle(n_particles=n_particles, model=f_dist, prior=prior, algorithm=_ALGORITHMS[alg], v=v, delta=δ,
+                   seed=seed, device=device, rank=rank, world=world)
+    if dist is not None:
+        from .dist import install_collectives
+        install_collectives(h, device)
+    h.initialize(n_simulation)
+    state = SABCstate()
+    state.algorithm = alg
+    state.cdfs_dist_prior = CdfTransform(h)
+    res = SABCresult(None, None, None, state, h, f_dist, prior, seed)
+    _refresh(res, first=True)
+    return res
+
+
+def update_population_(population_state: SABCresult, f_dist, prior, *args, n_simulation, v=1.0, δ=0.1,
+                       proposal: Proposal = None, resample=None, checkpoint_history=1, show_progressbar=None,
+                       show_checkpoint=None, **kwargs):
+    """`update_population!` (SimulatedAnnealingABC.jl:251-402): updates the particles with
+    `n_simulation` simulations, mutates `population_state` and returns it."""
+    if not v > 0:
+        raise SABCError(-3, "Annealing speed `v` must be positive.")                 # :261
+    if not δ > 0:
+        raise SABCError(-4, "Resamping intensity `δ` must be positive.")            # :262
+    res = population_state
+    if args or kwargs:
+        raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
+    if f_dist is not res._model or prior is not res._prior:
+        if type(f_dist) is not type(res._model) or list(f_dist.params) != list(res._model.params) or \
+                prior.descriptors() != res._prior.descriptors():
+            raise ValueError("f_dist / prior differ from the ones this SABCresult was initialised with")
+    h = res._handle
+    if proposal is None:
+        proposal = DifferentialEvolution(n_para=len(prior))                           # :254
+    if not isinstance(proposal, Proposal):
+        raise TypeError("proposal must be RandomWalk, DifferentialEvolution or StretchMove")
+    n_global = h.cfg.n_particles
+    if resample is None:
+        resample = 2 * n_global                                                        # :255
+    if show_checkpoint is None:
+        show_checkpoint = math.inf
+    # the reference starts from the arrays held by the result (:264-267): push them to the device
+    th = res.population.reshape(1, -1) if res._prior.univariate else np.ascontiguousarray(res.population.T)
+    h.set_population(th, np.ascontiguousarray(res.u.T), np.ascontiguousarray(res.ρ.T))
+
+    n_pop = n_simulation // n_global                                                   # :275
+    chunk = n_pop
+    if math.isfinite(show_checkpoint) and show_checkpoint >= 1:
+        k = int(show_checkpoint)
+        if k % max(int(checkpoint_history), 1) == 0:
+            chunk = k
+        else:
+            warnings.warn("show_checkpoint is not a multiple of checkpoint_history; progress lines are disabled")
+    done, t0 = 0, time.time()
+    while True:
+        todo = min(chunk, n_pop - done) if n_pop > 0 else 0
+        budget = todo * n_global if n_pop > 0 else n_simulation
+        h.update(n_simulation=budget, proposal=proposal, v=v, delta=δ, resample=resample,
+                 checkpoint_history=checkpoint_history)
+        done += todo
+        if done >= n_pop:
+            break
+        eta = (time.time() - t0) / done * (n_pop - done)                              # :359-364
+        log.info("Update %d of %d. ϵ: %s, ETA: %.0f s", done, n_pop, np.array2string(h.eps, precision=4), eta)
+    if isinstance(proposal, RandomWalk):
+        sg = h.proposal_sigma
+        proposal.Σ = float(sg[0, 0]) if len(prior) == 1 else sg                       # rw.Σ, proposals.jl:47,59
+    _refresh(res)
+    log.info("All particles have been updated %d times.", n_pop)                      # :399
+    return res
+
+
+def sabc(f_dist, prior, *args, n_particles=100, n_simulation=10_000, algorithm="single_eps", proposal: Proposal = None,
+         resample=None, v=1.0, δ=0.1, checkpoint_history=1, show_progressbar=None, show_checkpoint=None,
+         seed=None, device=None, distributed=None, **kwargs):
+    """Simulated Annealing ABC (SimulatedAnnealingABC.jl:451-492).  Same keywords as the
+    reference plus `seed` (Philox key; random if omitted), `device` and `distributed`."""
+    alg = str(algorithm).lstrip(":")
+    if alg not in _ALGORITHMS:                                                        # :462-464
+        raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
+    if proposal is None:
+        proposal = DifferentialEvolution(n_para=len(prior))                           # :454
+    if resample is None:
+        resample = 2 * n_particles                                                     # :455
+    population_state = initialization(f_dist, prior, *args, n_particles=n_particles, n_simulation=n_simulation,
+                                      v=v, δ=δ, algorithm=alg, seed=seed, device=device, distributed=distributed,
+                                      **kwargs)                                       # :470-473
+    n_sim_remaining = n_simulation - population_state.state.n_simulation             # :478
+    if n_sim_remaining < n_particles:
+        warnings.warn("`n_simulation` too small to update all particles!")           # :479
+    update_population_(population_state, f_dist, prior, *args, n_simulation=n_sim_remaining, resample=resample,
+                       proposal=proposal, v=v, δ=δ, checkpoint_history=checkpoint_history,
+                       show_progressbar=show_progressbar, show_checkpoint=show_checkpoint, **kwargs)   # :481-489
+    return population_state

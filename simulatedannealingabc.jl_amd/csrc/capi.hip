@@ -1,0 +1,423 @@
+// capi.hip -- the extern "C" surface of libsabc_hip.so (include/sabc_hip.h).
+// Plain pointers and sizes only; no exceptions cross this boundary.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sabc_hip.h"
+#include "engine.hpp"
+#include "hip_backend.hpp"
+#include "host_math.hpp"
+#include "kernels.hpp"
+
+using namespace sabc;
+
+namespace {
+
+thread_local std::string g_err;
+
+// world == 1
+class NoCollectives : public Collectives {
+ public:
+  int allreduce_sum(double *, int64_t) override { return 0; }
+  int allgather(const double *, double *, int64_t) override { return -1; }
+};
+
+// user-supplied hooks (torch.distributed from Python, MPI/RCCL from Julia)
+class CallbackCollectives : public Collectives {
+ public:
+  CallbackCollectives(HipBackend *be, int world, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, bool dev)
+      : be_(be), world_(world), ar_(ar), ag_(ag), ctx_(ctx), dev_(dev) {}
+  int allreduce_sum(double *buf, int64_t count) override {
+    if (dev_) return ar_(ctx_, buf, count, (void *)be_->stream());
+    double *h = be_->host_stage(count);
+    if (hipMemcpyAsync(h, buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, be_->stream()) != hipSuccess) return -1;
+    if (hipStreamSynchronize(be_->stream()) != hipSuccess) return -1;
+    if (ar_(ctx_, h, count, nullptr)) return -1;
+    if (hipMemcpyAsync(buf, h, (size_t)count * sizeof(double), hipMemcpyHostToDevice, be_->stream()) != hipSuccess) return -1;
+    return hipStreamSynchronize(be_->stream()) == hipSuccess ? 0 : -1;
+  }
+  int allgather(const double *send, double *recv, int64_t count) override {
+    if (dev_) return ag_(ctx_, send, recv, count, (void *)be_->stream());
+    double *h = be_->host_stage(count * (world_ + 1));
+    if (hipMemcpyAsync(h, send, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, be_->stream()) != hipSuccess) return -1;
+    if (hipStreamSynchronize(be_->stream()) != hipSuccess) return -1;
+    if (ag_(ctx_, h, h + count, count, nullptr)) return -1;
+    if (hipMemcpyAsync(recv, h + count, (size_t)count * world_ * sizeof(double), hipMemcpyHostToDevice, be_->stream()) != hipSuccess) return -1;
+    return hipStreamSynchronize(be_->stream()) == hipSuccess ? 0 : -1;
+  }
+
+ private:
+  HipBackend *be_;
+  int world_;
+  sabc_allreduce_fn ar_;
+  sabc_allgather_fn ag_;
+  void *ctx_;
+  bool dev_;
+};
+
+// RCCL over xGMI, bound at run time so that the library loads on hosts without librccl
+// (and picks up the copy torch already mapped when there is one).
+struct Id128 { char b[128]; };   // ncclUniqueId, passed by value
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+};
+
+RcclApi *rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (int (*)(void *))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (int (*)(void **, int, Id128, int))dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (int (*)(void *))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+      api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(api.lib, "ncclAllGather");
+    }
+  }
+  return (api.lib && api.GetUniqueId && api.CommInitRank && api.AllReduce && api.AllGather) ? &api : nullptr;
+}
+
+class RcclCollectives : public Collectives {
+ public:
+  RcclCollectives(HipBackend *be, void *comm) : be_(be), comm_(comm) {}
+  ~RcclCollectives() override {
+    RcclApi *a = rccl_api();
+    if (a && a->CommDestroy && comm_) a->CommDestroy(comm_);
+  }
+  int allreduce_sum(double *buf, int64_t count) override {   // ncclFloat64 = 8, ncclSum = 0
+    return rccl_api()->AllReduce(buf, buf, (size_t)count, 8, 0, comm_, be_->stream());
+  }
+  int allgather(const double *send, double *recv, int64_t count) override {
+    return rccl_api()->AllGather(send, recv, (size_t)count, 8, comm_, be_->stream());
+  }
+
+ private:
+  HipBackend *be_;
+  void *comm_;
+};
+
+int usable_device(int device, std::string &why) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    why = "no usable HIP device (libsabc_hip.so has no CPU path): ";
+    why += hipGetErrorString(e);
+    return SABC_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= n) {
+    why = "device ordinal out of range";
+    return SABC_ERR_NO_DEVICE;
+  }
+  return 0;
+}
+
+}  // namespace
+
+struct sabc_handle {
+  Engine *eng = nullptr;
+  HipBackend *be = nullptr;
+  Collectives *coll = nullptr;
+  std::string err;
+};
+
+namespace {
+int hfail(sabc_handle *h, int code) {
+  if (!h) return code;
+  h->err = h->eng && !h->eng->error().empty() ? h->eng->error() : h->err;
+  if (h->be && !h->be->error().empty()) { h->err += h->err.empty() ? "" : " | "; h->err += h->be->error(); }
+  return code;
+}
+int hset(sabc_handle *h, int code, const char *msg) {
+  if (h) h->err = msg;
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+int sabc_abi_version(void) { return SABC_ABI_VERSION; }
+const char *sabc_last_global_error(void) { return g_err.c_str(); }
+
+int sabc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sabc_create(const sabc_config *cfg, sabc_handle **out) {
+  if (!cfg || !out) { g_err = "null argument"; return SABC_ERR_BAD_CONFIG; }
+  *out = nullptr;
+  sabc_handle *h = new (std::nothrow) sabc_handle();
+  if (!h) { g_err = "out of memory"; return SABC_ERR_BAD_CONFIG; }
+  // configuration errors are reported even without a GPU (they are the reference's own errors)
+  h->be = new HipBackend(cfg->device);
+  h->coll = new NoCollectives();
+  h->eng = new Engine(*cfg, h->be, h->coll);
+  int rc = h->eng->validate();
+  if (rc) { g_err = h->eng->error(); sabc_destroy(h); return rc; }
+  std::string why;
+  rc = usable_device(cfg->device, why);
+  if (rc) { g_err = why; sabc_destroy(h); return rc; }
+  if (h->be->allocate(h->eng->model(), h->eng->shard())) {
+    g_err = h->be->error();
+    sabc_destroy(h);
+    return SABC_ERR_HIP;
+  }
+  *out = h;
+  return 0;
+}
+
+void sabc_destroy(sabc_handle *h) {
+  if (!h) return;
+  delete h->eng;
+  delete h->coll;
+  delete h->be;
+  delete h;
+}
+
+const char *sabc_last_error(const sabc_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int sabc_set_stream(sabc_handle *h, void *hip_stream) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->set_stream((hipStream_t)hip_stream) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+
+int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, int device_buffers) {
+  if (!h || !ar || !ag) return hset(h, SABC_ERR_COMM, "null collective hook");
+  Collectives *c = new CallbackCollectives(h->be, h->eng->shard().world, ar, ag, ctx, device_buffers != 0);
+  delete h->coll;
+  h->coll = c;
+  h->eng->set_collectives(c);
+  return 0;
+}
+
+int sabc_comm_unique_id(void *out_128b) {
+  RcclApi *a = rccl_api();
+  if (!a) { g_err = "librccl.so could not be loaded"; return SABC_ERR_COMM; }
+  return a->GetUniqueId(out_128b) == 0 ? 0 : SABC_ERR_COMM;
+}
+
+int sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b) {
+  if (!h) return SABC_ERR_STATE;
+  RcclApi *a = rccl_api();
+  if (!a) return hset(h, SABC_ERR_COMM, "librccl.so could not be loaded");
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  Id128 id;
+  std::memcpy(id.b, unique_id_128b, 128);
+  void *comm = nullptr;
+  const Shard &sh = h->eng->shard();
+  if (a->CommInitRank(&comm, sh.world, id, sh.rank) != 0) return hset(h, SABC_ERR_COMM, "ncclCommInitRank failed");
+  delete h->coll;
+  h->coll = new RcclCollectives(h->be, comm);
+  h->eng->set_collectives(h->coll);
+  return 0;
+}
+
+int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
+  if (!h) return SABC_ERR_STATE;
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  const int rc = h->eng->initialize(n_simulation);
+  return rc ? hfail(h, rc) : 0;
+}
+
+int sabc_update(sabc_handle *h, const sabc_update_args *args) {
+  if (!h || !args) return SABC_ERR_STATE;
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  const int rc = h->eng->update(*args);
+  return rc ? hfail(h, rc) : 0;
+}
+
+int64_t sabc_n_local(const sabc_handle *h) { return h ? h->eng->shard().n_local : 0; }
+int64_t sabc_local_offset(const sabc_handle *h) { return h ? h->eng->shard().gid0 : 0; }
+
+int sabc_get_population(sabc_handle *h, double *theta, double *u, double *rho) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->download(theta, u, rho) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+
+int sabc_set_population(sabc_handle *h, const double *theta, const double *u, const double *rho) {
+  if (!h) return SABC_ERR_STATE;
+  if (h->be->upload(theta, u, rho)) return hfail(h, SABC_ERR_HIP);
+  h->eng->mark_initialized();
+  return 0;
+}
+
+int sabc_get_counters(const sabc_handle *h, int64_t out[4]) {
+  if (!h) return SABC_ERR_STATE;
+  h->eng->counters(out);
+  return 0;
+}
+int sabc_set_counters(sabc_handle *h, const int64_t in[4]) {
+  if (!h) return SABC_ERR_STATE;
+  h->eng->set_counters(in);
+  return 0;
+}
+int sabc_get_epsilon(const sabc_handle *h, double *eps, int32_t *len) {
+  if (!h) return SABC_ERR_STATE;
+  for (int i = 0; i < h->eng->eps_len(); ++i) eps[i] = h->eng->eps()[i];
+  if (len) *len = h->eng->eps_len();
+  return 0;
+}
+int sabc_set_epsilon(sabc_handle *h, const double *eps, int32_t len) {
+  if (!h) return SABC_ERR_STATE;
+  const int rc = h->eng->set_eps(eps, len);
+  return rc ? hfail(h, rc) : 0;
+}
+int64_t sabc_history_len(const sabc_handle *h) { return h ? h->eng->history_len() : 0; }
+int sabc_get_history(const sabc_handle *h, double *e, double *u, double *r) {
+  if (!h) return SABC_ERR_STATE;
+  h->eng->history(e, u, r);
+  return 0;
+}
+int sabc_clear_history(sabc_handle *h) {
+  if (!h) return SABC_ERR_STATE;
+  h->eng->clear_history();
+  return 0;
+}
+
+int64_t sabc_cdf_len(const sabc_handle *h, int32_t stat) {
+  if (!h || stat < 0 || stat >= h->eng->model().s) return 0;
+  return h->eng->cdf_len()[stat];
+}
+int sabc_get_cdf_knots(sabc_handle *h, int32_t stat, double *out) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->get_knots(stat, out, sabc_cdf_len(h, stat)) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+int sabc_set_cdf_knots(sabc_handle *h, int32_t stat, const double *knots, int64_t len) {
+  if (!h) return SABC_ERR_STATE;
+  if (h->be->set_knots(stat, knots, len)) return hfail(h, SABC_ERR_BAD_CONFIG);
+  h->eng->set_cdf_len(stat, len);
+  return 0;
+}
+int sabc_cdf_apply(sabc_handle *h, const double *rho, int64_t m, double *u_out) {
+  if (!h) return SABC_ERR_STATE;
+  for (int j = 0; j < h->eng->model().s; ++j)
+    if (h->eng->cdf_len()[j] < 3) return hset(h, SABC_ERR_STATE, "ECDF tables are not built yet");
+  return h->be->cdf_apply_host(rho, m, u_out) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+int sabc_get_proposal_sigma(const sabc_handle *h, double *sigma) {
+  if (!h) return SABC_ERR_STATE;
+  const int d = h->eng->model().d;
+  for (int i = 0; i < d * d; ++i) sigma[i] = h->eng->sigma()[i];
+  return 0;
+}
+double sabc_last_ess(const sabc_handle *h) { return h ? h->be->last_ess() : 0.0; }
+
+// ---- stand-alone operators -----------------------------------------------------------------
+int sabc_op_build_cdf(int32_t device, const double *x, int64_t n, double *knots_out, int64_t *len_out) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (n < 1) { g_err = "empty input"; return SABC_ERR_EMPTY_CDF; }
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  double *a = nullptr, *b = nullptr, *k = nullptr;
+  int64_t *meta = nullptr;
+  void *tmp = nullptr;
+  size_t bytes = 0;
+  hipError_t e = hipMalloc((void **)&a, (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&b, (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&k, (size_t)(n + 2) * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&meta, 16);
+  if (e == hipSuccess) e = (hipError_t)sort_f64(a, b, n, nullptr, &bytes, nullptr);
+  if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+  if (e == hipSuccess) e = hipMemcpy(a, x, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)sort_f64(a, b, n, tmp, &bytes, nullptr);
+  if (e == hipSuccess) e = (hipError_t)launch_cdf_knots(b, n, k, meta, nullptr);
+  int64_t hm[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(hm, meta, 16, hipMemcpyDeviceToHost);
+  int64_t len = 0;
+  if (e == hipSuccess) {
+    const int64_t mpos = n - hm[0];
+    len = mpos > 0 ? mpos + 2 : 0;
+    if (len) e = hipMemcpy(knots_out, k, (size_t)len * 8, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(k); (void)hipFree(meta); (void)hipFree(tmp);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  if (hm[1]) { g_err = "Negative distances are not allowed!"; return SABC_ERR_NEG_DISTANCE; }
+  if (!len) { g_err = "no positive entry"; return SABC_ERR_EMPTY_CDF; }
+  *len_out = len;
+  return 0;
+}
+
+int sabc_op_cdf_eval(int32_t device, const double *knots, int64_t len, const double *q, int64_t m, double *out) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (len < 2 || m < 0) { g_err = "bad length"; return SABC_ERR_BAD_CONFIG; }
+  if (m == 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  double *k = nullptr, *dq = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void **)&k, (size_t)len * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&dq, (size_t)m * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&dout, (size_t)m * 8);
+  if (e == hipSuccess) e = hipMemcpy(k, knots, (size_t)len * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dq, q, (size_t)m * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)launch_cdf_eval(k, len, dq, m, dout, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)m * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(k); (void)hipFree(dq); (void)hipFree(dout);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  return 0;
+}
+
+int sabc_op_eps_single(double ubar, double v, double *eps_out) {
+  *eps_out = hostmath::eps_single(ubar, v);
+  return 0;
+}
+
+int sabc_op_eps_multi(const double *ubar, int32_t s, double v, double *eps_out) {
+  if (s < 1 || s > SABC_MAX_STATS) return SABC_ERR_BAD_CONFIG;
+  return hostmath::eps_multi(ubar, s, v, eps_out) ? 0 : SABC_ERR_ZERO_MEAN_U;
+}
+
+int sabc_op_simulate(sabc_handle *h, const double *theta, int64_t m, uint64_t pid0, uint64_t iter, double *rho_out) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->simulate_host(theta, m, pid0, iter, rho_out) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+
+int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
+                   uint32_t out_words[4], double out_normals[2]) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  uint32_t *w = nullptr;
+  double *z = nullptr;
+  hipError_t e = hipMalloc((void **)&w, 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&z, 16);
+  if (e == hipSuccess) e = (hipError_t)launch_philox_debug(seed, pid, purpose, iter, k, w, z, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_words, w, 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out_normals, z, 16, hipMemcpyDeviceToHost);
+  (void)hipFree(w); (void)hipFree(z);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  return 0;
+}
+
+int sabc_profile_enable(sabc_handle *h, int32_t on) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->profile_enable(on != 0);
+  return 0;
+}
+
+int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->profile_get(kernel, total_ms, launches) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+// device_models.hpp -- priors, device-coded simulators (the user's f_dist of
+// SimulatedAnnealingABC.jl:164,175,315 shipped as data) and the empirical-CDF lookup
+// (cdf_estimators.jl:39-42,68-70) as gfx950 device functions.
+#pragma once
+#include "device_rng.hpp"
+#include "sabc_types.hpp"
+
+namespace sabc {
+
+#define SABC_LOG2PI 1.8378770664093454835606594728112
+
+// ---- prior: product of Normal / Uniform (Distributions.logpdf at :314,318) ----
+template <int D>
+__device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double *th) {
+  double lp = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const double x = th[k];
+    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
+      const double z = (x - m.prior_a[k]) / m.prior_b[k];
+      lp += -(z * z + SABC_LOG2PI) / 2.0 - log(m.prior_b[k]);
+    } else {
+      if (x >= m.prior_a[k] && x <= m.prior_b[k]) lp += -log(m.prior_b[k] - m.prior_a[k]);
+      else lp = -INFINITY;
+    }
+  }
+  return lp;
+}
+
+// rand(prior) at :174; dimension k uses block k of the PRIOR stream
+template <int D>
+__device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    const u32x4 w = stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k);
+    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
+      double z0, z1;
+      box_muller(w, z0, z1);
+      th[k] = m.prior_a[k] + m.prior_b[k] * z0;
+    } else {
+      th[k] = m.prior_a[k] + (m.prior_b[k] - m.prior_a[k]) * u52(w.x, w.y);
+    }
+  }
+}
+
+// ---- empirical CDF: knots T[0..len), ordinates k/(len-1), piecewise linear, flat outside ----
+__device__ __forceinline__ double cdf_apply(const double *__restrict__ T, int64_t len, double x) {
+  if (!(x >= T[0])) return (x != x) ? x : 0.0;
+  if (x > T[len - 1]) return 1.0;
+  int64_t lo = 0, hi = len;               // lo = #knots < x
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (T[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  const int64_t i0 = lo > 0 ? lo - 1 : 0;
+  const double L1 = (double)(len - 1);
+  const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
+  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
+  return y0 + slope * (x - T[i0]);
+}
+
+__device__ __forceinline__ double finite_or_big(double v) { return isfinite(v) ? v : 1e30; }
+
+// ---- simulators ----
+template <int MODEL, int D, int S>
+struct Sim;
+
+// y_1..n_obs ~ Normal(theta1, sd); rho1 = |obs_mean - mean(y)|, rho2 = |obs_m2 - mean(y^2)|
+// (test/runtests.jl:35,86,128-131,167-170; BASELINE configs 1-2)
+template <int D, int S>
+struct Sim<SABC_MODEL_GAUSS_IID, D, S> {
+  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                             double *rho) {
+    const int n_obs = (int)m.p[0];
+    const double mu = th[0];
+    const double sd = (D >= 2) ? th[1] : m.p[1];
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    double sum = 0.0, sum2 = 0.0;
+    const int n_pairs = n_obs >> 1;
+    for (int k = 0; k < n_pairs; ++k) {
+      double z0, z1;
+      ns.pair(z0, z1);
+      const double x0 = mu + sd * z0;
+      const double x1 = mu + sd * z1;
+      sum += x0; if (S >= 2) sum2 += x0 * x0;
+      sum += x1; if (S >= 2) sum2 += x1 * x1;
+    }
+    if (n_obs & 1) {
+      double z0, z1;
+      ns.pair(z0, z1);
+      const double x0 = mu + sd * z0;
+      sum += x0; if (S >= 2) sum2 += x0 * x0;
+    }
+    rho[0] = fabs(m.p[2] - sum / n_obs);
+    if (S >= 2) rho[1] = fabs(m.p[3] - sum2 / n_obs);
+  }
+};
+
+// x_1..n_obs ~ N(theta, [[1,r],[r,1]]); rho = (||mean - obs||, |var1+var2 - obs|, |cov12 - obs|)
+template <int D, int S>
+struct Sim<SABC_MODEL_GAUSS2D, D, S> {
+  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                             double *rho) {
+    const int n_obs = (int)m.p[0];
+    const double r = m.p[1], c = sqrt(1.0 - r * r);
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    double S1 = 0, S2 = 0, Q11 = 0, Q22 = 0, Q12 = 0;
+    for (int k = 0; k < n_obs; ++k) {
+      double za, zb;
+      ns.pair(za, zb);
+      const double e1 = za, e2 = r * za + c * zb;
+      S1 += e1; S2 += e2; Q11 += e1 * e1; Q22 += e2 * e2; Q12 += e1 * e2;
+    }
+    const double m1 = S1 / n_obs, m2 = S2 / n_obs;
+    const double var1 = (Q11 - S1 * m1) / (n_obs - 1), var2 = (Q22 - S2 * m2) / (n_obs - 1);
+    const double cov = (Q12 - S1 * m2) / (n_obs - 1);
+    const double d1 = th[0] + m1 - m.p[2], d2 = th[1] + m2 - m.p[3];
+    rho[0] = sqrt(d1 * d1 + d2 * d2);
+    if (S >= 2) rho[1] = fabs(var1 + var2 - m.p[4]);
+    if (S >= 3) rho[2] = fabs(cov - m.p[5]);
+  }
+};
+
+// g-and-k: x = A + B (1 + c tanh(g z / 2)) (1 + z^2)^k z; rho_j = |x_(rank_j) - obs_j|.
+// Thread-per-particle stopgap: insertion sort in private memory (the wave-cooperative
+// ranking kernel replaces this; see DESIGN.md "next").
+template <int D, int S>
+struct Sim<SABC_MODEL_GK, D, S> {
+  static constexpr int kMaxDraws = 128;
+  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                             double *rho) {
+    int n_draws = (int)m.p[0];
+    if (n_draws > kMaxDraws) n_draws = kMaxDraws;
+    const double c = m.p[1];
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    double x[kMaxDraws];
+    for (int k = 0; k < n_draws; ++k) {
+      const double z = ns.next();
+      const double v = th[0] + th[1] * (1.0 + c * tanh(th[2] * z / 2.0)) * pow(1.0 + z * z, th[3]) * z;
+      int j = k;
+      while (j > 0 && x[j - 1] > v) { x[j] = x[j - 1]; --j; }   // NaN stays where it is inserted
+      x[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int rank = (int)m.p[2 + j];
+      rho[j] = finite_or_big(fabs(x[rank - 1] - m.p[2 + S + j]));
+    }
+  }
+};
+
+// stochastic Lotka-Volterra, Euler-Maruyama; rho = |mean/sd of prey and predator paths - obs|
+template <int D, int S>
+struct Sim<SABC_MODEL_LV, D, S> {
+  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                             double *rho) {
+    const int n_steps = (int)m.p[0];
+    const double dt = m.p[1], sg = m.p[2];
+    double X = m.p[3], Y = m.p[4];
+    const double sq = sqrt(dt);
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    double SX = 0, QX = 0, SY = 0, QY = 0;
+    for (int t = 0; t < n_steps; ++t) {
+      double z1, z2;
+      ns.pair(z1, z2);
+      const double xy = X * Y;
+      const double dX = (th[0] * X - th[1] * xy) * dt + sg * X * sq * z1;
+      const double dY = (th[1] * xy - th[2] * Y) * dt + sg * Y * sq * z2;
+      X = fmax(X + dX, 0.0);
+      Y = fmax(Y + dY, 0.0);
+      SX += X; QX += X * X; SY += Y; QY += Y * Y;
+    }
+    const double mX = SX / n_steps, mY = SY / n_steps;
+    const double vX = (QX - SX * mX) / (n_steps - 1), vY = (QY - SY * mY) / (n_steps - 1);
+    const double st[4] = {mX, sqrt(fmax(vX, 0.0)), mY, sqrt(fmax(vY, 0.0))};
+#pragma unroll
+    for (int j = 0; j < S; ++j) rho[j] = finite_or_big(fabs(st[j < 4 ? j : 3] - m.p[5 + j]));
+  }
+};
+
+}  // namespace sabc

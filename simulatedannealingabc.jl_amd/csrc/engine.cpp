@@ -1,0 +1,339 @@
+// engine.cpp -- see engine.hpp.  Line references are to the reference checkout
+// (src/SimulatedAnnealingABC.jl unless a file is named).
+#include "engine.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "host_math.hpp"
+
+namespace sabc {
+
+Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cfg_(cfg), be_(backend), coll_(coll) {
+  std::memset(&m_, 0, sizeof(m_));
+  m_.model_id = cfg.model_id;
+  m_.d = cfg.n_para;
+  m_.s = cfg.n_stats;
+  m_.n_model_params = cfg.n_model_params;
+  for (int i = 0; i < SABC_MAX_MODEL_PARAMS; ++i) m_.p[i] = cfg.model_params[i];
+  for (int k = 0; k < kMaxPara; ++k) {
+    m_.prior_kind[k] = cfg.prior_kind[k];
+    m_.prior_a[k] = cfg.prior_a[k];
+    m_.prior_b[k] = cfg.prior_b[k];
+  }
+  m_.seed = cfg.seed;
+  const int world = cfg.world < 1 ? 1 : cfg.world;
+  sh_ = make_shard(cfg.n_particles, cfg.rank, world);
+  for (int i = 0; i < kMaxPara * kMaxPara; ++i) sigma_[i] = -1.0;   // proposals.jl:32,34 sentinel
+}
+
+int Engine::validate() {
+  if (cfg_.abi_version != SABC_ABI_VERSION) return fail(SABC_ERR_BAD_CONFIG, "sabc_config.abi_version mismatch");
+  if (!(cfg_.algorithm == SABC_ALG_SINGLE_EPS || cfg_.algorithm == SABC_ALG_MULTI_EPS))
+    return fail(SABC_ERR_BAD_ALGORITHM, "Argument `algorithm` must be :multi_eps or :single_eps!");   // :462-464
+  if (cfg_.n_particles < 1) return fail(SABC_ERR_BAD_CONFIG, "n_particles must be positive");
+  const int d = cfg_.n_para, s = cfg_.n_stats;
+  if (d < 1 || d > kMaxPara || s < 1 || s > kMaxStats) return fail(SABC_ERR_BAD_CONFIG, "n_para / n_stats out of range");
+  if (cfg_.world < 1 || cfg_.rank < 0 || cfg_.rank >= cfg_.world) return fail(SABC_ERR_BAD_CONFIG, "bad rank / world");
+  if (cfg_.world > 1)
+    for (int r = 0; r < cfg_.world; ++r)
+      if (shard_n_local(sh_, r) < 2) return fail(SABC_ERR_BAD_CONFIG, "every shard needs at least two particles");
+  const double *p = cfg_.model_params;
+  bool ok = false;
+  switch (cfg_.model_id) {
+    case SABC_MODEL_GAUSS_IID:
+      ok = (d == 1 || d == 2) && (s == 1 || s == 2) && cfg_.n_model_params >= 4 && p[0] >= 1;
+      break;
+    case SABC_MODEL_GAUSS2D:
+      ok = d == 2 && s == 3 && cfg_.n_model_params >= 6 && p[0] >= 2 && std::fabs(p[1]) < 1.0;
+      break;
+    case SABC_MODEL_GK:
+      ok = d == 4 && s == 4 && cfg_.n_model_params >= 10 && p[0] >= 1 && p[0] <= 128;
+      for (int j = 0; ok && j < 4; ++j) ok = p[2 + j] >= 1 && p[2 + j] <= p[0];
+      break;
+    case SABC_MODEL_LV:
+      ok = d == 3 && s == 4 && cfg_.n_model_params >= 9 && p[0] >= 2 && p[1] > 0;
+      break;
+    default:
+      ok = false;
+  }
+  if (!ok) return fail(SABC_ERR_BAD_CONFIG, "unknown model id or model parameters inconsistent with n_para / n_stats");
+  for (int k = 0; k < d; ++k) {
+    if (cfg_.prior_kind[k] == SABC_PRIOR_NORMAL) {
+      if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Normal prior needs sigma > 0");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_UNIFORM) {
+      if (!(cfg_.prior_b[k] > cfg_.prior_a[k])) return fail(SABC_ERR_BAD_CONFIG, "Uniform prior needs upper > lower");
+    } else {
+      return fail(SABC_ERR_BAD_CONFIG, "unknown prior kind");
+    }
+  }
+  np_ = n_partials(d, s);
+  eps_len_ = cfg_.algorithm == SABC_ALG_MULTI_EPS ? s : 1;
+  return 0;
+}
+
+void Engine::counters(int64_t out[4]) const {
+  out[0] = n_simulation_; out[1] = n_accept_; out[2] = n_resampling_; out[3] = n_population_updates_;
+}
+void Engine::set_counters(const int64_t in[4]) {
+  n_simulation_ = in[0]; n_accept_ = in[1]; n_resampling_ = in[2]; n_population_updates_ = in[3];
+}
+int Engine::set_eps(const double *e, int len) {
+  if (len != eps_len_) return fail(SABC_ERR_BAD_CONFIG, "epsilon length does not match the algorithm");
+  for (int i = 0; i < len; ++i) eps_[i] = e[i];
+  return 0;
+}
+void Engine::history(double *e, double *u, double *r) const {
+  if (e) std::memcpy(e, eps_hist_.data(), eps_hist_.size() * sizeof(double));
+  if (u) std::memcpy(u, u_hist_.data(), u_hist_.size() * sizeof(double));
+  if (r) std::memcpy(r, rho_hist_.data(), rho_hist_.size() * sizeof(double));
+}
+
+// block partials -> shard sums -> (allreduce over shards) -> host
+int Engine::global_sums(int64_t rows) {
+  int rc = be_->reduce_partials(rows);
+  if (rc) return fail(SABC_ERR_HIP, "reduce_partials failed");
+  if (sh_.world > 1) {
+    rc = coll_->allreduce_sum(be_->sums_buffer(), np_);
+    if (rc) return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
+  }
+  rc = be_->read_sums(sums_);
+  if (rc) return fail(SABC_ERR_HIP, "reading the population sums failed");
+  return 0;
+}
+
+StepCtrl Engine::make_ctrl(const sabc_update_args *a, uint64_t iter) const {
+  StepCtrl c;
+  std::memset(&c, 0, sizeof(c));
+  c.iter = iter;
+  c.eps_len = eps_len_;
+  for (int j = 0; j < kMaxStats; ++j) c.eps[j] = eps_[j];
+  if (a) { c.prop_kind = a->proposal_kind; c.prop_p0 = a->proposal_p0; c.prop_p1 = a->proposal_p1; }
+  const int d = m_.d;
+  for (int i = 0; i < d * d; ++i) c.chol[i] = chol_[i];
+  for (int k = 0; k < d; ++k) c.pivot[k] = pivot_[k];
+  return c;
+}
+
+int Engine::stats_pass() {
+  const StepCtrl c = make_ctrl(nullptr, 0);
+  int64_t rows = 0;
+  if (be_->stats(c, &rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
+  return global_sums(rows);
+}
+
+int Engine::recenter() {
+  const int d = m_.d, s = m_.s;
+  const double n = (double)sh_.n_global;
+  for (int k = 0; k < d; ++k) pivot_[k] += sums_[1 + 2 * s + k] / n;
+  return stats_pass();
+}
+
+// update_proposal!(::RandomWalk): proposals.jl:46-48 (n-D) and :58-60 (1-D)
+int Engine::update_proposal(const sabc_update_args &a) {
+  if (a.proposal_kind != SABC_PROP_RANDOMWALK) return 0;     // proposals.jl:116,150
+  const int d = m_.d, s = m_.s;
+  const double *S = &sums_[1 + 2 * s], *Q = &sums_[1 + 2 * s + d];
+  double cov[kMaxPara * kMaxPara];
+  hostmath::cov_from_sums(S, Q, d, (double)sh_.n_global, cov);
+  if (d == 1) {
+    sigma_[0] = a.proposal_p0 * cov[0];                      // proposals.jl:59
+    if (sigma_[0] < 0.0) return fail(SABC_ERR_NOT_POSDEF, "RandomWalk variance is negative");
+    chol_[0] = std::sqrt(sigma_[0]);                         // proposals.jl:54
+    return 0;
+  }
+  for (int k = 0; k < d; ++k)
+    for (int l = 0; l < d; ++l) sigma_[k * d + l] = a.proposal_p0 * (cov[k * d + l] + (k == l ? 1e-8 : 0.0));   // :47
+  if (!hostmath::cholesky(sigma_, d, chol_))
+    return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
+  return 0;
+}
+
+// :200-204 and :350-354
+int Engine::update_epsilon(double v) {
+  const int s = m_.s;
+  const double n = (double)sh_.n_global;
+  if (cfg_.algorithm == SABC_ALG_MULTI_EPS) {
+    double ubar[kMaxStats];
+    for (int j = 0; j < s; ++j) ubar[j] = sums_[1 + j] / n;
+    if (!hostmath::eps_multi(ubar, s, v, eps_))
+      return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
+  } else {
+    double tot = 0.0;
+    for (int j = 0; j < s; ++j) tot += sums_[1 + j];
+    eps_[0] = hostmath::eps_single(tot / (n * (double)s), v);   // mean(u) over all n*s entries, :203,353
+  }
+  return 0;
+}
+
+// resample_population, :124-137.  Needs sums_ to hold the CURRENT sum of u; leaves the sums
+// of the resampled population in sums_.
+int Engine::resample(double delta, uint64_t iter) {
+  const int d = m_.d, s = m_.s;
+  const double n = (double)sh_.n_global;
+  double ubar[kMaxStats] = {0};
+  for (int j = 0; j < s; ++j) ubar[j] = sums_[1 + j] / n;                   // :126
+  if (be_->resample_weights(ubar, delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :127
+  const int64_t rows = d + s + 1;
+  const double *gathered = be_->pop_block();
+  if (sh_.world > 1) {
+    double *g = be_->gather_buffer((int64_t)sh_.world * rows * sh_.cap);
+    if (!g) return fail(SABC_ERR_HIP, "out of memory for the resample gather buffer");
+    if (coll_->allgather(be_->pop_block(), g, rows * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of the population failed");
+    gathered = g;
+  }
+  if (be_->resample_draw(gathered, iter)) return fail(SABC_ERR_HIP, "resample draw kernel failed");   // :129-132
+  return stats_pass();
+}
+
+void Engine::push_history() {
+  const int s = m_.s;
+  const double n = (double)sh_.n_global;
+  for (int i = 0; i < eps_len_; ++i) eps_hist_.push_back(eps_[i]);          // :368
+  for (int j = 0; j < s; ++j) u_hist_.push_back(sums_[1 + j] / n);          // :369
+  for (int j = 0; j < s; ++j) rho_hist_.push_back(sums_[1 + s + j] / n);    // :370
+}
+
+PartnerView Engine::partner_view(const double *base, int64_t rank_stride, int inactive_half) const {
+  PartnerView pv;
+  std::memset(&pv, 0, sizeof(pv));
+  const int64_t n_full = sh_.cap, n_last = shard_n_local(sh_, sh_.world - 1);
+  const int64_t h_full = n_full / 2, h_last = n_last / 2;
+  pv.base = base;
+  pv.rank_stride = rank_stride;
+  pv.cap = sh_.cap;
+  pv.world = sh_.world;
+  if (inactive_half == 1) {        // second halves are frozen
+    pv.off_full = h_full; pv.m_full = n_full - h_full;
+    pv.off_last = h_last; pv.m_last = n_last - h_last;
+  } else {
+    pv.off_full = 0; pv.m_full = h_full;
+    pv.off_last = 0; pv.m_last = h_last;
+  }
+  if (sh_.world == 1) { pv.m_full = pv.m_last; pv.off_full = pv.off_last; }
+  pv.m_total = (int64_t)(sh_.world - 1) * pv.m_full + pv.m_last;
+  if (pv.m_full < 1) pv.m_full = 1;
+  return pv;
+}
+
+// ------------------------------------------------------------------------------------------
+// initialization(), :151-227
+// ------------------------------------------------------------------------------------------
+int Engine::initialize(int64_t n_simulation) {
+  const int s = m_.s;
+  if (n_simulation < sh_.n_global) {                                        // :155-156
+    char buf[160];
+    std::snprintf(buf, sizeof(buf), "`n_simulation = %lld` is too small for %lld particles.", (long long)n_simulation,
+                  (long long)sh_.n_global);
+    return fail(SABC_ERR_NSIM_TOO_SMALL, buf);
+  }
+  if (be_->prior_simulate()) return fail(SABC_ERR_HIP, "prior sample / simulate kernel failed");   // :172-179
+  const double *gathered_rho = be_->rho_block();
+  if (sh_.world > 1) {
+    double *g = be_->gather_buffer((int64_t)sh_.world * s * sh_.cap);
+    if (!g) return fail(SABC_ERR_HIP, "out of memory for the rho gather buffer");
+    if (coll_->allgather(be_->rho_block(), g, (int64_t)s * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of rho failed");
+    gathered_rho = g;
+  }
+  int any_negative = 0;
+  if (be_->build_cdf(gathered_rho, cdf_len_, &any_negative)) return fail(SABC_ERR_HIP, "ECDF build failed");   // :187
+  if (any_negative) return fail(SABC_ERR_NEG_DISTANCE, "Negative distances are not allowed!");             // :185
+  for (int j = 0; j < s; ++j)
+    if (cdf_len_[j] < 3) return fail(SABC_ERR_EMPTY_CDF, "all prior distances of one statistic are zero");
+  if (be_->cdf_population()) return fail(SABC_ERR_HIP, "ECDF transform kernel failed");                   // :190-192
+  for (int k = 0; k < kMaxPara; ++k) pivot_[k] = 0.0;
+  int rc = stats_pass();
+  if (rc) return rc;
+  rc = resample(cfg_.delta, 0);                                             // :197
+  if (rc) return rc;
+  rc = update_epsilon(cfg_.v);                                              // :200-204
+  if (rc) return rc;
+  clear_history();
+  push_history();                                                           // :180,207-208
+  n_simulation_ = sh_.n_global;                                             // :213
+  n_accept_ = 0; n_resampling_ = 1; n_population_updates_ = 0;              // :223
+  initialized_ = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// update_population!(), :251-402
+// ------------------------------------------------------------------------------------------
+int Engine::update(const sabc_update_args &a) {
+  if (!initialized_) return fail(SABC_ERR_STATE, "population is not initialized");
+  if (!(a.v > 0)) return fail(SABC_ERR_BAD_V, "Annealing speed `v` must be positive.");                 // :261
+  if (!(a.delta > 0)) return fail(SABC_ERR_BAD_DELTA, "Resamping intensity `δ` must be positive.");     // :262
+  if (a.proposal_kind < SABC_PROP_RANDOMWALK || a.proposal_kind > SABC_PROP_STRETCH)
+    return fail(SABC_ERR_BAD_CONFIG, "unknown proposal kind");
+  if (a.proposal_kind == SABC_PROP_RANDOMWALK && !(a.proposal_p0 > 0 && a.proposal_p0 <= 1))
+    return fail(SABC_ERR_BAD_BETA, "Mixing parameter `β` must be between zero and one.");              // proposals.jl:30
+  if (a.n_simulation < 0) return fail(SABC_ERR_BAD_CONFIG, "n_simulation must not be negative");
+  const int s = m_.s, d = m_.d;
+  const int64_t N = sh_.n_global;
+  const int64_t n_pop = a.n_simulation / N;                                 // :275
+  const int64_t n_updates = n_pop * N;                                      // :276
+  int64_t last_checkpoint = 0;                                              // :277
+  int rc;
+  if (a.proposal_kind == SABC_PROP_RANDOMWALK) {                            // :284
+    if ((rc = stats_pass())) return rc;
+    if ((rc = recenter())) return rc;
+    if ((rc = update_proposal(a))) return rc;
+  }
+  const bool two_phase = a.proposal_kind != SABC_PROP_RANDOMWALK;
+  if (n_pop > 0 && two_phase) {
+    const int64_t need = a.proposal_kind == SABC_PROP_DIFFEVO ? 2 : 1;
+    for (int half = 0; half < 2; ++half)
+      if (partner_view(nullptr, 0, half).m_total < need)
+        return fail(SABC_ERR_BAD_CONFIG, "too few particles in a half batch for this proposal");
+  }
+  const int64_t h = sh_.n_local / 2;
+  for (int64_t ix = 1; ix <= n_pop; ++ix) {                                 // :294
+    const uint64_t iter = (uint64_t)(n_population_updates_ + ix);
+    const StepCtrl c = make_ctrl(&a, iter);
+    int64_t rows = 0, r = 0;
+    if (!two_phase) {
+      // RandomWalk ignores the inactive half (proposals.jl:40,52), so both half batches of :304
+      // are independent given eps and Sigma: one launch over the whole shard is the same update.
+      PartnerView none;
+      std::memset(&none, 0, sizeof(none));
+      if (be_->update_range(c, none, 0, sh_.n_local, 0, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
+      rows = r;
+    } else {
+      for (int half = 0; half < 2; ++half) {                                // :300-304
+        const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
+        const double *base = be_->pop_block();
+        int64_t stride = 0;
+        if (sh_.world > 1) {        // partners come from the inactive halves of ALL shards
+          double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
+          if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
+          if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
+          base = g;
+          stride = (int64_t)d * sh_.cap;
+        }
+        const PartnerView pv = partner_view(base, stride, 1 - half);
+        if (be_->update_range(c, pv, lo, cnt, rows, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
+        rows += r;
+      }
+    }
+    if ((rc = global_sums(rows))) return rc;
+    n_accept_ += (int64_t)std::llround(sums_[0]);                           // :334
+    if ((double)n_accept_ >= (double)(n_resampling_ + 1) * a.resample) {    // :340
+      if ((rc = resample(a.delta, iter))) return rc;                        // :341
+      n_resampling_ += 1;                                                   // :342
+    }
+    if ((rc = update_proposal(a))) return rc;                               // :348
+    if ((rc = update_epsilon(a.v))) return rc;                              // :350-354
+    for (int k = 0; k < d; ++k) pivot_[k] += sums_[1 + 2 * s + k] / (double)N;   // keep the moment sums centred
+    if (a.checkpoint_history > 0 && ix % a.checkpoint_history == 0) {       // :367-372
+      push_history();
+      last_checkpoint = ix;
+    }
+  }
+  if (last_checkpoint != n_pop) push_history();                             // :378-382
+  n_simulation_ += n_updates;                                               // :391
+  n_population_updates_ += n_pop;                                           // :394
+  return 0;
+}
+
+}  // namespace sabc

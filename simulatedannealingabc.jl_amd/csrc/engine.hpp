@@ -1,0 +1,114 @@
+// engine.hpp -- host side of the population update loop: what `sabc`, `initialization`,
+// `update_population!`, `resample_population`, `update_epsilon_*` and `update_proposal!`
+// (SimulatedAnnealingABC.jl:92-137,151-227,251-402; proposals.jl:46-60) do BETWEEN the
+// per-particle kernels.  Pure C++ against two small interfaces:
+//   Backend      -- where the particles live and the kernels that touch them (HipBackend in
+//                   hip_backend.hip is the product; tests/ plugs a CPU stand-in built on the oracle
+//                   to exercise this file without a GPU);
+//   Collectives  -- allreduce / allgather across shards (one process per GPU).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "sabc_types.hpp"
+
+namespace sabc {
+
+class Collectives {
+ public:
+  virtual ~Collectives() = default;
+  // pointers are in the Backend's memory space (device memory for HipBackend)
+  virtual int allreduce_sum(double *buf, int64_t count) = 0;
+  virtual int allgather(const double *send, double *recv, int64_t count_per_rank) = 0;
+};
+
+class Backend {
+ public:
+  virtual ~Backend() = default;
+  virtual int allocate(const ModelDesc &m, const Shard &sh) = 0;
+  // blocks in backend memory; pop_block() may change after resample_draw()
+  virtual double *pop_block() = 0;                  // [(d+s+1)][cap]: theta rows, u rows, weight row
+  virtual double *rho_block() = 0;                  // [s][cap]
+  virtual double *sums_buffer() = 0;                // [np]
+  virtual double *gather_buffer(int64_t doubles) = 0;
+  // K1
+  virtual int prior_simulate() = 0;
+  // K2: gathered_rho is [world][s][cap]; len_out[j] = knot count (<= 0: no positive entry)
+  virtual int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) = 0;
+  // K3
+  virtual int cdf_population() = 0;
+  // K4 on local particles [lo, lo+cnt); partial rows start at row0; returns rows written
+  virtual int update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+                           int64_t *rows_out) = 0;
+  virtual int stats(const StepCtrl &c, int64_t *rows_out) = 0;
+  virtual int reduce_partials(int64_t rows) = 0;    // -> sums_buffer()
+  virtual int read_sums(double *host_out) = 0;      // blocks until the stream has drained
+  // K5
+  virtual int resample_weights(const double *ubar, double delta) = 0;
+  virtual int resample_draw(const double *gathered_pop, uint64_t iter) = 0;
+  virtual double last_ess() = 0;
+  // state import/export (host buffers, column-major n_local x k)
+  virtual int download(double *theta, double *u, double *rho) = 0;
+  virtual int upload(const double *theta, const double *u, const double *rho) = 0;
+  virtual int get_knots(int stat, double *out, int64_t len) = 0;
+  virtual int set_knots(int stat, const double *knots, int64_t len) = 0;
+};
+
+class Engine {
+ public:
+  Engine(const sabc_config &cfg, Backend *backend, Collectives *coll);
+
+  int validate();                                   // config errors found at create time
+  int initialize(int64_t n_simulation);             // initialization(), :151-227
+  int update(const sabc_update_args &a);            // update_population!(), :251-402
+
+  const std::string &error() const { return err_; }
+  const Shard &shard() const { return sh_; }
+  const ModelDesc &model() const { return m_; }
+  int eps_len() const { return eps_len_; }
+  const double *eps() const { return eps_; }
+  int set_eps(const double *e, int len);
+  void counters(int64_t out[4]) const;
+  void set_counters(const int64_t in[4]);
+  int64_t history_len() const { return (int64_t)(eps_hist_.size() / (size_t)eps_len_); }
+  void history(double *e, double *u, double *r) const;
+  void clear_history() { eps_hist_.clear(); u_hist_.clear(); rho_hist_.clear(); }
+  const int64_t *cdf_len() const { return cdf_len_; }
+  void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
+  const double *sigma() const { return sigma_; }
+  bool initialized() const { return initialized_; }
+  void mark_initialized() { initialized_ = true; }
+  void set_collectives(Collectives *c) { coll_ = c; }
+
+ private:
+  int fail(int code, const std::string &msg) { err_ = msg; return code; }
+  int global_sums(int64_t rows);                    // reduce -> allreduce -> host sums_
+  int stats_pass();                                 // sums_ of the population as it stands
+  int recenter();                                   // pivot := population mean
+  int update_proposal(const sabc_update_args &a);   // proposals.jl:46-48,58-60 from sums_
+  int update_epsilon(double v);                     // :200-204, :350-354 from sums_
+  int resample(double delta, uint64_t iter);        // :124-137
+  void push_history();                              // :367-372 from sums_
+  StepCtrl make_ctrl(const sabc_update_args *a, uint64_t iter) const;
+  PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
+
+  sabc_config cfg_;
+  ModelDesc m_;
+  Shard sh_;
+  Backend *be_;
+  Collectives *coll_;
+  std::string err_;
+  bool initialized_ = false;
+
+  int np_ = 0, eps_len_ = 1;
+  double eps_[kMaxStats] = {0};
+  double sums_[kMaxPartials] = {0};
+  double pivot_[kMaxPara] = {0};
+  double sigma_[kMaxPara * kMaxPara];
+  double chol_[kMaxPara * kMaxPara] = {0};
+  int64_t cdf_len_[kMaxStats] = {0};
+  int64_t n_simulation_ = 0, n_accept_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
+  std::vector<double> eps_hist_, u_hist_, rho_hist_;
+};
+
+}  // namespace sabc

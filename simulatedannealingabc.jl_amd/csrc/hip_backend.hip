@@ -1,0 +1,325 @@
+// hip_backend.hip -- HipBackend: owns the shard in HBM and launches the gfx950 kernels.
+#include "hip_backend.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+
+namespace sabc {
+
+#define HB_CHECK(expr, what)                       \
+  do {                                             \
+    const int rc_ = check((expr), (what));         \
+    if (rc_) return rc_;                           \
+  } while (0)
+
+#define HB_LAUNCH(expr, what)                      \
+  do {                                             \
+    const int e_ = (expr);                         \
+    if (e_) return check((hipError_t)e_, (what));  \
+  } while (0)
+
+HipBackend::HipBackend(int device) : device_(device) {}
+
+HipBackend::~HipBackend() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto &v : ev_)
+    for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, sums_dev_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  for (double *p : dev)
+    if (p) (void)hipFree(p);
+  if (sort_tmp_) (void)hipFree(sort_tmp_);
+  if (meta_dev_) (void)hipFree(meta_dev_);
+  if (sums_host_) (void)hipHostFree(sums_host_);
+  if (totals_host_) (void)hipHostFree(totals_host_);
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+}
+
+int HipBackend::check(hipError_t e, const char *what) {
+  if (e == hipSuccess) return 0;
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  err_ = buf;
+  return -1;
+}
+
+int HipBackend::set_stream(hipStream_t s) {
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  if (stream_) HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  stream_ = s;
+  own_stream_ = false;
+  return 0;
+}
+
+PopPtrs HipBackend::pop_ptrs(int which) const {
+  PopPtrs pp;
+  pp.pop = pop_[which];
+  pp.rho = rho_;
+  pp.cap = sh_.cap;
+  pp.n_local = sh_.n_local;
+  pp.gid0 = sh_.gid0;
+  return pp;
+}
+
+CdfPtrs HipBackend::cdf_ptrs() const {
+  CdfPtrs c;
+  c.knots = knots_;
+  c.stride = knot_stride_;
+  for (int j = 0; j < kMaxStats; ++j) c.len[j] = cdf_len_[j];
+  return c;
+}
+
+int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
+  m_ = m;
+  sh_ = sh;
+  np_ = n_partials(m.d, m.s);
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  if (!stream_) {
+    HB_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    own_stream_ = true;
+  }
+  const size_t cap = (size_t)sh.cap, N = (size_t)sh.n_global;
+  const size_t rows = (size_t)(m.d + m.s + 1);
+  for (int b = 0; b < 2; ++b) {
+    HB_CHECK(hipMalloc((void **)&pop_[b], rows * cap * sizeof(double)), "hipMalloc(pop)");
+    HB_CHECK(hipMemsetAsync(pop_[b], 0, rows * cap * sizeof(double), stream_), "hipMemset(pop)");
+  }
+  HB_CHECK(hipMalloc((void **)&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
+  HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
+  knot_stride_ = (int64_t)N + 2;
+  HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (N + 2) * sizeof(double)), "hipMalloc(knots)");
+  partial_rows_ = 2 * n_blocks(sh.cap) + 4;
+  HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");
+  HB_CHECK(hipMalloc((void **)&sums_dev_, kMaxPartials * sizeof(double)), "hipMalloc(sums)");
+  HB_CHECK(hipHostMalloc((void **)&sums_host_, kMaxPartials * sizeof(double)), "hipHostMalloc(sums)");
+  const size_t nb = (N + kScanChunk - 1) / kScanChunk;
+  HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
+  HB_CHECK(hipMalloc((void **)&block_sums_, 2 * nb * sizeof(double)), "hipMalloc(block_sums)");
+  HB_CHECK(hipMalloc((void **)&totals_dev_, 2 * sizeof(double)), "hipMalloc(totals)");
+  HB_CHECK(hipHostMalloc((void **)&totals_host_, 2 * sizeof(double)), "hipHostMalloc(totals)");
+  totals_host_[0] = totals_host_[1] = 0.0;
+  HB_CHECK(hipMalloc((void **)&meta_dev_, 2 * kMaxStats * sizeof(int64_t)), "hipMalloc(meta)");
+  return 0;
+}
+
+double *HipBackend::gather_buffer(int64_t doubles) {
+  if (doubles > gather_cap_) {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (gather_) (void)hipFree(gather_);
+    gather_ = nullptr;
+    gather_cap_ = 0;
+    if (hipMalloc((void **)&gather_, (size_t)doubles * sizeof(double)) != hipSuccess) return nullptr;
+    gather_cap_ = doubles;
+  }
+  return gather_;
+}
+
+double *HipBackend::host_stage(int64_t doubles) {
+  if ((int64_t)stage_.size() < doubles) stage_.resize((size_t)doubles);
+  return stage_.data();
+}
+
+void HipBackend::profile_enable(bool on) {
+  prof_ = on;
+  if (on)
+    for (int k = 0; k < SABC_KERNEL_COUNT; ++k) { prof_ms_[k] = 0.0; prof_n_[k] = 0; }
+}
+
+void HipBackend::prof_begin(int kernel) {
+  if (!prof_) return;
+  EvPair e;
+  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+  (void)hipEventRecord(e.a, stream_);
+  ev_[kernel].push_back(e);
+}
+
+void HipBackend::prof_end(int kernel) {
+  if (!prof_ || ev_[kernel].empty()) return;
+  (void)hipEventRecord(ev_[kernel].back().b, stream_);
+}
+
+int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
+  if (kernel < 0 || kernel >= SABC_KERNEL_COUNT) return -1;
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  for (auto &e : ev_[kernel]) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { prof_ms_[kernel] += ms; prof_n_[kernel] += 1; }
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  ev_[kernel].clear();
+  if (total_ms) *total_ms = prof_ms_[kernel];
+  if (launches) *launches = prof_n_[kernel];
+  return 0;
+}
+
+int HipBackend::prior_simulate() {
+  prof_begin(SABC_KERNEL_INIT);
+  HB_LAUNCH(launch_prior_simulate(m_, pop_ptrs(cur_), stream_), "k_prior_simulate");
+  prof_end(SABC_KERNEL_INIT);
+  return 0;
+}
+
+int HipBackend::build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) {
+  const int64_t N = sh_.n_global;
+  if (!col_a_) {
+    HB_CHECK(hipMalloc((void **)&col_a_, (size_t)N * sizeof(double)), "hipMalloc(col_a)");
+    HB_CHECK(hipMalloc((void **)&col_b_, (size_t)N * sizeof(double)), "hipMalloc(col_b)");
+    size_t bytes = 0;
+    HB_LAUNCH(sort_f64(col_a_, col_b_, N, nullptr, &bytes, stream_), "radix sort size query");
+    sort_tmp_bytes_ = bytes ? bytes : 16;
+    HB_CHECK(hipMalloc(&sort_tmp_, sort_tmp_bytes_), "hipMalloc(sort_tmp)");
+  }
+  for (int j = 0; j < m_.s; ++j) {
+    HB_LAUNCH(launch_compact_column(gathered_rho, m_.s, j, sh_.cap, N, col_a_, stream_), "k_compact_column");
+    size_t bytes = sort_tmp_bytes_;
+    HB_LAUNCH(sort_f64(col_a_, col_b_, N, sort_tmp_, &bytes, stream_), "radix sort");
+    HB_LAUNCH(launch_cdf_knots(col_b_, N, knots_ + (int64_t)j * knot_stride_, meta_dev_ + 2 * j, stream_), "k_cdf_knots");
+  }
+  int64_t meta[2 * kMaxStats];
+  HB_CHECK(hipMemcpyAsync(meta, meta_dev_, 2 * (size_t)m_.s * sizeof(int64_t), hipMemcpyDeviceToHost, stream_), "memcpy(meta)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  *any_negative = 0;
+  for (int j = 0; j < m_.s; ++j) {
+    const int64_t mpos = N - meta[2 * j];
+    cdf_len_[j] = mpos > 0 ? mpos + 2 : 0;
+    len_out[j] = cdf_len_[j];
+    if (meta[2 * j + 1]) *any_negative = 1;
+  }
+  // the sort scratch is only needed once per result
+  (void)hipFree(col_a_); (void)hipFree(col_b_); (void)hipFree(sort_tmp_);
+  col_a_ = col_b_ = nullptr; sort_tmp_ = nullptr;
+  return 0;
+}
+
+int HipBackend::cdf_population() {
+  HB_LAUNCH(launch_cdf_population(m_, pop_ptrs(cur_), cdf_ptrs(), stream_), "k_cdf_population");
+  return 0;
+}
+
+int HipBackend::update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+                             int64_t *rows_out) {
+  const int64_t rows = n_blocks(cnt);
+  if (lo < 0 || cnt < 0 || lo + cnt > sh_.n_local || row0 + rows > partial_rows_) {
+    err_ = "update_range: range outside the shard";
+    return -1;
+  }
+  prof_begin(SABC_KERNEL_UPDATE);
+  HB_LAUNCH(launch_update(m_, c, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_), "k_update");
+  prof_end(SABC_KERNEL_UPDATE);
+  *rows_out = rows;
+  return 0;
+}
+
+int HipBackend::stats(const StepCtrl &c, int64_t *rows_out) {
+  HB_LAUNCH(launch_stats(m_, c, pop_ptrs(cur_), partials_, stream_), "k_stats");
+  *rows_out = n_blocks(sh_.n_local);
+  return 0;
+}
+
+int HipBackend::reduce_partials(int64_t rows) {
+  prof_begin(SABC_KERNEL_REDUCE);
+  HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, sums_dev_, stream_), "k_reduce_partials");
+  prof_end(SABC_KERNEL_REDUCE);
+  return 0;
+}
+
+int HipBackend::read_sums(double *host_out) {
+  HB_CHECK(hipMemcpyAsync(sums_host_, sums_dev_, (size_t)np_ * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(sums)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  std::memcpy(host_out, sums_host_, (size_t)np_ * sizeof(double));
+  return 0;
+}
+
+int HipBackend::resample_weights(const double *ubar, double delta) {
+  Vec8 ub;
+  for (int j = 0; j < kMaxStats; ++j) ub.v[j] = j < m_.s ? ubar[j] : 1.0;
+  HB_LAUNCH(launch_resample_weights(m_, pop_ptrs(cur_), ub, delta, stream_), "k_resample_weights");
+  return 0;
+}
+
+int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
+  const int rows = m_.d + m_.s + 1;
+  prof_begin(SABC_KERNEL_RESAMPLE);
+  HB_LAUNCH(launch_weight_scan(gathered_pop, rows, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, stream_), "weight scan");
+  const int nxt = 1 - cur_;
+  HB_LAUNCH(launch_resample_gather(m_, gathered_pop, rows, sh_.cap, sh_.n_global, cum_, totals_dev_, iter, pop_ptrs(nxt), stream_),
+            "k_resample_gather");
+  prof_end(SABC_KERNEL_RESAMPLE);
+  HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
+  cur_ = nxt;
+  return 0;
+}
+
+double HipBackend::last_ess() {
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  return totals_host_ && totals_host_[1] > 0 ? totals_host_[0] * totals_host_[0] / totals_host_[1] : 0.0;   // :134
+}
+
+int HipBackend::download(double *theta, double *u, double *rho) {
+  const size_t w = (size_t)sh_.n_local * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
+  if (sh_.n_local > 0) {
+    if (theta) HB_CHECK(hipMemcpy2DAsync(theta, w, pop_[cur_], pitch, w, (size_t)m_.d, hipMemcpyDeviceToHost, stream_), "download theta");
+    if (u) HB_CHECK(hipMemcpy2DAsync(u, w, pop_[cur_] + (size_t)m_.d * sh_.cap, pitch, w, (size_t)m_.s, hipMemcpyDeviceToHost, stream_), "download u");
+    if (rho) HB_CHECK(hipMemcpy2DAsync(rho, w, rho_, pitch, w, (size_t)m_.s, hipMemcpyDeviceToHost, stream_), "download rho");
+  }
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::upload(const double *theta, const double *u, const double *rho) {
+  const size_t w = (size_t)sh_.n_local * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
+  if (sh_.n_local > 0) {
+    if (theta) HB_CHECK(hipMemcpy2DAsync(pop_[cur_], pitch, theta, w, w, (size_t)m_.d, hipMemcpyHostToDevice, stream_), "upload theta");
+    if (u) HB_CHECK(hipMemcpy2DAsync(pop_[cur_] + (size_t)m_.d * sh_.cap, pitch, u, w, w, (size_t)m_.s, hipMemcpyHostToDevice, stream_), "upload u");
+    if (rho) HB_CHECK(hipMemcpy2DAsync(rho_, pitch, rho, w, w, (size_t)m_.s, hipMemcpyHostToDevice, stream_), "upload rho");
+  }
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::get_knots(int stat, double *out, int64_t len) {
+  if (stat < 0 || stat >= m_.s || len > cdf_len_[stat]) { err_ = "get_knots: bad statistic index or length"; return -1; }
+  HB_CHECK(hipMemcpyAsync(out, knots_ + (int64_t)stat * knot_stride_, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(knots)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::set_knots(int stat, const double *knots, int64_t len) {
+  if (stat < 0 || stat >= m_.s || len < 3 || len > knot_stride_) { err_ = "set_knots: bad statistic index or length"; return -1; }
+  HB_CHECK(hipMemcpyAsync(knots_ + (int64_t)stat * knot_stride_, knots, (size_t)len * sizeof(double), hipMemcpyHostToDevice, stream_), "memcpy(knots)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  cdf_len_[stat] = len;
+  return 0;
+}
+
+int HipBackend::cdf_apply_host(const double *rho, int64_t m, double *u_out) {
+  if (m <= 0) return 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  const size_t bytes = (size_t)m * m_.s * sizeof(double);
+  HB_CHECK(hipMalloc((void **)&d_in, bytes), "hipMalloc");
+  HB_CHECK(hipMalloc((void **)&d_out, bytes), "hipMalloc");
+  int rc = check(hipMemcpyAsync(d_in, rho, bytes, hipMemcpyHostToDevice, stream_), "memcpy");
+  if (!rc) rc = check((hipError_t)launch_cdf_apply_matrix(cdf_ptrs(), m_.s, d_in, m, d_out, stream_), "k_cdf_apply_matrix");
+  if (!rc) rc = check(hipMemcpyAsync(u_out, d_out, bytes, hipMemcpyDeviceToHost, stream_), "memcpy");
+  if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return rc;
+}
+
+int HipBackend::simulate_host(const double *theta, int64_t n, uint64_t pid0, uint64_t iter, double *rho_out) {
+  if (n <= 0) return 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  HB_CHECK(hipMalloc((void **)&d_in, (size_t)n * m_.d * sizeof(double)), "hipMalloc");
+  HB_CHECK(hipMalloc((void **)&d_out, (size_t)n * m_.s * sizeof(double)), "hipMalloc");
+  int rc = check(hipMemcpyAsync(d_in, theta, (size_t)n * m_.d * sizeof(double), hipMemcpyHostToDevice, stream_), "memcpy");
+  if (!rc) rc = check((hipError_t)launch_simulate_batch(m_, d_in, n, pid0, iter, d_out, stream_), "k_simulate_batch");
+  if (!rc) rc = check(hipMemcpyAsync(rho_out, d_out, (size_t)n * m_.s * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
+  if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return rc;
+}
+
+}  // namespace sabc

@@ -1,0 +1,88 @@
+// hip_backend.hpp -- the product Backend: particle shard resident in HBM, gfx950 kernels,
+// one HIP stream.  There is no CPU path behind it.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <string>
+#include <vector>
+#include "engine.hpp"
+#include "kernels.hpp"
+
+namespace sabc {
+
+class HipBackend : public Backend {
+ public:
+  explicit HipBackend(int device);
+  ~HipBackend() override;
+
+  int allocate(const ModelDesc &m, const Shard &sh) override;
+  double *pop_block() override { return pop_[cur_]; }
+  double *rho_block() override { return rho_; }
+  double *sums_buffer() override { return sums_dev_; }
+  double *gather_buffer(int64_t doubles) override;
+  int prior_simulate() override;
+  int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) override;
+  int cdf_population() override;
+  int update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+                   int64_t *rows_out) override;
+  int stats(const StepCtrl &c, int64_t *rows_out) override;
+  int reduce_partials(int64_t rows) override;
+  int read_sums(double *host_out) override;
+  int resample_weights(const double *ubar, double delta) override;
+  int resample_draw(const double *gathered_pop, uint64_t iter) override;
+  double last_ess() override;
+  int download(double *theta, double *u, double *rho) override;
+  int upload(const double *theta, const double *u, const double *rho) override;
+  int get_knots(int stat, double *out, int64_t len) override;
+  int set_knots(int stat, const double *knots, int64_t len) override;
+
+  // extras used by the C-ABI layer
+  int set_stream(hipStream_t s);
+  hipStream_t stream() const { return stream_; }
+  int device() const { return device_; }
+  const std::string &error() const { return err_; }
+  CdfPtrs cdf_ptrs() const;
+  void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
+  int cdf_apply_host(const double *rho, int64_t m, double *u_out);
+  int simulate_host(const double *theta, int64_t n, uint64_t pid0, uint64_t iter, double *rho_out);
+  void profile_enable(bool on);
+  int profile_get(int kernel, double *total_ms, int64_t *launches);
+  // host staging for collectives that cannot take device pointers
+  double *host_stage(int64_t doubles);
+
+ private:
+  int check(hipError_t e, const char *what);
+  PopPtrs pop_ptrs(int which) const;
+  void prof_begin(int kernel);
+  void prof_end(int kernel);
+
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  bool own_stream_ = false;
+  std::string err_;
+  ModelDesc m_{};
+  Shard sh_{};
+  int np_ = 0;
+  double *pop_[2] = {nullptr, nullptr};
+  int cur_ = 0;
+  double *rho_ = nullptr, *knots_ = nullptr;
+  int64_t knot_stride_ = 0;
+  int64_t cdf_len_[kMaxStats] = {0};
+  double *partials_ = nullptr;
+  int64_t partial_rows_ = 0;
+  double *sums_dev_ = nullptr, *sums_host_ = nullptr;
+  double *gather_ = nullptr;
+  int64_t gather_cap_ = 0;
+  double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr, *totals_host_ = nullptr;
+  double *col_a_ = nullptr, *col_b_ = nullptr;
+  void *sort_tmp_ = nullptr;
+  size_t sort_tmp_bytes_ = 0;
+  int64_t *meta_dev_ = nullptr;
+  std::vector<double> stage_;
+  bool prof_ = false;
+  struct EvPair { hipEvent_t a, b; };
+  std::vector<EvPair> ev_[SABC_KERNEL_COUNT];
+  double prof_ms_[SABC_KERNEL_COUNT] = {0};
+  int64_t prof_n_[SABC_KERNEL_COUNT] = {0};
+};
+
+}  // namespace sabc

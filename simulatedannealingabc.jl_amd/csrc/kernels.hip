@@ -1,0 +1,564 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the SABC particle-population update loop.
+//
+// Design notes (DESIGN.md has the long form):
+//  * one wavefront lane per particle; particle state is SoA ([row][cap]) so that the 64 lanes of a
+//    wave read/write 512 contiguous bytes per row;
+//  * no dense contraction anywhere -> MFMA deliberately unused; the kernel is bound by Philox
+//    integer multiplies and f64 log/sqrt/sincospi, not by HBM (40 algorithmic bytes per
+//    particle-simulation for d = s = 1);
+//  * the reductions the reference does in separate passes (n_accept :334, mean(u) :353, column
+//    means :369-370, cov(population) proposals.jl:47,59) are fused into the update kernel:
+//    wave shuffles -> LDS across the 4 waves of a block -> one partial row per block, summed
+//    later in a fixed order (bitwise reproducible for a given grid).
+#include <hip/hip_runtime.h>
+#include "device_models.hpp"
+#include "kernels.hpp"
+
+namespace sabc {
+
+// ------------------------------------------------------------------------------------------
+// block reduction of NP per-lane values: wave shuffles, then LDS across the 4 wavefronts
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], double *__restrict__ out) {
+  __shared__ double sm[kBlock / 64][NP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NP; ++c) {
+    double v = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sm[wave][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int c = threadIdx.x;
+    out[c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
+  }
+}
+
+template <int D, int S>
+__device__ __forceinline__ void moment_terms(const StepCtrl &c, bool accepted, const double *th, const double *u,
+                                             const double *rho, double (&acc)[n_partials(D, S)]) {
+  acc[0] = accepted ? 1.0 : 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) { acc[1 + j] = u[j]; acc[1 + S + j] = rho[j]; }
+  double dk[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { dk[k] = th[k] - c.pivot[k]; acc[1 + 2 * S + k] = dk[k]; }
+  int q = 1 + 2 * S + D;
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int l = 0; l <= k; ++l) acc[q++] = dk[k] * dk[l];
+}
+
+__device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+
+__device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint64_t j) {
+  int64_t r = (int64_t)(j / (uint64_t)pv.m_full);
+  if (r > pv.world - 1) r = pv.world - 1;
+  const int64_t o = (int64_t)j - r * pv.m_full;
+  const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
+  return pv.base + r * pv.rank_stride + off + o;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
+//     + fused block partials.   SimulatedAnnealingABC.jl:308-331
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int D, int S, int PROP>
+__global__ void __launch_bounds__(kBlock)
+k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cdf, const PartnerView pv,
+         const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
+  constexpr int NP = n_partials(D, S);
+  double acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < act_n) {
+    const int64_t li = act_lo + t;
+    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+    double th[D], u[S], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
+      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
+    }
+
+    // ---- proposal (:311) ----
+    double thp[D];
+    double logf = 0.0;
+    if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
+      NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
+      double z[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) z[k] = ns.next();
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l <= k; ++l) a += c.chol[k * D + l] * z[l];
+        thp[k] = th[k] + a;
+      }
+    } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
+      uint64_t i1 = 0, i2 = 0;
+      for (uint32_t a = 0;; ++a) {                 // :103-107, redraw both until distinct
+        const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
+        i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+        i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
+        if (i1 != i2 || a > 64u) break;
+      }
+      double z0, z1;
+      box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
+      const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);      // :110
+      const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
+#pragma unroll
+      for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+    } else {                                       // StretchMove, proposals.jl:137-148
+      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
+      const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
+      const double U = u52(w.z, w.w);
+      const double a = c.prop_p0;
+      const double tt = (a - 1.0) * U + 1.0;
+      const double z = tt * tt / a;                                          // :144
+      const double *p = partner_ptr(pv, ip);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double pk = p[(int64_t)k * pv.cap];
+        thp[k] = pk + z * (th[k] - pk);                                      // :147
+      }
+      logf = log(z) * (double)(D - 1);                                       // :146
+    }
+
+    // ---- acceptance probability (:314-322) ----
+    const double lpp = prior_logpdf<D>(m, thp);
+    double log_accept = -INFINITY;
+    double up[S], rp[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
+    if (lpp > -INFINITY) {
+      Sim<MODEL, D, S>::run(m, thp, gid, c.iter, rp);                        // :315
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        up[j] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rp[j]);   // :316
+        const double e = (c.eps_len == 1) ? c.eps[0] : c.eps[j];
+        a += (u[j] - up[j]) / e;                                             // :319
+      }
+      log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
+    }
+
+    // ---- accept / store (:324-329) ----
+    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
+    const bool accepted = log(u52(wa.x, wa.y)) < log_accept;
+    if (accepted) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        u[j] = up[j]; rho[j] = rp[j];
+        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+      }
+    }
+    moment_terms<D, S>(c, accepted, th, u, rho, acc);
+  }
+  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+}
+
+// moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
+template <int D, int S>
+__global__ void __launch_bounds__(kBlock)
+k_stats(const StepCtrl c, const PopPtrs pp, double *__restrict__ partials) {
+  constexpr int NP = n_partials(D, S);
+  double acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li < pp.n_local) {
+    double th[D], u[S], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
+      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
+    }
+    moment_terms<D, S>(c, false, th, u, rho, acc);
+  }
+  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+}
+
+// fixed-order sum of the per-block partial rows (single block)
+__global__ void __launch_bounds__(kBlock)
+k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ sums) {
+  __shared__ double sm[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c < np; ++c) {
+    double v = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += kBlock) v += partials[r * np + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[c] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: prior sample + simulate (SimulatedAnnealingABC.jl:172-179), iteration 0
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int D, int S>
+__global__ void __launch_bounds__(kBlock) k_prior_simulate(const ModelDesc m, const PopPtrs pp) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  double th[D], rho[S];
+  prior_sample<D>(m, gid, th);
+  Sim<MODEL, D, S>::run(m, th, gid, 0, rho);
+#pragma unroll
+  for (int k = 0; k < D; ++k) pp.pop[(int64_t)k * pp.cap + li] = th[k];
+#pragma unroll
+  for (int j = 0; j < S; ++j) pp.rho[(int64_t)j * pp.cap + li] = rho[j];
+}
+
+// K3 over the shard: u = cdf(rho)  (:190-192)
+__global__ void __launch_bounds__(kBlock) k_cdf_population(const int d, const int s, const PopPtrs pp, const CdfPtrs cdf) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  for (int j = 0; j < s; ++j)
+    pp.pop[(int64_t)(d + j) * pp.cap + li] =
+        cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], pp.rho[(int64_t)j * pp.cap + li]);
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: resample (SimulatedAnnealingABC.jl:124-137)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_resample_weights(const int d, const int s, const PopPtrs pp, const Vec8 ubar, const double delta) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  double a = 0.0;
+  for (int j = 0; j < s; ++j) a += pp.pop[(int64_t)(d + j) * pp.cap + li] * delta / ubar.v[j];   // :127
+  pp.pop[(int64_t)(d + s) * pp.cap + li] = exp(-a);
+}
+
+__device__ __forceinline__ double gathered_weight(const double *g, int rows, int64_t cap, int64_t gid) {
+  const int64_t r = gid / cap, o = gid - r * cap;
+  return g[(r * rows + (rows - 1)) * cap + o];
+}
+
+// pass 1: per-chunk sums of w and w^2
+__global__ void __launch_bounds__(kBlock)
+k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n, double *__restrict__ bs,
+            double *__restrict__ bq) {
+  __shared__ double sm[2][kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + e;
+    const double w = i < n ? gathered_weight(g, rows, cap, i) : 0.0;
+    s += w; q += w * w;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); q += __shfl_down(q, off, 64); }
+  if (lane == 0) { sm[0][wave] = s; sm[1][wave] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bs[blockIdx.x] = ((sm[0][0] + sm[0][1]) + sm[0][2]) + sm[0][3];
+    bq[blockIdx.x] = ((sm[1][0] + sm[1][1]) + sm[1][2]) + sm[1][3];
+  }
+}
+
+// pass 2 (single block of 1024): exclusive scan of the chunk sums in place; totals
+__global__ void __launch_bounds__(1024)
+k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int64_t nb, double *__restrict__ totals) {
+  __shared__ double sm[2][1024];
+  const int t = threadIdx.x;
+  const int64_t per = (nb + 1023) / 1024;
+  const int64_t lo = (int64_t)t * per, hi = (lo + per < nb) ? lo + per : nb;
+  double s = 0.0, q = 0.0;
+  for (int64_t b = lo; b < hi; ++b) { s += bs[b]; q += bq[b]; }
+  sm[0][t] = s; sm[1][t] = q;
+  __syncthreads();
+  if (t == 0) {                       // 1024 sequential adds: fixed order, negligible time
+    double rs = 0.0, rq = 0.0;
+    for (int k = 0; k < 1024; ++k) { const double v = sm[0][k]; sm[0][k] = rs; rs += v; rq += sm[1][k]; }
+    totals[0] = rs; totals[1] = rq;
+  }
+  __syncthreads();
+  double run = sm[0][t];
+  for (int64_t b = lo; b < hi; ++b) { const double v = bs[b]; bs[b] = run; run += v; }
+}
+
+// pass 3: inclusive scan inside each chunk + chunk offset
+__global__ void __launch_bounds__(kBlock)
+k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n,
+             const double *__restrict__ bs, double *__restrict__ cum) {
+  __shared__ double sm[kBlock];
+  const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
+  double w[4];
+  double s = 0.0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + e;
+    w[e] = i < n ? gathered_weight(g, rows, cap, i) : 0.0;
+    s += w[e];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {             // exclusive scan of 256 thread totals, fixed order
+    double run = 0.0;
+    for (int k = 0; k < kBlock; ++k) { const double v = sm[k]; sm[k] = run; run += v; }
+  }
+  __syncthreads();
+  double run = bs[blockIdx.x] + sm[threadIdx.x];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + e;
+    run += w[e];
+    if (i < n) cum[i] = run;
+  }
+}
+
+// n_local categorical draws + gather of theta and u rows (rho is NOT permuted, :131-132)
+__global__ void __launch_bounds__(kBlock)
+k_resample_gather(const uint64_t seed, const int d, const int s, const double *__restrict__ g, const int rows,
+                  const int64_t cap, const int64_t n, const double *__restrict__ cum,
+                  const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= dst.n_local) return;
+  const uint64_t gid = (uint64_t)(dst.gid0 + li);
+  const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
+  const double t = u52(w.x, w.y) * totals[0];
+  int64_t lo = 0, hi = n;             // first k with cum[k] > t
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (cum[mid] > t) hi = mid; else lo = mid + 1;
+  }
+  const int64_t idx = lo < n ? lo : n - 1;
+  const int64_t r = idx / cap, o = idx - r * cap;
+  for (int row = 0; row < d + s; ++row)
+    dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: ECDF knots from a sorted column (cdf_estimators.jl:29-33)
+// ------------------------------------------------------------------------------------------
+__global__ void k_cdf_meta(const double *__restrict__ sorted, const int64_t n, int64_t *__restrict__ meta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t lo = 0, hi = n;             // first index with sorted[i] > 0
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (sorted[mid] > 0.0) hi = mid; else lo = mid + 1;
+  }
+  meta[0] = lo;
+  meta[1] = (n > 0 && sorted[0] < 0.0) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_cdf_fill(const double *__restrict__ sorted, const int64_t n, const int64_t *__restrict__ meta,
+           double *__restrict__ knots) {
+  const int64_t z = meta[0], mpos = n - z;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < mpos) knots[1 + i] = sorted[z + i];
+  if (i == 0) {
+    knots[0] = 0.0;
+    if (mpos > 0) knots[mpos + 1] = sorted[n - 1] * 1.5;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_compact_column(const double *__restrict__ g, const int s, const int stat, const int64_t cap, const int64_t n,
+                 double *__restrict__ out) {
+  const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (gid >= n) return;
+  const int64_t r = gid / cap, o = gid - r * cap;
+  out[gid] = g[(r * s + stat) * cap + o];
+}
+
+// ------------------------------------------------------------------------------------------
+// operators exposed on their own
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_cdf_eval(const double *__restrict__ knots, const int64_t len, const double *__restrict__ q, const int64_t m,
+           double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < m) out[i] = cdf_apply(knots, len, q[i]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_cdf_apply_matrix(const CdfPtrs cdf, const int s, const double *__restrict__ rho, const int64_t m,
+                   double *__restrict__ u) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  for (int j = 0; j < s; ++j)
+    u[(int64_t)j * m + i] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rho[(int64_t)j * m + i]);
+}
+
+template <int MODEL, int D, int S>
+__global__ void __launch_bounds__(kBlock)
+k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,
+                 const uint64_t iter, double *__restrict__ rho_out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double th[D], rho[S];
+#pragma unroll
+  for (int k = 0; k < D; ++k) th[k] = theta[(int64_t)k * n + i];
+  Sim<MODEL, D, S>::run(m, th, pid0 + (uint64_t)i, iter, rho);
+#pragma unroll
+  for (int j = 0; j < S; ++j) rho_out[(int64_t)j * n + i] = rho[j];
+}
+
+__global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
+                               uint32_t *words, double *normals) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const u32x4 w = stream_block(seed, pid, purpose, iter, k);
+  words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
+  box_muller(w, normals[0], normals[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+#define SABC_LAUNCH_RC() ((int)hipGetLastError())
+
+// dispatch on the (model, d, s) combinations that exist
+#define SABC_DISPATCH_MODEL(m, CALL)                                                              \
+  do {                                                                                            \
+    const int key_ = (m).model_id * 100 + (m).d * 10 + (m).s;                                     \
+    switch (key_) {                                                                               \
+      case SABC_MODEL_GAUSS_IID * 100 + 11: { CALL(SABC_MODEL_GAUSS_IID, 1, 1); break; }          \
+      case SABC_MODEL_GAUSS_IID * 100 + 12: { CALL(SABC_MODEL_GAUSS_IID, 1, 2); break; }          \
+      case SABC_MODEL_GAUSS_IID * 100 + 21: { CALL(SABC_MODEL_GAUSS_IID, 2, 1); break; }          \
+      case SABC_MODEL_GAUSS_IID * 100 + 22: { CALL(SABC_MODEL_GAUSS_IID, 2, 2); break; }          \
+      case SABC_MODEL_GAUSS2D * 100 + 23: { CALL(SABC_MODEL_GAUSS2D, 2, 3); break; }              \
+      case SABC_MODEL_GK * 100 + 44: { CALL(SABC_MODEL_GK, 4, 4); break; }                        \
+      case SABC_MODEL_LV * 100 + 34: { CALL(SABC_MODEL_LV, 3, 4); break; }                        \
+      default: return (int)hipErrorInvalidValue;                                                  \
+    }                                                                                             \
+  } while (0)
+
+int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
+#define CALL(M, D, S) hipLaunchKernelGGL((k_prior_simulate<M, D, S>), grid, block, 0, stream, m, pp)
+  SABC_DISPATCH_MODEL(m, CALL);
+#undef CALL
+  return SABC_LAUNCH_RC();
+}
+
+int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_cdf_population, dim3((unsigned)n_blocks(pp.n_local)), dim3(kBlock), 0, stream, m.d, m.s, pp, cdf);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_update(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, CdfPtrs cdf, PartnerView pv, int64_t act_lo,
+                  int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
+  if (act_n <= 0) return 0;
+  const dim3 grid((unsigned)n_blocks(act_n)), block(kBlock);
+  double *out = partials + row0 * n_partials(m.d, m.s);
+#define CALLP(M, D, S, P) \
+  hipLaunchKernelGGL((k_update<M, D, S, P>), grid, block, 0, stream, m, c, pp, cdf, pv, act_lo, act_n, out)
+#define CALL(M, D, S)                                                           \
+  switch (c.prop_kind) {                                                        \
+    case SABC_PROP_RANDOMWALK: CALLP(M, D, S, SABC_PROP_RANDOMWALK); break;     \
+    case SABC_PROP_DIFFEVO: CALLP(M, D, S, SABC_PROP_DIFFEVO); break;           \
+    case SABC_PROP_STRETCH: CALLP(M, D, S, SABC_PROP_STRETCH); break;           \
+    default: return (int)hipErrorInvalidValue;                                  \
+  }
+  SABC_DISPATCH_MODEL(m, CALL);
+#undef CALL
+#undef CALLP
+  return SABC_LAUNCH_RC();
+}
+
+int launch_stats(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, double *partials, hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
+#define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, c, pp, partials)
+  SABC_DISPATCH_MODEL(m, CALL);
+#undef CALL
+  return SABC_LAUNCH_RC();
+}
+
+int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, stream, partials, rows, np, sums);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_weights(const ModelDesc &m, PopPtrs pp, Vec8 ubar, double delta, hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_weights, dim3((unsigned)n_blocks(pp.n_local)), dim3(kBlock), 0, stream, m.d, m.s, pp,
+                     ubar, delta);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
+                       double *cum, double *totals, hipStream_t stream) {
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  double *bs = block_sums, *bq = block_sums + nb;
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, bq);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
+                           const double *cum, const double *totals, uint64_t iter, PopPtrs dst, hipStream_t stream) {
+  if (dst.n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_gather, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), 0, stream, m.seed, m.d,
+                     m.s, gathered, rows, cap, n_global, cum, totals, iter, dst);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream) {
+  hipLaunchKernelGGL(k_cdf_meta, dim3(1), dim3(64), 0, stream, sorted, n, meta);
+  hipLaunchKernelGGL(k_cdf_fill, dim3((unsigned)n_blocks(n > 0 ? n : 1)), dim3(kBlock), 0, stream, sorted, n, meta, knots);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(k_compact_column, dim3((unsigned)n_blocks(n_global)), dim3(kBlock), 0, stream, gathered, s, stat,
+                     cap, n_global, out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m, double *out, hipStream_t stream) {
+  if (m <= 0) return 0;
+  hipLaunchKernelGGL(k_cdf_eval, dim3((unsigned)n_blocks(m)), dim3(kBlock), 0, stream, knots, len, q, m, out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream) {
+  if (m <= 0) return 0;
+  hipLaunchKernelGGL(k_cdf_apply_matrix, dim3((unsigned)n_blocks(m)), dim3(kBlock), 0, stream, cdf, s, rho, m, u_out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
+                          double *rho_out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
+#define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out)
+  SABC_DISPATCH_MODEL(m, CALL);
+#undef CALL
+  return SABC_LAUNCH_RC();
+}
+
+int launch_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k, uint32_t *words,
+                        double *normals, hipStream_t stream) {
+  hipLaunchKernelGGL(k_philox_debug, dim3(1), dim3(64), 0, stream, seed, pid, purpose, iter, k, words, normals);
+  return SABC_LAUNCH_RC();
+}
+
+}  // namespace sabc

@@ -1,0 +1,69 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels (defined in kernels.hip, sort.hip).
+// Every launcher only enqueues work on `stream` and returns the hipError_t of the launch as int.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "sabc_types.hpp"
+
+namespace sabc {
+
+// Local shard in HBM.  pop = [(d + s + 1)][cap] doubles: rows 0..d-1 theta, d..d+s-1 u, last row
+// resample weights.  rho = [s][cap].  SoA so that lane i touches address base + i (coalesced).
+struct PopPtrs {
+  double *pop;
+  double *rho;
+  int64_t cap, n_local, gid0;
+};
+
+struct CdfPtrs {
+  const double *knots;   // [s][stride]
+  int64_t stride;
+  int64_t len[kMaxStats];
+};
+
+struct Vec8 {
+  double v[kMaxStats];
+};
+
+constexpr int kBlock = 256;        // 4 wavefronts of 64
+constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
+
+inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
+
+// K1: theta_i ~ prior, rho_i = f_dist(theta_i)                       SimulatedAnnealingABC.jl:172-179
+int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
+// K3: u_ij = cdf_j(rho_ij) for the whole shard                        :190-192
+int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
+// K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
+// writes one partial row per block at partials[(row0 + blockIdx) * np]
+int launch_update(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, CdfPtrs cdf, PartnerView pv, int64_t act_lo,
+                  int64_t act_n, double *partials, int64_t row0, hipStream_t stream);
+// moment sums of the current shard (no update): same partial layout, n_accept = 0
+int launch_stats(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, double *partials, hipStream_t stream);
+// sums[c] = sum over rows of partials[row][c] in a fixed order
+int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream);
+// K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
+int launch_resample_weights(const ModelDesc &m, PopPtrs pp, Vec8 ubar, double delta, hipStream_t stream);
+// K5b: inclusive scan of the global weight vector (gathered layout [world][rows][cap]) -> cum[n_global];
+// totals[0] = sum w, totals[1] = sum w^2                               :129,134
+int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
+                       double *cum, double *totals, hipStream_t stream);
+// K5c: n_local categorical draws by inverse CDF + gather of theta and u (not rho)   :129-132
+int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
+                           const double *cum, const double *totals, uint64_t iter, PopPtrs dst, hipStream_t stream);
+// K2: knots = [0; sorted positives; 1.5 max] from an ascending-sorted column         cdf_estimators.jl:29-33
+// meta[0] = number of non-positive entries, meta[1] = 1 if any entry is negative
+int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream);
+// compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
+int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
+                          hipStream_t stream);
+// ascending sort of n doubles (rocPRIM radix sort); query tmp size with tmp == nullptr
+int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream);
+// operators
+int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m, double *out, hipStream_t stream);
+int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);
+int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
+                          double *rho_out, hipStream_t stream);
+int launch_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k, uint32_t *words,
+                        double *normals, hipStream_t stream);
+
+}  // namespace sabc

@@ -1,0 +1,75 @@
+"""Collective hooks for a sharded population: one process per GPU under torch.distributed.
+Backend "nccl" IS RCCL on ROCm: the hooks get device pointers and run on the library's HIP
+stream (no host round trip).  Backend "gloo" gets host pointers (the library stages them);
+it exists for tests on one GPU / no GPU.
+
+Per population update the engine issues ONE allreduce of the fused sums
+(1 + 2s + d + d(d+1)/2 doubles: n_accept, Σu, Σρ, Σθ, Σθθᵀ); an allgather of the population
+only when a resample triggers (SimulatedAnnealingABC.jl:340) and, for DifferentialEvolution /
+StretchMove, an allgather of θ per half batch so partners are drawn from all shards."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+
+class _DevPtr:
+    """Expose a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def _host_tensor(ptr, n):
+    import torch
+    arr = np.ctypeslib.as_array((C.c_double * int(n)).from_address(int(ptr)))
+    return torch.from_numpy(arr)
+
+
+def make_hooks(device, group=None):
+    """Return (allreduce, allgather, device_buffers) for sabc_set_collectives."""
+    import torch
+    import torch.distributed as dist
+
+    backend = dist.get_backend(group)
+    world = dist.get_world_size(group)
+    on_device = backend == "nccl"
+
+    def tensor(ptr, n):
+        if on_device:
+            return torch.as_tensor(_DevPtr(ptr, n), device=f"cuda:{device}")
+        return _host_tensor(ptr, n)
+
+    def stream_ctx(stream):
+        if on_device and stream:
+            return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=f"cuda:{device}"))
+        import contextlib
+        return contextlib.nullcontext()
+
+    def allreduce(ctx, buf, count, stream):
+        try:
+            with stream_ctx(stream):
+                dist.all_reduce(tensor(buf, count), group=group)
+            return 0
+        except Exception as e:   # never raise through the C frame
+            print(f"[sabc] allreduce hook failed: {e!r}", flush=True)
+            return -1
+
+    def allgather(ctx, send, recv, count, stream):
+        try:
+            with stream_ctx(stream):
+                out = tensor(recv, count * world)
+                dist.all_gather(list(out.chunk(world)), tensor(send, count), group=group)
+            return 0
+        except Exception as e:
+            print(f"[sabc] allgather hook failed: {e!r}", flush=True)
+            return -1
+
+    return allreduce, allgather, on_device
+
+
+def install_collectives(handle, device, group=None):
+    ar, ag, on_device = make_hooks(device, group)
+    handle.set_collectives(ar, ag, on_device)

@@ -1,0 +1,74 @@
+"""Priors as data.  The reference takes any `Distributions.Distribution` and calls `rand`,
+`logpdf` and `length` on it (SimulatedAnnealingABC.jl:163,174,254,314,318); the device path
+needs the prior as a descriptor, so the supported set is products of univariate Normal and
+Uniform.  Names follow Distributions.jl."""
+from __future__ import annotations
+
+from . import _lib
+
+
+class Distribution:
+    def descriptors(self):
+        raise NotImplementedError
+
+    def __len__(self):
+        return len(self.descriptors())
+
+    @property
+    def univariate(self):
+        return False
+
+
+class Normal(Distribution):
+    def __init__(self, μ=0.0, σ=1.0):
+        if not σ > 0:
+            raise ValueError("Normal: the standard deviation σ must be positive")
+        self.μ, self.σ = float(μ), float(σ)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_NORMAL, self.μ, self.σ)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"Normal(μ={self.μ}, σ={self.σ})"
+
+
+class Uniform(Distribution):
+    def __init__(self, a=0.0, b=1.0):
+        if not b > a:
+            raise ValueError("Uniform: the upper bound must exceed the lower bound")
+        self.a, self.b = float(a), float(b)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_UNIFORM, self.a, self.b)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"Uniform(a={self.a}, b={self.b})"
+
+
+class Product(Distribution):
+    """`product_distribution([...])` of univariate components (test/runtests.jl:87-88)."""
+
+    def __init__(self, components):
+        self.components = list(components)
+        if not self.components or not all(isinstance(c, Distribution) and c.univariate for c in self.components):
+            raise ValueError("product_distribution needs univariate Normal / Uniform components")
+        if len(self.components) > _lib.MAX_PARA:
+            raise ValueError(f"at most {_lib.MAX_PARA} parameters are supported")
+
+    def descriptors(self):
+        return [c.descriptors()[0] for c in self.components]
+
+    def __repr__(self):
+        return "Product(" + ", ".join(map(repr, self.components)) + ")"
+
+
+def product_distribution(components):
+    return Product(components)

@@ -1,0 +1,233 @@
+"""SabcHandle: a thin Python owner of one `sabc_handle*` (the same calls a Julia wrapper makes
+with `ccall`).  All state lives on the GPU behind the handle; arrays cross only on request."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, SABCError, UpdateArgs
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class SabcHandle:
+    def __init__(self, *, n_particles, model, prior, algorithm=_lib.ALG_SINGLE_EPS, v=1.0, delta=0.1,
+                 seed=20241220, device=0, rank=0, world=1):
+        """model: object with model_id / params / n_stats; prior: distributions.Prior."""
+        cfg = Config()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.device = int(device)
+        cfg.n_particles = int(n_particles)
+        cfg.n_para = len(prior)
+        cfg.n_stats = int(model.n_stats)
+        cfg.model_id = int(model.model_id)
+        params = list(model.params)
+        cfg.n_model_params = len(params)
+        for i, p in enumerate(params):
+            cfg.model_params[i] = float(p)
+        for k, (kind, a, b) in enumerate(prior.descriptors()):
+            cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
+        cfg.algorithm = int(algorithm)
+        cfg.rank, cfg.world = int(rank), int(world)
+        cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)
+        self.cfg = cfg
+        self.d, self.s = cfg.n_para, cfg.n_stats
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.sabc_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise SABCError(rc, _lib.global_error())
+        self._h = h
+        self._keep = []   # ctypes callbacks must outlive the handle
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sabc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise SABCError(rc, self._L.sabc_last_error(self._h).decode("utf-8", "replace"))
+
+    # ---- hot path ----
+    def initialize(self, n_simulation):
+        self._check(self._L.sabc_initialize(self._h, int(n_simulation)))
+
+    def update(self, *, n_simulation, proposal, v=1.0, delta=0.1, resample=None, checkpoint_history=1):
+        a = UpdateArgs()
+        a.n_simulation, a.v, a.delta = int(n_simulation), float(v), float(delta)
+        a.resample = float(2 * self.cfg.n_particles if resample is None else resample)
+        a.checkpoint_history = int(checkpoint_history)
+        a.proposal_kind, a.proposal_p0, a.proposal_p1 = proposal.descriptor()
+        self._check(self._L.sabc_update(self._h, C.byref(a)))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._L.sabc_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_collectives(self, allreduce, allgather, device_buffers: bool):
+        ar, ag = _lib.ALLREDUCE_FN(allreduce), _lib.ALLGATHER_FN(allgather)
+        self._keep += [ar, ag]
+        self._check(self._L.sabc_set_collectives(self._h, ar, ag, None, int(device_buffers)))
+
+    # ---- state ----
+    @property
+    def n_local(self):
+        return int(self._L.sabc_n_local(self._h))
+
+    @property
+    def local_offset(self):
+        return int(self._L.sabc_local_offset(self._h))
+
+    def get_population(self, theta=True, u=True, rho=True):
+        """Local shard as (theta [d][n_local], u [s][n_local], rho [s][n_local]) = column-major n x k."""
+        n = self.n_local
+        th = np.empty((self.d, n)) if theta else None
+        uu = np.empty((self.s, n)) if u else None
+        rr = np.empty((self.s, n)) if rho else None
+        self._check(self._L.sabc_get_population(self._h, _dp(th), _dp(uu), _dp(rr)))
+        return th, uu, rr
+
+    def set_population(self, theta=None, u=None, rho=None):
+        n = self.n_local
+        def prep(a, rows):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != (rows, n):
+                raise ValueError(f"expected shape {(rows, n)}, got {a.shape}")
+            return a
+        th, uu, rr = prep(theta, self.d), prep(u, self.s), prep(rho, self.s)
+        self._check(self._L.sabc_set_population(self._h, _dp(th), _dp(uu), _dp(rr)))
+
+    @property
+    def counters(self):
+        out = (C.c_int64 * 4)()
+        self._check(self._L.sabc_get_counters(self._h, out))
+        return dict(n_simulation=out[0], n_accept=out[1], n_resampling=out[2], n_population_updates=out[3])
+
+    def set_counters(self, n_simulation, n_accept, n_resampling, n_population_updates):
+        arr = (C.c_int64 * 4)(n_simulation, n_accept, n_resampling, n_population_updates)
+        self._check(self._L.sabc_set_counters(self._h, arr))
+
+    @property
+    def eps(self):
+        out = np.zeros(_lib.MAX_STATS)
+        ln = C.c_int32()
+        self._check(self._L.sabc_get_epsilon(self._h, _dp(out), C.byref(ln)))
+        return out[: ln.value].copy()
+
+    def set_eps(self, eps):
+        e = np.ascontiguousarray(eps, dtype=np.float64)
+        self._check(self._L.sabc_set_epsilon(self._h, _dp(e), len(e)))
+
+    @property
+    def history(self):
+        m = int(self._L.sabc_history_len(self._h))
+        le = self.s if self.cfg.algorithm == _lib.ALG_MULTI_EPS else 1
+        e, u, r = np.zeros((m, le)), np.zeros((m, self.s)), np.zeros((m, self.s))
+        if m:
+            self._check(self._L.sabc_get_history(self._h, _dp(e), _dp(u), _dp(r)))
+        return e, u, r
+
+    def clear_history(self):
+        self._check(self._L.sabc_clear_history(self._h))
+
+    def cdf_knots(self, stat):
+        m = int(self._L.sabc_cdf_len(self._h, stat))
+        out = np.zeros(m)
+        if m:
+            self._check(self._L.sabc_get_cdf_knots(self._h, stat, _dp(out)))
+        return out
+
+    def set_cdf_knots(self, stat, knots):
+        k = np.ascontiguousarray(knots, dtype=np.float64)
+        self._check(self._L.sabc_set_cdf_knots(self._h, stat, _dp(k), len(k)))
+
+    def cdf_apply(self, rho):
+        """rho: [s][m] -> u [s][m] on the device (cdf_estimators.jl:68-70)."""
+        r = np.ascontiguousarray(rho, dtype=np.float64).reshape(self.s, -1)
+        out = np.empty_like(r)
+        self._check(self._L.sabc_cdf_apply(self._h, _dp(r), r.shape[1], _dp(out)))
+        return out
+
+    @property
+    def proposal_sigma(self):
+        out = np.zeros((self.d, self.d))
+        self._check(self._L.sabc_get_proposal_sigma(self._h, _dp(out)))
+        return out
+
+    @property
+    def ess(self):
+        return float(self._L.sabc_last_ess(self._h))
+
+    def simulate(self, theta, pid0, it):
+        """theta [d][m] -> rho [s][m] with the RNG streams of particles pid0.. at iteration `it`."""
+        th = np.ascontiguousarray(theta, dtype=np.float64).reshape(self.d, -1)
+        out = np.empty((self.s, th.shape[1]))
+        self._check(self._L.sabc_op_simulate(self._h, _dp(th), th.shape[1], int(pid0), int(it), _dp(out)))
+        return out
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._check(self._L.sabc_profile_enable(self._h, int(on)))
+
+    def profile_get(self, kernel):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._L.sabc_profile_get(self._h, int(kernel), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+# ---- stand-alone operators ----
+def op_build_cdf(x, device=0):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(len(x) + 2)
+    ln = C.c_int64()
+    rc = _lib.lib().sabc_op_build_cdf(device, _dp(x), len(x), _dp(out), C.byref(ln))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return out[: ln.value].copy()
+
+
+def op_cdf_eval(knots, q, device=0):
+    k = np.ascontiguousarray(knots, dtype=np.float64)
+    qq = np.atleast_1d(np.ascontiguousarray(q, dtype=np.float64))
+    out = np.empty_like(qq)
+    rc = _lib.lib().sabc_op_cdf_eval(device, _dp(k), len(k), _dp(qq), len(qq), _dp(out))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return out if np.ndim(q) else float(out[0])
+
+
+def op_eps_single(ubar, v):
+    out = C.c_double()
+    _lib.lib().sabc_op_eps_single(float(ubar), float(v), C.byref(out))
+    return out.value
+
+
+def op_eps_multi(ubar, v):
+    ub = np.ascontiguousarray(ubar, dtype=np.float64)
+    out = np.zeros(len(ub))
+    rc = _lib.lib().sabc_op_eps_multi(_dp(ub), len(ub), float(v), _dp(out))
+    if rc:
+        raise SABCError(rc, "Division by zero - Mean u for a statistic is <= eps()")
+    return out
+
+
+def op_philox(seed, pid, purpose, it, k, device=0):
+    w = (C.c_uint32 * 4)()
+    z = np.zeros(2)
+    rc = _lib.lib().sabc_op_philox(device, seed, pid, purpose, it, k, w, _dp(z))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return [int(x) for x in w], z

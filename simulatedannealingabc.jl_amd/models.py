@@ -1,0 +1,91 @@
+"""Device-coded simulators.  In the reference `f_dist` is an arbitrary Julia closure
+(SimulatedAnnealingABC.jl:164,175,315); a GPU kernel needs it as data, so `sabc` takes a
+`DeviceDistance` descriptor naming one of the simulators compiled into csrc/device_models.hpp.
+Definitions (and the observed summaries each one is compared with) are in DESIGN.md."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceDistance:
+    model_id: int = 0
+    n_stats: int = 0
+    n_para: tuple = ()
+
+    @property
+    def params(self):
+        raise NotImplementedError
+
+    def __call__(self, θ, *a, **k):
+        raise TypeError("a DeviceDistance is evaluated on the GPU; use SabcHandle.simulate() to call it directly")
+
+
+class GaussianIID(DeviceDistance):
+    """y_1..n_obs ~ Normal(θ[1], sd) with sd = θ[2] when the prior has two dimensions;
+    ρ = (|obs_mean − mean(y)|,) or with `obs_m2` also |obs_m2 − mean(y.^2)|.
+    Covers test/runtests.jl:35,86,128-131,167-170 and BASELINE configs 1-2."""
+    model_id = _lib.MODEL_GAUSS_IID
+    n_para = (1, 2)
+
+    def __init__(self, n_obs=100, sd=1.0, obs_mean=0.0, obs_m2=None):
+        self.n_obs, self.sd, self.obs_mean, self.obs_m2 = int(n_obs), float(sd), float(obs_mean), obs_m2
+        self.n_stats = 1 if obs_m2 is None else 2
+
+    @property
+    def params(self):
+        return [self.n_obs, self.sd, self.obs_mean, 0.0 if self.obs_m2 is None else float(self.obs_m2)]
+
+
+class Gaussian2D(DeviceDistance):
+    """x_1..n_obs ~ N(θ, [[1,r],[r,1]]); ρ = (‖mean − obs‖₂, |var₁+var₂ − obs|, |cov₁₂ − obs|)."""
+    model_id = _lib.MODEL_GAUSS2D
+    n_para = (2,)
+    n_stats = 3
+
+    def __init__(self, n_obs=50, r=0.6, obs_mean=(0.0, 0.0), obs_varsum=2.0, obs_cov=0.6):
+        self.n_obs, self.r = int(n_obs), float(r)
+        self.obs_mean, self.obs_varsum, self.obs_cov = tuple(map(float, obs_mean)), float(obs_varsum), float(obs_cov)
+
+    @classmethod
+    def from_observations(cls, y, r=0.6):
+        y = np.asarray(y, dtype=np.float64)
+        c = np.cov(y.T)
+        return cls(n_obs=len(y), r=r, obs_mean=y.mean(0), obs_varsum=c[0, 0] + c[1, 1], obs_cov=c[0, 1])
+
+    @property
+    def params(self):
+        return [self.n_obs, self.r, self.obs_mean[0], self.obs_mean[1], self.obs_varsum, self.obs_cov]
+
+
+class GandK(DeviceDistance):
+    """g-and-k: x = A + B(1 + c·tanh(g z/2))(1+z²)^k z, z~N(0,1), n_draws draws;
+    ρ_j = |x_(rank_j) − obs_j| for four order statistics (1-based ranks)."""
+    model_id = _lib.MODEL_GK
+    n_para = (4,)
+    n_stats = 4
+
+    def __init__(self, n_draws=128, c=0.8, ranks=(16, 48, 80, 112), obs=(0.0, 0.0, 0.0, 0.0)):
+        self.n_draws, self.c = int(n_draws), float(c)
+        self.ranks, self.obs = tuple(int(r) for r in ranks), tuple(float(o) for o in obs)
+
+    @property
+    def params(self):
+        return [self.n_draws, self.c, *self.ranks, *self.obs]
+
+
+class LotkaVolterra(DeviceDistance):
+    """Stochastic Lotka–Volterra by Euler–Maruyama: dX = (aX − bXY)dt + σX dW₁,
+    dY = (bXY − cY)dt + σY dW₂, clamped at 0; ρ = |mean X, sd X, mean Y, sd Y − obs|."""
+    model_id = _lib.MODEL_LV
+    n_para = (3,)
+    n_stats = 4
+
+    def __init__(self, n_steps=256, dt=0.05, σ=0.1, x0=50.0, y0=50.0, obs=(0.0, 0.0, 0.0, 0.0)):
+        self.n_steps, self.dt, self.σ, self.x0, self.y0 = int(n_steps), float(dt), float(σ), float(x0), float(y0)
+        self.obs = tuple(float(o) for o in obs)
+
+    @property
+    def params(self):
+        return [self.n_steps, self.dt, self.σ, self.x0, self.y0, *self.obs]
