@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-simulations/sec of the SABC population update loop on MI355X.
+
+One "step" = one population update (SimulatedAnnealingABC.jl:294-375): every particle is
+proposed, simulated, ECDF-transformed and MH-accepted once, then the fused sums give the new
+epsilon / proposal covariance (and a resample when it triggers).  Workload = BASELINE.json
+configs[1]: 1-D Gaussian-mean ABC, n_particles = 1e6, f_dist as a device-side kernel,
+RandomWalk proposal.  The population is resident in HBM before the timed region; the timed
+region is ONE call of the C-ABI entry point sabc_update() for K population updates.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (one rank per GPU)
+
+For N > 1 the n_particles = 1e6 population is sharded over the ranks (strong scaling, the
+north-star target is quoted at n_particles = 1e6 on 8 GPUs); --particles-per-gpu switches to weak.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SEED = 20241220
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def observed_mean():
+    """y_obs: 100 draws of N(1.5, 1) with the fixed seed; only its mean is used."""
+    return float(np.random.default_rng(SEED).normal(1.5, 1.0, 100).mean())
+
+
+def cpu_baseline(n, updates, threads):
+    """The oracle (CPU restatement, NOT the Julia reference: Julia is not installed) on the host
+    cores of this box, same workload, bounded sample; update loop only, like `value`."""
+    from oracle import oracle as O
+    O.set_threads(threads)
+    cfg = O.make_config(n_particles=n, n_para=1, n_stats=1, model_id=O.MODEL_GAUSS_IID,
+                        model_params=[100, 1.0, observed_mean(), 0.0], prior=[(O.PRIOR_NORMAL, 0.0, 2.0)], seed=SEED)
+    run = O.OracleRun(cfg)
+    run.initialize(n)
+    t0 = time.perf_counter()
+    run.update(O.make_update_args(n_simulation=updates * n, proposal=(O.PROP_RANDOMWALK, 0.8, 0.0), n_particles=n))
+    dt = time.perf_counter() - t0
+    return {"value": updates * n / dt, "unit": "particle-simulations/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/sabc_oracle.c (OpenMP), cfg2 n_particles={n}, {updates} population updates, "
+                      f"{dt:.1f} s; CPU restatement, not the Julia reference"}
+
+
+def load_traffic(workload_n):
+    """HBM bytes per launch of the update kernel from a committed rocprofv3 --pmc pass, if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        if int(t.get("n_particles", -1)) == int(workload_n):
+            return t.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-particles", type=int, default=1_000_000)
+    ap.add_argument("--particles-per-gpu", type=int, default=0, help="weak scaling: this many particles per rank")
+    ap.add_argument("--proposal", default="randomwalk", choices=["randomwalk", "de", "stretch"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-updates", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sabc_amd as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the SABC engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    weak = args.particles_per_gpu > 0
+    n = args.particles_per_gpu * world if weak else args.n_particles
+    K, W = args.steps, args.warmup
+    model = S.GaussianIID(n_obs=100, sd=1.0, obs_mean=observed_mean())
+    prior = S.Normal(0.0, 2.0)
+    proposal = {"randomwalk": S.RandomWalk(n_para=1), "de": S.DifferentialEvolution(n_para=1),
+                "stretch": S.StretchMove()}[args.proposal]
+
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, device=local_rank, rank=rank, world=world)
+    if world > 1:
+        from sabc_amd.dist import install_collectives
+        install_collectives(h, local_rank)
+    t_init0 = time.perf_counter()
+    h.initialize(n)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init0
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if W > 0:
+        h.update(n_simulation=W * n, proposal=proposal)
+    h.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kern_ms, launches = h.profile_get(S._lib.KERNEL_UPDATE)
+    red_ms, red_n = h.profile_get(S._lib.KERNEL_REDUCE)
+    res_ms, res_n = h.profile_get(S._lib.KERNEL_RESAMPLE)
+    c = h.counters
+    th, _, _ = h.get_population(u=False, rho=False)
+
+    if rank == 0:
+        d, s = 1, 1
+        bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
+        sims_per_launch = h.n_local * (K / max(launches, 1)) if launches else 0
+        avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
+        sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
+        achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
+        yb = observed_mean()
+        post_var = 1.0 / (1.0 / 4.0 + 100.0)
+        out = {
+            "metric": "particle-simulations/sec at n_particles=1e6",
+            "value": K * n / dt,
+            "unit": "particle-simulations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak" if weak else "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: 1-D Gaussian-mean ABC (Normal(0,2) prior, |mean(x)-mean(y_obs)|, "
+                            f"100 draws per simulation), n_particles={n}, proposal={args.proposal}, single_eps",
+                "n_particles": n, "n_obs": 100, "proposal": args.proposal, "algorithm": "single_eps",
+                "particles_per_gpu": h.n_local, "seed": SEED,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if launches else None,
+                "traffic": load_traffic(n),
+                "kernel": "k_update<GAUSS_IID,1,1,RandomWalk>" if args.proposal == "randomwalk" else "k_update",
+                "avg_launch_us": avg_launch_s * 1e6 if launches else None,
+                "launches": launches,
+                "algorithmic_bytes_per_sim": bytes_per_sim,
+                "note": "not HBM-bound by construction: 100 f64 normals (50 Philox4x32-10 blocks + 50 Box-Muller "
+                        "log/sqrt/sincospi) per 40 algorithmic bytes; see normals_per_s",
+            },
+            "normals_per_s": 100.0 * K * n / dt,
+            "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
+            "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
+            "resamples_in_timed_region": res_n,
+            "init_s": t_init,
+            "state": {"n_accept": c["n_accept"], "n_resampling": c["n_resampling"],
+                      "n_population_updates": c["n_population_updates"], "eps": h.eps.tolist(),
+                      "shard0_mean": float(th.mean()), "shard0_var": float(th.var()),
+                      "analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            threads = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_updates, threads)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""Parity of the HIP path against the oracle, through the C-ABI, on a real MI355X.
+
+Integer / index work (Philox words, accept counts, resample counts, ECDF knot counts, sorted
+knots) must be bit-exact.  Floating-point work is f64 on both sides; the only differences are
+the device libm (log, sqrt, sincospi, exp, tanh, pow) and FMA contraction, so the tolerance
+is rtol = 1e-9 on particle values after tens of population updates (observed ~1e-13)."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal, oracle_config, oracle_proposal, oracle_run
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-9, atol=1e-12)
+SQRT_EPS = math.sqrt(np.finfo(float).eps)
+
+
+def test_philox_words_bit_exact(S, O, gpu):
+    for seed, pid, purpose, it, k in [(0, 0, 0, 0, 0), (SEED, 123456, 1, 77, 49), (2**63 + 5, 2**33 + 9, 5, 2**32 + 3, 7)]:
+        w, z = S.op_philox(seed, pid, purpose, it, k)
+        assert w == O.stream_block(seed, pid, purpose, it, k)
+        np.testing.assert_allclose(z, O.normal_pair(seed, pid, purpose, it, k), rtol=0, atol=4e-15)
+    assert S.op_philox(0, 0, 0, 0, 0)[0] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]   # Random123 KAT
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_device_simulators_match_oracle(S, O, gpu, name):
+    model, prior = hip_model_prior(S, name)
+    h = S.SabcHandle(n_particles=64, model=model, prior=prior, seed=SEED)
+    cfg = oracle_config(O, name, 64)
+    m = 300
+    th = np.array([O.prior_sample(cfg, 1000 + i) for i in range(m)]).T            # [d][m]
+    got = h.simulate(th, pid0=17, it=5)
+    want = np.array([O.simulate(cfg, th[:, i], 17 + i, 5) for i in range(m)]).T
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    h.close()
+
+
+# ---- test/runtests.jl:9-29 on the device operators ----
+@pytest.mark.parametrize("data", ["random", "repeats", "zeros", "big"])
+def test_cdf_estimator_on_device(S, O, gpu, data):
+    rng = np.random.default_rng(3)
+    x = {"random": rng.random(100) * 4, "repeats": np.array([1, 2, 2, 3, 3, 3.0]), "zeros": np.array([1, 0, 2, 0, 3.0]),
+         "big": np.abs(rng.standard_normal(200_003))}[data]
+    kn = S.op_build_cdf(x)
+    np.testing.assert_array_equal(kn, O.build_cdf(x))                             # sorted knots: bit-exact
+    assert S.op_cdf_eval(kn, 0.0) <= SQRT_EPS                                     # runtests.jl:13
+    assert S.op_cdf_eval(kn, math.inf) == pytest.approx(1.0)                      # runtests.jl:14
+    q = np.sort(rng.random(100) * 3)
+    got = S.op_cdf_eval(kn, q)
+    assert np.all(np.diff(got) >= 0)                                              # runtests.jl:15
+    qq = np.concatenate([q, kn[:50], [-1.0, 0.0, kn[-1], kn[-1] * 2]])
+    np.testing.assert_allclose(S.op_cdf_eval(kn, qq), O.cdf_apply(kn, qq), rtol=1e-14, atol=1e-16)
+
+
+def test_cdf_estimator_errors(S, gpu):
+    with pytest.raises(S.SABCError) as e:
+        S.op_build_cdf([0.0, 0.0, 0.0])
+    assert e.value.code == -10
+    with pytest.raises(S.SABCError) as e:
+        S.op_build_cdf([1.0, -0.5, 2.0])
+    assert e.value.code == -2
+
+
+# RandomWalk adds independent noise to a particle's own value: differences stay at libm level.
+# StretchMove / DifferentialEvolution build theta' from 2-3 other particles, so a 1e-16 difference
+# compounds by ~(1 + 2 gamma) per population update (3.4^12 ~ 2e6 for d = 1): looser bound, same counts.
+PROP_TOL = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}
+
+
+def compare(res, run, d, prop="rw"):
+    TOL = dict(rtol=PROP_TOL[prop], atol=PROP_TOL[prop] * 1e-2)
+    st, c = res.state, run.counters
+    assert (st.n_simulation, st.n_accept, st.n_resampling, st.n_population_updates) == \
+        (c["n_simulation"], c["n_accept"], c["n_resampling"], c["n_population_updates"])
+    pop = res.population.reshape(-1, 1) if d == 1 else res.population
+    np.testing.assert_allclose(pop.T, run.theta, **TOL)
+    # u = ECDF(rho): a 1e-15 relative difference in rho is amplified by rho / (knot spacing)
+    np.testing.assert_allclose(res.u.T, run.u, rtol=TOL['rtol'], atol=max(1e-9, TOL['rtol']))
+    np.testing.assert_allclose(res.ρ.T, run.rho, **TOL)
+    np.testing.assert_allclose(st.ϵ, run.eps, rtol=TOL["rtol"])
+    e, u, r = run.history
+    np.testing.assert_allclose(np.array(st.ϵ_history), e, rtol=TOL["rtol"])
+    np.testing.assert_allclose(np.array(st.u_history), u, rtol=TOL["rtol"])
+    np.testing.assert_allclose(np.array(st.ρ_history), r, rtol=TOL["rtol"])
+
+
+CASES = [(name, alg, prop) for name in MODELS for alg in ("single_eps", "multi_eps") for prop in ("rw", "de", "stretch")]
+
+
+@pytest.mark.parametrize("name,alg,prop", CASES, ids=["-".join(c) for c in CASES])
+def test_trajectory_parity(S, O, gpu, name, alg, prop):
+    """sabc() on the device == sabc() on the oracle, same seed: identical accept / resample
+    counts and particle values to 1e-9 after 12 population updates."""
+    heavy = name in ("gk_cfg4", "lv_cfg5")
+    n, k = (301, 8) if heavy else (1001, 12)          # odd n: the two half batches differ in size (:300-301)
+    d = len(MODELS[name]["prior"])
+    O.set_threads(8)
+    run = oracle_run(O, name, n, (k + 1) * n, algorithm=alg, prop=prop, resample=n // 4)
+    O.set_threads(1)
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=(k + 1) * n, algorithm=alg,
+                 proposal=hip_proposal(S, prop, d), resample=n // 4, seed=SEED)
+    assert res.state.n_resampling >= 2               # the resample path ran inside the loop
+    compare(res, run, d, prop)
+    for j in range(MODELS[name]["s"]):
+        kn = res.state.cdfs_dist_prior.knots(j)          # sorted device-simulated distances
+        assert len(kn) == len(run.cdf_knots(j))
+        np.testing.assert_allclose(kn, run.cdf_knots(j), rtol=1e-11, atol=1e-14)
+    if prop == "rw":
+        got = np.atleast_2d(res._handle.proposal_sigma)
+        np.testing.assert_allclose(got, run.sigma, rtol=1e-8)
+
+
+def test_resume_matches_oracle(S, O, gpu):
+    """update_population! twice (docs/src/usage.md:43-45) == the oracle doing the same; a call
+    with fewer simulations than particles changes nothing (runtests.jl:73-78)."""
+    n = 500
+    name, d = "gauss2_meansd", 2
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=6 * n, proposal=S.RandomWalk(n_para=d), seed=SEED)
+    run = oracle_run(O, name, n, 6 * n, prop="rw")
+    for prop, budget in (("de", 4 * n + 17), ("stretch", 3 * n), ("rw", n - 1)):
+        S.update_population_(res, model, prior, n_simulation=budget, proposal=hip_proposal(S, prop, d), v=0.7, δ=0.2,
+                             checkpoint_history=3)
+        run.update(O.make_update_args(n_simulation=budget, n_para=d, n_particles=n, v=0.7, delta=0.2,
+                                      proposal=oracle_proposal(O, prop, d), checkpoint_history=3))
+        compare(res, run, d, "de")
+    assert res.state.n_population_updates == 5 + 4 + 3
+
+
+def test_cdfs_dist_prior_callable(S, O, gpu):
+    res = S.sabc(*hip_model_prior(S, "gauss2_2stats"), n_particles=200, n_simulation=600, seed=SEED)
+    run = oracle_run(O, "gauss2_2stats", 200, 600)
+    f = res.state.cdfs_dist_prior
+    for rho in ([0.1, 0.2], [0.0, 5.0], [1e9, 1e-9]):
+        want = [O.cdf_apply(f.knots(j), rho[j]) for j in range(2)]     # same knots: only the lookup differs
+        np.testing.assert_allclose(f(rho), want, rtol=1e-14, atol=1e-16)
+        want = [O.cdf_apply(run.cdf_knots(j), rho[j]) for j in range(2)]
+        np.testing.assert_allclose(f(rho), want, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("alg", ["multi_eps", "single_eps"])
+@pytest.mark.parametrize("name", ["gauss1_uniform", "gauss2_meansd", "gauss1_2stats", "gauss2_2stats"])
+def test_reference_integration_tests_on_device(S, gpu, name, alg):
+    """test/runtests.jl:56-79,95-116,133-156,172-196 restated on the device path (unseeded, like the reference)."""
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=100, n_simulation=1000, algorithm=alg)
+    assert res.state.n_simulation <= 1000 and res.state.n_population_updates == 9 and len(res.population) == 100
+    if MODELS[name]["s"] > 1:
+        assert np.all(res.state.ϵ < 1)
+    S.update_population_(res, model, prior, n_simulation=1000)
+    assert res.state.n_simulation <= 2000 and res.state.n_population_updates == 19
+    n_sim = res.state.n_simulation
+    S.update_population_(res, model, prior, n_simulation=50)
+    assert res.state.n_simulation == n_sim
+
+
+@pytest.mark.parametrize("prop", ["de", "stretch", "rw"])
+@pytest.mark.parametrize("name", ["gauss1_uniform", "gauss2_meansd"])
+def test_reference_proposal_tests_on_device(S, gpu, name, prop):
+    """test/runtests.jl:211-267."""
+    model, prior = hip_model_prior(S, name)
+    p = hip_proposal(S, prop, len(prior))
+    res = S.sabc(model, prior, proposal=p, n_particles=100, n_simulation=1000)
+    assert res.state.n_simulation <= 1000 and len(res.population) == 100
+    S.update_population_(res, model, prior, proposal=p, n_simulation=1000)
+    assert res.state.n_simulation <= 2000
+
+
+def test_negative_distance_and_device_errors(S, gpu):
+    with pytest.raises(S.SABCError) as e:
+        S.sabc(S.GaussianIID(), S.Uniform(-1, 1), n_particles=100, n_simulation=1000, device=99)
+    assert e.value.code == -20

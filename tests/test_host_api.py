@@ -1,0 +1,84 @@
+"""Host logic that needs no GPU: the C-ABI library loads and exports every symbol the header
+declares, configuration errors carry the reference's messages, and the product path fails
+loudly (no CPU fallback) when no device is usable."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sabc_hip.h")).read()
+    return re.findall(r"SABC_API\s+[\w\s\*]+?\b(sabc_\w+)\s*\(", src)
+
+
+def test_library_exports_every_declared_symbol(S):
+    L = C.CDLL(os.path.join(ROOT, "simulatedannealingabc.jl_amd", "libsabc_hip.so"))
+    names = declared_symbols()
+    assert len(names) >= 37
+    for name in names:
+        assert hasattr(L, name), f"{name} is declared in include/sabc_hip.h but not exported"
+    assert L.sabc_abi_version() == 1
+
+
+def test_host_side_eps_operators_match_oracle(S, O):
+    for ub in [0.5, 0.31, 0.02, 1e-6]:
+        assert S.op_eps_single(ub, 1.0) == pytest.approx(O.eps_single(ub, 1.0), rel=1e-13)
+    assert S.op_eps_single(1e-17, 1.0) == 0.0
+    ub = np.array([0.3, 0.21, 0.45, 0.6])
+    np.testing.assert_allclose(S.op_eps_multi(ub, 0.7), O.eps_multi(ub, 0.7), rtol=1e-11)
+    np.testing.assert_allclose(S.op_eps_multi([0.5], 1.0), O.eps_multi([0.5], 1.0), rtol=1e-12)
+    with pytest.raises(S.SABCError):
+        S.op_eps_multi([0.3, 0.0], 1.0)
+
+
+def test_reference_error_behaviour(S):
+    f, prior = S.GaussianIID(), S.Uniform(-10, 10)
+    with pytest.raises(S.SABCError, match="too small"):                       # runtests.jl:39-40
+        S.sabc(f, prior, n_particles=100, n_simulation=10)
+    for kw in (dict(v=-0.1), dict(δ=-0.1)):                                   # runtests.jl:43-54
+        with pytest.raises(S.SABCError):
+            S.sabc(f, prior, n_particles=100, n_simulation=10, **kw)
+    with pytest.raises(S.SABCError, match="algorithm"):                       # :462-464
+        S.sabc(f, prior, n_particles=100, n_simulation=1000, algorithm="both_eps")
+    with pytest.raises(S.SABCError, match="between zero and one"):            # proposals.jl:30
+        S.RandomWalk(β=1.1, n_para=1)
+    with pytest.raises(S.SABCError):
+        S.RandomWalk(β=-0.1, n_para=1)
+
+
+def test_proposal_constructors(S):
+    with pytest.raises(TypeError):                                            # runtests.jl:204-205 (MethodError)
+        S.DifferentialEvolution(1, 0.1)
+    with pytest.raises(TypeError):
+        S.DifferentialEvolution(1)
+    with pytest.raises(ValueError):                                           # runtests.jl:207-208 (ArgumentError)
+        S.DifferentialEvolution(γ0=1, n_para=5)
+    with pytest.raises(ValueError):
+        S.DifferentialEvolution(γ0=1, n_para=5, σ_gamma=1.4)
+    assert S.DifferentialEvolution(n_para=2).γ0 == pytest.approx(2.38 / 2)    # proposals.jl:93
+    assert S.StretchMove().a == 2.0 and S.RandomWalk(n_para=3).β == 0.8
+
+
+def test_config_validation_happens_before_the_device_is_touched(S):
+    with pytest.raises(ValueError):
+        S.sabc(S.Gaussian2D(), S.Normal(0, 1), n_particles=100, n_simulation=1000)     # needs a 2-D prior
+    with pytest.raises(NotImplementedError):
+        S.sabc(lambda θ: abs(θ), S.Normal(0, 1), n_particles=100, n_simulation=1000)   # host closures: SURVEY 8f
+    with pytest.raises(S.SABCError) as e:
+        S.SabcHandle(n_particles=100, model=S.GandK(n_draws=500), prior=S.product_distribution([S.Uniform(0, 10)] * 4))
+    assert e.value.code == -8
+
+
+def test_no_cpu_fallback(S):
+    if S.lib().sabc_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(S.SABCError) as e:
+        S.sabc(S.GaussianIID(), S.Uniform(-10, 10), n_particles=100, n_simulation=1000)
+    assert e.value.code == -20 and "no CPU path" in str(e.value)
+    with pytest.raises(S.SABCError):
+        S.op_build_cdf([1.0, 2.0, 3.0])
