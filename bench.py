@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--particles-per-gpu", type=int, default=0, help="weak scaling: this many particles per rank")
     ap.add_argument("--proposal", default="randomwalk", choices=["randomwalk", "de", "stretch"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=10)
     args = ap.parse_args()
 
@@ -117,8 +118,9 @@ def main():
 
     if W > 0:
         h.update(n_simulation=W * n, proposal=proposal)
-    h.profile_enable(True)
+    h.profile_enable(not args.no_kernel_events)
     barrier()
+    syncs0 = h.host_syncs
     t0 = time.perf_counter()
     h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
     barrier()
@@ -128,6 +130,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    syncs = h.host_syncs - syncs0
     kern_ms, launches = h.profile_get(S._lib.KERNEL_UPDATE)
     red_ms, red_n = h.profile_get(S._lib.KERNEL_REDUCE)
     res_ms, res_n = h.profile_get(S._lib.KERNEL_RESAMPLE)
@@ -180,6 +183,7 @@ def main():
             "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": res_n,
+            "host_syncs_in_timed_region": syncs,
             "init_s": t_init,
             "state": {"n_accept": c["n_accept"], "n_resampling": c["n_resampling"],
                       "n_population_updates": c["n_population_updates"], "eps": h.eps.tolist(),

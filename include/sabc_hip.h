@@ -172,12 +172,19 @@ SABC_API int sabc_op_simulate(sabc_handle *h, const double *theta, int64_t m, ui
 SABC_API int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                             uint32_t out_words[4], double out_normals[2]);
 
+/* Box-Muller pairs of block k for particles pid0..pid0+m-1 (out: z0,z1 interleaved): bulk accuracy
+   check of the device log / sqrt / sincos against the oracle's libm */
+SABC_API int sabc_op_normal_pairs(int32_t device, uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter,
+                                  uint32_t k, int64_t m, double *out_2m);
+
 /* ---- measurement ---- */
 enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
        SABC_KERNEL_COUNT = 4 };
 /* HIP-event timing of the named kernel on the library's stream, accumulated since enable */
 SABC_API int sabc_profile_enable(sabc_handle *h, int32_t on);
 SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
+/* how many times update()/initialize() had to wait for the device so far (run-ahead windows) */
+SABC_API int64_t sabc_host_syncs(const sabc_handle *h);
 
 #ifdef __cplusplus
 }

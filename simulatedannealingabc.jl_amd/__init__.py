@@ -9,7 +9,7 @@ from ._lib import SABCError, build, lib  # noqa: F401
 from .api import SABCresult, SABCstate, initialization, is_logging, sabc, update_population_  # noqa: F401
 from .distributions import Normal, Product, Uniform, product_distribution  # noqa: F401
 from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
-                     op_philox)
+                     op_normal_pairs, op_philox)
 from .models import DeviceDistance, GandK, Gaussian2D, GaussianIID, LotkaVolterra  # noqa: F401
 from .proposals import DifferentialEvolution, Proposal, RandomWalk, StretchMove  # noqa: F401
 
@@ -18,6 +18,6 @@ __all__ = [
     "RandomWalk", "DifferentialEvolution", "StretchMove", "Proposal",
     "Normal", "Uniform", "Product", "product_distribution",
     "DeviceDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",
-    "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox",
+    "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox", "op_normal_pairs",
     "build", "lib", "is_logging",
 ]

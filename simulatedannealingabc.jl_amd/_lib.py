@@ -137,8 +137,11 @@ def lib():
         "sabc_op_simulate": ([vp, dp, C.c_int64, C.c_uint64, C.c_uint64, dp], C.c_int),
         "sabc_op_philox": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                             C.POINTER(C.c_uint32), dp], C.c_int),
+        "sabc_op_normal_pairs": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int64, dp],
+                                 C.c_int),
         "sabc_profile_enable": ([vp, C.c_int32], C.c_int),
         "sabc_profile_get": ([vp, C.c_int32, dp, ip64], C.c_int),
+        "sabc_host_syncs": ([vp], C.c_int64),
     }
     for name, (args, res) in sig.items():
         fn = getattr(L, name)   # AttributeError here = a symbol the header declares is missing

@@ -409,6 +409,24 @@ int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose
   return 0;
 }
 
+int sabc_op_normal_pairs(int32_t device, uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k,
+                         int64_t m, double *out_2m) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (m <= 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  double *d = nullptr;
+  hipError_t e = hipMalloc((void **)&d, (size_t)m * 16);
+  if (e == hipSuccess) e = (hipError_t)launch_normal_pairs(seed, pid0, purpose, iter, k, m, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out_2m, d, (size_t)m * 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  return 0;
+}
+
+int64_t sabc_host_syncs(const sabc_handle *h) { return h ? h->eng->host_syncs() : 0; }
+
 int sabc_profile_enable(sabc_handle *h, int32_t on) {
   if (!h) return SABC_ERR_STATE;
   h->be->profile_enable(on != 0);

@@ -1,0 +1,63 @@
+// control.hpp -- what happens to the algorithm state between two population updates
+// (SimulatedAnnealingABC.jl:334,348-354,367-372; proposals.jl:46-60), as ONE function over the
+// ControlBlock.  It is compiled as device code and run by a single lane (k_control in kernels.hip)
+// so that the host does not have to read the sums back after every update; the CPU engine tests
+// call the very same function on the host.
+#pragma once
+#include "host_math.hpp"
+#include "sabc_types.hpp"
+
+namespace sabc {
+
+SABC_HD inline void control_step(ControlBlock &cb, const ControlArgs &a, double *hist) {
+  const int d = a.d, s = a.s;
+  const double n = a.n_global;
+  const double *S = &cb.sums[1 + 2 * s], *Q = &cb.sums[1 + 2 * s + d];
+
+  if (a.mode & CTRL_ACCUMULATE) cb.n_accept += (int64_t)(cb.sums[0] + 0.5);          // :334
+
+  if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK) {            // update_proposal!
+    double cov[kMaxPara * kMaxPara];
+    hostmath::cov_from_sums(S, Q, d, n, cov);
+    if (d == 1) {
+      cb.sigma[0] = a.prop_p0 * cov[0];                                              // proposals.jl:59
+      if (cb.sigma[0] < 0.0) cb.error = SABC_ERR_NOT_POSDEF;
+      else cb.chol[0] = sqrt(cb.sigma[0]);                                           // proposals.jl:54
+    } else {
+      for (int k = 0; k < d; ++k)
+        for (int l = 0; l < d; ++l)
+          cb.sigma[k * d + l] = a.prop_p0 * (cov[k * d + l] + (k == l ? 1e-8 : 0.0));   // proposals.jl:47
+      if (!hostmath::cholesky(cb.sigma, d, cb.chol)) cb.error = SABC_ERR_NOT_POSDEF;   // MvNormal(...), :42
+    }
+  }
+
+  if (a.mode & CTRL_EPSILON) {                                                       // :350-354
+    if (a.algorithm == SABC_ALG_MULTI_EPS) {
+      double ubar[kMaxStats];
+      for (int j = 0; j < s; ++j) ubar[j] = cb.sums[1 + j] / n;
+      if (!hostmath::eps_multi(ubar, s, a.v, cb.eps)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
+    } else {
+      double tot = 0.0;
+      for (int j = 0; j < s; ++j) tot += cb.sums[1 + j];
+      cb.eps[0] = hostmath::eps_single(tot / (n * (double)s), a.v);                  // mean(u), :353
+    }
+  }
+
+  if (a.mode & CTRL_HISTORY) {                                                       // :367-372
+    if (cb.hist_rows < a.hist_capacity) {
+      double *row = hist + cb.hist_rows * (cb.eps_len + 2 * s);
+      for (int i = 0; i < cb.eps_len; ++i) row[i] = cb.eps[i];
+      for (int j = 0; j < s; ++j) row[cb.eps_len + j] = cb.sums[1 + j] / n;
+      for (int j = 0; j < s; ++j) row[cb.eps_len + s + j] = cb.sums[1 + s + j] / n;
+      cb.hist_rows += 1;
+    } else {
+      cb.error = SABC_ERR_STATE;
+    }
+  }
+
+  // keep the moment sums centred: the sums in hand are relative to the old pivot, so this goes last
+  if (a.mode & CTRL_PIVOT)
+    for (int k = 0; k < d; ++k) cb.pivot[k] += S[k] / n;
+}
+
+}  // namespace sabc

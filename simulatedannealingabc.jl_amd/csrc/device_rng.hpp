@@ -41,20 +41,101 @@ __device__ __forceinline__ u32x4 stream_block(uint64_t seed, uint64_t pid, uint3
   return philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)pid, k, (uint32_t)iter, c3);
 }
 
-// (x + 1/2) * 2^-52 with x the top 52 bits: exact in binary64, in (0,1)
+// (x + 1/2) * 2^-52 with x the top 52 bits of the 64-bit word: exact in binary64, in (0,1).
+// Built without an int->fp conversion: the 52 bits become the mantissa of a double in [1,2) and
+// (1 - 2^-53) is subtracted, which is exact ((x + 1/2) 2^-52 is representable).
 __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
   const uint64_t x = (((uint64_t)hi << 32) | lo) >> 12;
-  return ((double)x + 0.5) * 0x1.0p-52;
+  return __longlong_as_double((long long)(0x3FF0000000000000ull | x)) - 0x1.fffffffffffffp-1;
 }
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
 
+// ---- f64 elementary functions specialised to the Box-Muller input ranges -------------------
+// ocml's log / sincospi / sqrt are correctly-rounded-grade general routines built on double-double
+// arithmetic (52 v_add_f64 per pair in the ISA).  The inputs here are known: u in [2^-53, 1), so
+// no special values, no denormals, no range reduction beyond one table-free step.  Each routine
+// below stays within ~1.5 ulp (tests/test_gpu_parity.py::test_normal_pairs_accuracy).
+
+// q = a / b for finite, normal a, b of moderate magnitude: v_rcp_f64 + two Newton steps + one
+// residual correction (what the compiler emits for '/', minus the scale/fixup for special values)
+__device__ __forceinline__ double div_fast(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  r = fma(fma(-b, r, 1.0), r, r);
+  r = fma(fma(-b, r, 1.0), r, r);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
+
+// sqrt(x) for x in [1e-300, 1e300]: v_rsq_f64 + two coupled Newton steps + one correction
+__device__ __forceinline__ double sqrt_fast(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  return fma(fma(-g, g, x), h, g);
+}
+
+// log(x) for normal x > 0: x = 2^e m with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s),
+// s = (m-1)/(m+1), degree-7 minimax polynomial in s^2 (the classic fdlibm scheme and constants)
+__device__ __forceinline__ double log_fast(double x) {
+  const uint64_t ix = (uint64_t)__double_as_longlong(x);
+  int hx = (int)(ix >> 32);
+  hx += 0x3ff00000 - 0x3fe6a09e;
+  const int e = (hx >> 20) - 0x3ff;
+  hx = (hx & 0x000fffff) + 0x3fe6a09e;
+  const double m = __longlong_as_double((long long)(((uint64_t)(uint32_t)hx << 32) | (ix & 0xffffffffull)));
+  const double f = m - 1.0;
+  const double hfsq = 0.5 * f * f;
+  const double s = div_fast(f, 2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                   2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double R = t2 + t1;
+  const double dk = (double)e;
+  return fma(dk, 6.93147180369123816490e-01, (fma(s, hfsq + R, dk * 1.90821492927058770002e-10) - hfsq) + f);
+}
+
+// sin and cos of 2 pi u for u in (0,1): quadrant k = rint(4u) and r = 4u - k are exact; the two
+// Taylor polynomials run on a = (pi/2) r, |a| <= pi/4
+__device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
+  const double t = 4.0 * u;
+  const double kf = rint(t);
+  const double a = 1.57079632679489661923 * (t - kf);
+  const double a2 = a * a;
+  double p = -1.0 / 1307674368000.0;
+  p = fma(p, a2, 1.0 / 6227020800.0);
+  p = fma(p, a2, -1.0 / 39916800.0);
+  p = fma(p, a2, 1.0 / 362880.0);
+  p = fma(p, a2, -1.0 / 5040.0);
+  p = fma(p, a2, 1.0 / 120.0);
+  p = fma(p, a2, -1.0 / 6.0);
+  const double s = fma(a, a2 * p, a);
+  double q = 1.0 / 20922789888000.0;
+  q = fma(q, a2, -1.0 / 87178291200.0);
+  q = fma(q, a2, 1.0 / 479001600.0);
+  q = fma(q, a2, -1.0 / 3628800.0);
+  q = fma(q, a2, 1.0 / 40320.0);
+  q = fma(q, a2, -1.0 / 720.0);
+  q = fma(q, a2, 1.0 / 24.0);
+  q = fma(q, a2, -0.5);
+  const double c = fma(a2, q, 1.0);
+  const int k = (int)kf;                       // 0..4
+  const double s1 = (k & 1) ? c : s;           // odd quadrant: swap
+  const double c1 = (k & 1) ? s : c;
+  sn = (k & 2) ? -s1 : s1;                     // k = 2,3: sin flips
+  cs = ((k + 1) & 2) ? -c1 : c1;               // k = 1,2: cos flips
+}
+
 __device__ __forceinline__ void box_muller(const u32x4 w, double &z0, double &z1) {
   const double ua = u52(w.x, w.y);
   const double ub = u52(w.z, w.w);
-  const double r = sqrt(-2.0 * log(ua));
+  const double r = sqrt_fast(-2.0 * log_fast(ua));
   double sn, cs;
-  sincospi(2.0 * ub, &sn, &cs);   // angle 2*pi*ub without a range reduction
+  sincos_2pi(ub, sn, cs);
   z0 = r * cs;
   z1 = r * sn;
 }

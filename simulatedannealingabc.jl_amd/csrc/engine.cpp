@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstring>
 
-#include "host_math.hpp"
+#include "control.hpp"
 
 namespace sabc {
 
@@ -25,7 +25,8 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
   m_.seed = cfg.seed;
   const int world = cfg.world < 1 ? 1 : cfg.world;
   sh_ = make_shard(cfg.n_particles, cfg.rank, world);
-  for (int i = 0; i < kMaxPara * kMaxPara; ++i) sigma_[i] = -1.0;   // proposals.jl:32,34 sentinel
+  std::memset(&cb_, 0, sizeof(cb_));
+  for (int i = 0; i < kMaxPara * kMaxPara; ++i) cb_.sigma[i] = -1.0;   // proposals.jl:32,34 sentinel
 }
 
 int Engine::validate() {
@@ -70,18 +71,19 @@ int Engine::validate() {
   }
   np_ = n_partials(d, s);
   eps_len_ = cfg_.algorithm == SABC_ALG_MULTI_EPS ? s : 1;
+  cb_.eps_len = eps_len_;
   return 0;
 }
 
 void Engine::counters(int64_t out[4]) const {
-  out[0] = n_simulation_; out[1] = n_accept_; out[2] = n_resampling_; out[3] = n_population_updates_;
+  out[0] = n_simulation_; out[1] = cb_.n_accept; out[2] = n_resampling_; out[3] = n_population_updates_;
 }
 void Engine::set_counters(const int64_t in[4]) {
-  n_simulation_ = in[0]; n_accept_ = in[1]; n_resampling_ = in[2]; n_population_updates_ = in[3];
+  n_simulation_ = in[0]; cb_.n_accept = in[1]; n_resampling_ = in[2]; n_population_updates_ = in[3];
 }
 int Engine::set_eps(const double *e, int len) {
   if (len != eps_len_) return fail(SABC_ERR_BAD_CONFIG, "epsilon length does not match the algorithm");
-  for (int i = 0; i < len; ++i) eps_[i] = e[i];
+  for (int i = 0; i < len; ++i) cb_.eps[i] = e[i];
   return 0;
 }
 void Engine::history(double *e, double *u, double *r) const {
@@ -90,91 +92,78 @@ void Engine::history(double *e, double *u, double *r) const {
   if (r) std::memcpy(r, rho_hist_.data(), rho_hist_.size() * sizeof(double));
 }
 
-// block partials -> shard sums -> (allreduce over shards) -> host
-int Engine::global_sums(int64_t rows) {
-  int rc = be_->reduce_partials(rows);
-  if (rc) return fail(SABC_ERR_HIP, "reduce_partials failed");
-  if (sh_.world > 1) {
-    rc = coll_->allreduce_sum(be_->sums_buffer(), np_);
-    if (rc) return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
-  }
-  rc = be_->read_sums(sums_);
-  if (rc) return fail(SABC_ERR_HIP, "reading the population sums failed");
+// block partials -> shard sums (ControlBlock::sums) -> allreduce over shards; nothing is read back
+int Engine::global_reduce(int64_t rows) {
+  if (be_->reduce_partials(rows)) return fail(SABC_ERR_HIP, "reduce_partials failed");
+  if (sh_.world > 1 && coll_->allreduce_sum(be_->sums_buffer(), np_))
+    return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
   return 0;
 }
 
-StepCtrl Engine::make_ctrl(const sabc_update_args *a, uint64_t iter) const {
-  StepCtrl c;
-  std::memset(&c, 0, sizeof(c));
-  c.iter = iter;
-  c.eps_len = eps_len_;
-  for (int j = 0; j < kMaxStats; ++j) c.eps[j] = eps_[j];
-  if (a) { c.prop_kind = a->proposal_kind; c.prop_p0 = a->proposal_p0; c.prop_p1 = a->proposal_p1; }
-  const int d = m_.d;
-  for (int i = 0; i < d * d; ++i) c.chol[i] = chol_[i];
-  for (int k = 0; k < d; ++k) c.pivot[k] = pivot_[k];
-  return c;
-}
-
-int Engine::stats_pass() {
-  const StepCtrl c = make_ctrl(nullptr, 0);
+int Engine::stats_reduce() {
   int64_t rows = 0;
-  if (be_->stats(c, &rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
-  return global_sums(rows);
+  if (be_->stats(&rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
+  return global_reduce(rows);
 }
 
-int Engine::recenter() {
-  const int d = m_.d, s = m_.s;
-  const double n = (double)sh_.n_global;
-  for (int k = 0; k < d; ++k) pivot_[k] += sums_[1 + 2 * s + k] / n;
-  return stats_pass();
-}
-
-// update_proposal!(::RandomWalk): proposals.jl:46-48 (n-D) and :58-60 (1-D)
-int Engine::update_proposal(const sabc_update_args &a) {
-  if (a.proposal_kind != SABC_PROP_RANDOMWALK) return 0;     // proposals.jl:116,150
-  const int d = m_.d, s = m_.s;
-  const double *S = &sums_[1 + 2 * s], *Q = &sums_[1 + 2 * s + d];
-  double cov[kMaxPara * kMaxPara];
-  hostmath::cov_from_sums(S, Q, d, (double)sh_.n_global, cov);
-  if (d == 1) {
-    sigma_[0] = a.proposal_p0 * cov[0];                      // proposals.jl:59
-    if (sigma_[0] < 0.0) return fail(SABC_ERR_NOT_POSDEF, "RandomWalk variance is negative");
-    chol_[0] = std::sqrt(sigma_[0]);                         // proposals.jl:54
-    return 0;
-  }
-  for (int k = 0; k < d; ++k)
-    for (int l = 0; l < d; ++l) sigma_[k * d + l] = a.proposal_p0 * (cov[k * d + l] + (k == l ? 1e-8 : 0.0));   // :47
-  if (!hostmath::cholesky(sigma_, d, chol_))
-    return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
+int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool notify) {
+  ControlArgs c;
+  std::memset(&c, 0, sizeof(c));
+  c.mode = mode;
+  c.d = m_.d; c.s = m_.s;
+  c.algorithm = cfg_.algorithm;
+  c.prop_kind = a ? a->proposal_kind : -1;
+  c.prop_p0 = a ? a->proposal_p0 : 0.0;
+  c.n_global = (double)sh_.n_global;
+  c.v = v;
+  c.hist_capacity = hist_capacity_;
+  c.notify_seq = notify ? ++notify_seq_ : 0;
+  if (be_->control(c)) return fail(SABC_ERR_HIP, "control kernel failed");
   return 0;
 }
 
-// :200-204 and :350-354
-int Engine::update_epsilon(double v) {
-  const int s = m_.s;
-  const double n = (double)sh_.n_global;
-  if (cfg_.algorithm == SABC_ALG_MULTI_EPS) {
-    double ubar[kMaxStats];
-    for (int j = 0; j < s; ++j) ubar[j] = sums_[1 + j] / n;
-    if (!hostmath::eps_multi(ubar, s, v, eps_))
-      return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
-  } else {
-    double tot = 0.0;
-    for (int j = 0; j < s; ++j) tot += sums_[1 + j];
-    eps_[0] = hostmath::eps_single(tot / (n * (double)s), v);   // mean(u) over all n*s entries, :203,353
-  }
+int Engine::wait_accept(int64_t *known_accept) {
+  int err = 0;
+  if (be_->wait_notify(notify_seq_, known_accept, &err)) return fail(SABC_ERR_HIP, "waiting for the control step failed");
+  host_syncs_ += 1;
+  if (err) { cb_.error = err; return sync_control(); }
   return 0;
 }
 
-// resample_population, :124-137.  Needs sums_ to hold the CURRENT sum of u; leaves the sums
-// of the resampled population in sums_.
+int Engine::sync_control() {
+  if (be_->read_control(&cb_)) return fail(SABC_ERR_HIP, "reading the control block failed");
+  host_syncs_ += 1;
+  switch (cb_.error) {
+    case 0: return 0;
+    case SABC_ERR_ZERO_MEAN_U: return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
+    case SABC_ERR_NOT_POSDEF: return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
+    default: return fail(cb_.error, "error raised by the device-side control step");
+  }
+}
+
+// the rows the control kernel appended on the device -> the host-side histories (:33-35)
+int Engine::drain_history() {
+  const int s = m_.s, row_len = eps_len_ + 2 * s;
+  const int64_t rows = cb_.hist_rows;
+  if (rows > 0) {
+    std::vector<double> buf((size_t)(rows * row_len));
+    if (be_->read_history(buf.data(), rows, row_len)) return fail(SABC_ERR_HIP, "reading the history rows failed");
+    for (int64_t r = 0; r < rows; ++r) {
+      const double *row = &buf[(size_t)(r * row_len)];
+      eps_hist_.insert(eps_hist_.end(), row, row + eps_len_);
+      u_hist_.insert(u_hist_.end(), row + eps_len_, row + eps_len_ + s);
+      rho_hist_.insert(rho_hist_.end(), row + eps_len_ + s, row + row_len);
+    }
+  }
+  cb_.hist_rows = 0;
+  return 0;
+}
+
+// resample_population, :124-137.  ControlBlock::sums must hold the CURRENT sum of u (the weights
+// kernel takes ubar from there); leaves the sums of the resampled population in its place.
 int Engine::resample(double delta, uint64_t iter) {
   const int d = m_.d, s = m_.s;
-  const double n = (double)sh_.n_global;
-  double ubar[kMaxStats] = {0};
-  for (int j = 0; j < s; ++j) ubar[j] = sums_[1 + j] / n;                   // :126
-  if (be_->resample_weights(ubar, delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :127
+  if (be_->resample_weights(delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :126-127
   const int64_t rows = d + s + 1;
   const double *gathered = be_->pop_block();
   if (sh_.world > 1) {
@@ -184,15 +173,7 @@ int Engine::resample(double delta, uint64_t iter) {
     gathered = g;
   }
   if (be_->resample_draw(gathered, iter)) return fail(SABC_ERR_HIP, "resample draw kernel failed");   // :129-132
-  return stats_pass();
-}
-
-void Engine::push_history() {
-  const int s = m_.s;
-  const double n = (double)sh_.n_global;
-  for (int i = 0; i < eps_len_; ++i) eps_hist_.push_back(eps_[i]);          // :368
-  for (int j = 0; j < s; ++j) u_hist_.push_back(sums_[1 + j] / n);          // :369
-  for (int j = 0; j < s; ++j) rho_hist_.push_back(sums_[1 + s + j] / n);    // :370
+  return stats_reduce();
 }
 
 PartnerView Engine::partner_view(const double *base, int64_t rank_stride, int inactive_half) const {
@@ -228,6 +209,11 @@ int Engine::initialize(int64_t n_simulation) {
                   (long long)sh_.n_global);
     return fail(SABC_ERR_NSIM_TOO_SMALL, buf);
   }
+  for (int k = 0; k < kMaxPara; ++k) cb_.pivot[k] = 0.0;
+  cb_.n_accept = 0; cb_.hist_rows = 0; cb_.error = 0; cb_.eps_len = eps_len_;
+  hist_capacity_ = 4;
+  if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
+  if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
   if (be_->prior_simulate()) return fail(SABC_ERR_HIP, "prior sample / simulate kernel failed");   // :172-179
   const double *gathered_rho = be_->rho_block();
   if (sh_.world > 1) {
@@ -242,19 +228,54 @@ int Engine::initialize(int64_t n_simulation) {
   for (int j = 0; j < s; ++j)
     if (cdf_len_[j] < 3) return fail(SABC_ERR_EMPTY_CDF, "all prior distances of one statistic are zero");
   if (be_->cdf_population()) return fail(SABC_ERR_HIP, "ECDF transform kernel failed");                   // :190-192
-  for (int k = 0; k < kMaxPara; ++k) pivot_[k] = 0.0;
-  int rc = stats_pass();
+  int rc = stats_reduce();
   if (rc) return rc;
-  rc = resample(cfg_.delta, 0);                                             // :197
-  if (rc) return rc;
-  rc = update_epsilon(cfg_.v);                                              // :200-204
-  if (rc) return rc;
+  if ((rc = resample(cfg_.delta, 0))) return rc;                            // :197
+  if ((rc = control(CTRL_EPSILON | CTRL_HISTORY | CTRL_PIVOT, nullptr, cfg_.v))) return rc;   // :200-208
+  if ((rc = sync_control())) return rc;
   clear_history();
-  push_history();                                                           // :180,207-208
+  if ((rc = drain_history())) return rc;                                    // :180,207-208
   n_simulation_ = sh_.n_global;                                             // :213
-  n_accept_ = 0; n_resampling_ = 1; n_population_updates_ = 0;              // :223
+  cb_.n_accept = 0; n_resampling_ = 1; n_population_updates_ = 0;           // :223
   initialized_ = true;
   return 0;
+}
+
+// one population update, enqueued only: the per-particle kernels (:304-331), the fused sums and
+// their allreduce.  Nothing is read back here.
+int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter) {
+  const int d = m_.d;
+  StepArgs c;
+  std::memset(&c, 0, sizeof(c));
+  c.iter = iter;
+  c.prop_kind = a.proposal_kind; c.prop_p0 = a.proposal_p0; c.prop_p1 = a.proposal_p1;
+  int64_t rows = 0, r = 0;
+  if (a.proposal_kind == SABC_PROP_RANDOMWALK) {
+    // RandomWalk ignores the inactive half (proposals.jl:40,52), so both half batches of :304
+    // are independent given eps and Sigma: one launch over the whole shard is the same update.
+    PartnerView none;
+    std::memset(&none, 0, sizeof(none));
+    if (be_->update_range(c, none, 0, sh_.n_local, 0, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
+    rows = r;
+  } else {
+    const int64_t h = sh_.n_local / 2;
+    for (int half = 0; half < 2; ++half) {                                  // :300-304
+      const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
+      const double *base = be_->pop_block();
+      int64_t stride = 0;
+      if (sh_.world > 1) {          // partners come from the inactive halves of ALL shards
+        double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
+        if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
+        if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
+        base = g;
+        stride = (int64_t)d * sh_.cap;
+      }
+      const PartnerView pv = partner_view(base, stride, 1 - half);
+      if (be_->update_range(c, pv, lo, cnt, rows, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
+      rows += r;
+    }
+  }
+  return global_reduce(rows);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -269,68 +290,74 @@ int Engine::update(const sabc_update_args &a) {
   if (a.proposal_kind == SABC_PROP_RANDOMWALK && !(a.proposal_p0 > 0 && a.proposal_p0 <= 1))
     return fail(SABC_ERR_BAD_BETA, "Mixing parameter `β` must be between zero and one.");              // proposals.jl:30
   if (a.n_simulation < 0) return fail(SABC_ERR_BAD_CONFIG, "n_simulation must not be negative");
-  const int s = m_.s, d = m_.d;
   const int64_t N = sh_.n_global;
   const int64_t n_pop = a.n_simulation / N;                                 // :275
   const int64_t n_updates = n_pop * N;                                      // :276
+  const int64_t cph = a.checkpoint_history;
   int64_t last_checkpoint = 0;                                              // :277
   int rc;
-  if (a.proposal_kind == SABC_PROP_RANDOMWALK) {                            // :284
-    if ((rc = stats_pass())) return rc;
-    if ((rc = recenter())) return rc;
-    if ((rc = update_proposal(a))) return rc;
+  // the host mirror is the truth between calls (state setters write into it)
+  cb_.hist_rows = 0; cb_.error = 0; cb_.eps_len = eps_len_;
+  hist_capacity_ = (cph > 0 ? n_pop / cph : 0) + 2;
+  if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
+  if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
+
+  if (a.proposal_kind == SABC_PROP_RANDOMWALK) {                            // update_proposal!, :284
+    if ((rc = stats_reduce())) return rc;
+    if ((rc = control(CTRL_PIVOT, &a, a.v))) return rc;                     // centre the moment sums first
+    if ((rc = stats_reduce())) return rc;
+    if ((rc = control(CTRL_PROPOSAL, &a, a.v))) return rc;
   }
-  const bool two_phase = a.proposal_kind != SABC_PROP_RANDOMWALK;
-  if (n_pop > 0 && two_phase) {
+  if (n_pop > 0 && a.proposal_kind != SABC_PROP_RANDOMWALK) {
     const int64_t need = a.proposal_kind == SABC_PROP_DIFFEVO ? 2 : 1;
     for (int half = 0; half < 2; ++half)
       if (partner_view(nullptr, 0, half).m_total < need)
         return fail(SABC_ERR_BAD_CONFIG, "too few particles in a half batch for this proposal");
   }
-  const int64_t h = sh_.n_local / 2;
-  for (int64_t ix = 1; ix <= n_pop; ++ix) {                                 // :294
-    const uint64_t iter = (uint64_t)(n_population_updates_ + ix);
-    const StepCtrl c = make_ctrl(&a, iter);
-    int64_t rows = 0, r = 0;
-    if (!two_phase) {
-      // RandomWalk ignores the inactive half (proposals.jl:40,52), so both half batches of :304
-      // are independent given eps and Sigma: one launch over the whole shard is the same update.
-      PartnerView none;
-      std::memset(&none, 0, sizeof(none));
-      if (be_->update_range(c, none, 0, sh_.n_local, 0, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
-      rows = r;
-    } else {
-      for (int half = 0; half < 2; ++half) {                                // :300-304
-        const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
-        const double *base = be_->pop_block();
-        int64_t stride = 0;
-        if (sh_.world > 1) {        // partners come from the inactive halves of ALL shards
-          double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
-          if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
-          if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
-          base = g;
-          stride = (int64_t)d * sh_.cap;
-        }
-        const PartnerView pv = partner_view(base, stride, 1 - half);
-        if (be_->update_range(c, pv, lo, cnt, rows, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
-        rows += r;
+
+  const int32_t after_update = CTRL_PROPOSAL | CTRL_EPSILON | CTRL_PIVOT;   // :348-354
+  int64_t known_accept = cb_.n_accept;     // exact as of the last time the host looked
+  int64_t ix = 1;
+  while (ix <= n_pop) {                                                     // :294
+    // The resample test of :340 needs n_accept.  Each update adds at most N accepts, so for the next
+    // W updates the threshold provably cannot be reached and the host need not look: it enqueues
+    // them back to back (eps, Sigma, history are produced on the device) and reads n_accept once.
+    const double threshold = (double)(n_resampling_ + 1) * a.resample;
+    const double slack = threshold - (double)known_accept;
+    int64_t W = n_pop - ix + 1;
+    if (slack < (double)W * (double)N) {
+      W = slack > 0 ? (int64_t)std::ceil(slack / (double)N) - 1 : 0;
+      if (W < 0) W = 0;
+    }
+    if (W >= 1) {
+      for (int64_t w = 0; w < W; ++w, ++ix) {
+        if ((rc = enqueue_update(a, (uint64_t)(n_population_updates_ + ix)))) return rc;
+        int32_t mode = CTRL_ACCUMULATE | after_update;
+        if (cph > 0 && ix % cph == 0) { mode |= CTRL_HISTORY; last_checkpoint = ix; }   // :367-372
+        if ((rc = control(mode, &a, a.v, /*notify=*/w == W - 1 && ix < n_pop))) return rc;
       }
-    }
-    if ((rc = global_sums(rows))) return rc;
-    n_accept_ += (int64_t)std::llround(sums_[0]);                           // :334
-    if ((double)n_accept_ >= (double)(n_resampling_ + 1) * a.resample) {    // :340
-      if ((rc = resample(a.delta, iter))) return rc;                        // :341
-      n_resampling_ += 1;                                                   // :342
-    }
-    if ((rc = update_proposal(a))) return rc;                               // :348
-    if ((rc = update_epsilon(a.v))) return rc;                              // :350-354
-    for (int k = 0; k < d; ++k) pivot_[k] += sums_[1 + 2 * s + k] / (double)N;   // keep the moment sums centred
-    if (a.checkpoint_history > 0 && ix % a.checkpoint_history == 0) {       // :367-372
-      push_history();
-      last_checkpoint = ix;
+      if (ix <= n_pop && (rc = wait_accept(&known_accept))) return rc;
+    } else {
+      // this update may cross the threshold: look at n_accept before deciding (:334,340)
+      const uint64_t iter = (uint64_t)(n_population_updates_ + ix);
+      if ((rc = enqueue_update(a, iter))) return rc;
+      if ((rc = control(CTRL_ACCUMULATE, &a, a.v, /*notify=*/true))) return rc;
+      if ((rc = wait_accept(&known_accept))) return rc;
+      if ((double)known_accept >= threshold) {                              // :340
+        if ((rc = resample(a.delta, iter))) return rc;                      // :341
+        n_resampling_ += 1;                                                 // :342
+      }
+      int32_t mode = after_update;
+      if (cph > 0 && ix % cph == 0) { mode |= CTRL_HISTORY; last_checkpoint = ix; }
+      if ((rc = control(mode, &a, a.v))) return rc;
+      ++ix;
     }
   }
-  if (last_checkpoint != n_pop) push_history();                             // :378-382
+  if (last_checkpoint != n_pop) {                                           // :378-382
+    if ((rc = control(CTRL_HISTORY, &a, a.v))) return rc;
+  }
+  if ((rc = sync_control())) return rc;
+  if ((rc = drain_history())) return rc;
   n_simulation_ += n_updates;                                               // :391
   n_population_updates_ += n_pop;                                           // :394
   return 0;

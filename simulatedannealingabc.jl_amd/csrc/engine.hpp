@@ -29,7 +29,7 @@ class Backend {
   // blocks in backend memory; pop_block() may change after resample_draw()
   virtual double *pop_block() = 0;                  // [(d+s+1)][cap]: theta rows, u rows, weight row
   virtual double *rho_block() = 0;                  // [s][cap]
-  virtual double *sums_buffer() = 0;                // [np]
+  virtual double *sums_buffer() = 0;                // ControlBlock::sums in backend memory (allreduce target)
   virtual double *gather_buffer(int64_t doubles) = 0;
   // K1
   virtual int prior_simulate() = 0;
@@ -37,14 +37,22 @@ class Backend {
   virtual int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) = 0;
   // K3
   virtual int cdf_population() = 0;
-  // K4 on local particles [lo, lo+cnt); partial rows start at row0; returns rows written
-  virtual int update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+  // K4 on local particles [lo, lo+cnt); partial rows start at row0; returns rows written.
+  // eps, the Cholesky factor and the pivot are read from the control block.
+  virtual int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                            int64_t *rows_out) = 0;
-  virtual int stats(const StepCtrl &c, int64_t *rows_out) = 0;
-  virtual int reduce_partials(int64_t rows) = 0;    // -> sums_buffer()
-  virtual int read_sums(double *host_out) = 0;      // blocks until the stream has drained
+  virtual int stats(int64_t *rows_out) = 0;
+  virtual int reduce_partials(int64_t rows) = 0;    // -> ControlBlock::sums
+  // state hand-over between updates (control.hpp), enqueued like a kernel
+  virtual int control(const ControlArgs &a) = 0;
+  // wait until the control step enqueued with notify_seq == seq has run; cheap (mailbox poll)
+  virtual int wait_notify(int64_t seq, int64_t *n_accept, int *error) = 0;
+  virtual int read_control(ControlBlock *out) = 0;  // blocks until the stream has drained
+  virtual int write_control(const ControlBlock &in) = 0;
+  virtual int history_reserve(int64_t rows) = 0;    // capacity of the device-side history buffer
+  virtual int read_history(double *out, int64_t rows, int row_len) = 0;
   // K5
-  virtual int resample_weights(const double *ubar, double delta) = 0;
+  virtual int resample_weights(double delta) = 0;   // ubar comes from ControlBlock::sums
   virtual int resample_draw(const double *gathered_pop, uint64_t iter) = 0;
   virtual double last_ess() = 0;
   // state import/export (host buffers, column-major n_local x k)
@@ -66,7 +74,7 @@ class Engine {
   const Shard &shard() const { return sh_; }
   const ModelDesc &model() const { return m_; }
   int eps_len() const { return eps_len_; }
-  const double *eps() const { return eps_; }
+  const double *eps() const { return cb_.eps; }
   int set_eps(const double *e, int len);
   void counters(int64_t out[4]) const;
   void set_counters(const int64_t in[4]);
@@ -75,21 +83,23 @@ class Engine {
   void clear_history() { eps_hist_.clear(); u_hist_.clear(); rho_hist_.clear(); }
   const int64_t *cdf_len() const { return cdf_len_; }
   void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
-  const double *sigma() const { return sigma_; }
+  const double *sigma() const { return cb_.sigma; }
   bool initialized() const { return initialized_; }
   void mark_initialized() { initialized_ = true; }
   void set_collectives(Collectives *c) { coll_ = c; }
+  // how often update() had to wait for the device (one per run-ahead window), for measurement
+  int64_t host_syncs() const { return host_syncs_; }
 
  private:
   int fail(int code, const std::string &msg) { err_ = msg; return code; }
-  int global_sums(int64_t rows);                    // reduce -> allreduce -> host sums_
-  int stats_pass();                                 // sums_ of the population as it stands
-  int recenter();                                   // pivot := population mean
-  int update_proposal(const sabc_update_args &a);   // proposals.jl:46-48,58-60 from sums_
-  int update_epsilon(double v);                     // :200-204, :350-354 from sums_
+  int global_reduce(int64_t rows);                  // block partials -> shard sums -> allreduce
+  int stats_reduce();                               // sums of the population as it stands
+  int control(int32_t mode, const sabc_update_args *a, double v, bool notify = false);
+  int wait_accept(int64_t *known_accept);           // poll the mailbox of the last notifying control step
+  int sync_control();                               // device -> cb_, raises device-side errors
   int resample(double delta, uint64_t iter);        // :124-137
-  void push_history();                              // :367-372 from sums_
-  StepCtrl make_ctrl(const sabc_update_args *a, uint64_t iter) const;
+  int enqueue_update(const sabc_update_args &a, uint64_t iter);
+  int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
 
   sabc_config cfg_;
@@ -101,13 +111,11 @@ class Engine {
   bool initialized_ = false;
 
   int np_ = 0, eps_len_ = 1;
-  double eps_[kMaxStats] = {0};
-  double sums_[kMaxPartials] = {0};
-  double pivot_[kMaxPara] = {0};
-  double sigma_[kMaxPara * kMaxPara];
-  double chol_[kMaxPara * kMaxPara] = {0};
+  ControlBlock cb_;                                 // host mirror, current after every public call
+  int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
-  int64_t n_simulation_ = 0, n_accept_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
+  int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0;
   std::vector<double> eps_hist_, u_hist_, rho_hist_;
 };
 

@@ -26,12 +26,14 @@ HipBackend::~HipBackend() {
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, sums_dev_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, hist_dev_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (meta_dev_) (void)hipFree(meta_dev_);
-  if (sums_host_) (void)hipHostFree(sums_host_);
+  if (cb_dev_) (void)hipFree(cb_dev_);
+  if (cb_host_) (void)hipHostFree(cb_host_);
+  if (mbox_host_) (void)hipHostFree(mbox_host_);
   if (totals_host_) (void)hipHostFree(totals_host_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
@@ -92,8 +94,12 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (N + 2) * sizeof(double)), "hipMalloc(knots)");
   partial_rows_ = 2 * n_blocks(sh.cap) + 4;
   HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");
-  HB_CHECK(hipMalloc((void **)&sums_dev_, kMaxPartials * sizeof(double)), "hipMalloc(sums)");
-  HB_CHECK(hipHostMalloc((void **)&sums_host_, kMaxPartials * sizeof(double)), "hipHostMalloc(sums)");
+  HB_CHECK(hipMalloc((void **)&cb_dev_, sizeof(ControlBlock)), "hipMalloc(control block)");
+  HB_CHECK(hipMemsetAsync(cb_dev_, 0, sizeof(ControlBlock), stream_), "hipMemset(control block)");
+  HB_CHECK(hipHostMalloc((void **)&cb_host_, sizeof(ControlBlock)), "hipHostMalloc(control block)");
+  HB_CHECK(hipHostMalloc((void **)&mbox_host_, sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
+  mbox_host_->seq = 0; mbox_host_->n_accept = 0; mbox_host_->error = 0;
+  HB_CHECK(hipHostGetDevicePointer((void **)&mbox_dev_, mbox_host_, 0), "hipHostGetDevicePointer(mailbox)");
   const size_t nb = (N + kScanChunk - 1) / kScanChunk;
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
   HB_CHECK(hipMalloc((void **)&block_sums_, 2 * nb * sizeof(double)), "hipMalloc(block_sums)");
@@ -199,7 +205,7 @@ int HipBackend::cdf_population() {
   return 0;
 }
 
-int HipBackend::update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                              int64_t *rows_out) {
   const int64_t rows = n_blocks(cnt);
   if (lo < 0 || cnt < 0 || lo + cnt > sh_.n_local || row0 + rows > partial_rows_) {
@@ -207,36 +213,87 @@ int HipBackend::update_range(const StepCtrl &c, const PartnerView &pv, int64_t l
     return -1;
   }
   prof_begin(SABC_KERNEL_UPDATE);
-  HB_LAUNCH(launch_update(m_, c, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_), "k_update");
+  HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_), "k_update");
   prof_end(SABC_KERNEL_UPDATE);
   *rows_out = rows;
   return 0;
 }
 
-int HipBackend::stats(const StepCtrl &c, int64_t *rows_out) {
-  HB_LAUNCH(launch_stats(m_, c, pop_ptrs(cur_), partials_, stream_), "k_stats");
+int HipBackend::stats(int64_t *rows_out) {
+  HB_LAUNCH(launch_stats(m_, cb_dev_, pop_ptrs(cur_), partials_, stream_), "k_stats");
   *rows_out = n_blocks(sh_.n_local);
   return 0;
 }
 
 int HipBackend::reduce_partials(int64_t rows) {
   prof_begin(SABC_KERNEL_REDUCE);
-  HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, sums_dev_, stream_), "k_reduce_partials");
+  HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, cb_dev_->sums, stream_), "k_reduce_partials");
   prof_end(SABC_KERNEL_REDUCE);
   return 0;
 }
 
-int HipBackend::read_sums(double *host_out) {
-  HB_CHECK(hipMemcpyAsync(sums_host_, sums_dev_, (size_t)np_ * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(sums)");
-  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-  std::memcpy(host_out, sums_host_, (size_t)np_ * sizeof(double));
+int HipBackend::control(const ControlArgs &a) {
+  HB_LAUNCH(launch_control(cb_dev_, a, hist_dev_, mbox_dev_, stream_), "k_control");
   return 0;
 }
 
-int HipBackend::resample_weights(const double *ubar, double delta) {
-  Vec8 ub;
-  for (int j = 0; j < kMaxStats; ++j) ub.v[j] = j < m_.s ? ubar[j] : 1.0;
-  HB_LAUNCH(launch_resample_weights(m_, pop_ptrs(cur_), ub, delta, stream_), "k_resample_weights");
+// Poll the mailbox.  A stream that has drained without the sequence word arriving means the
+// control kernel never ran (a fault upstream): report instead of spinning forever.
+int HipBackend::wait_notify(int64_t seq, int64_t *n_accept, int *error) {
+  for (uint64_t spins = 1;; ++spins) {
+    if (mbox_host_->seq == seq) break;
+    __builtin_ia32_pause();
+    if ((spins & 0x3FFF) == 0) {
+      const hipError_t q = hipStreamQuery(stream_);
+      if (q == hipSuccess) {
+        if (mbox_host_->seq == seq) break;
+        err_ = "control step did not report back although the stream is idle";
+        return -1;
+      }
+      if (q != hipErrorNotReady) return check(q, "hipStreamQuery");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  *n_accept = mbox_host_->n_accept;
+  *error = (int)mbox_host_->error;
+  return 0;
+}
+
+int HipBackend::read_control(ControlBlock *out) {
+  HB_CHECK(hipMemcpyAsync(cb_host_, cb_dev_, sizeof(ControlBlock), hipMemcpyDeviceToHost, stream_), "memcpy(control block)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  std::memcpy(out, cb_host_, sizeof(ControlBlock));
+  return 0;
+}
+
+int HipBackend::write_control(const ControlBlock &in) {
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");     // the staging copy is reused
+  std::memcpy(cb_host_, &in, sizeof(ControlBlock));
+  HB_CHECK(hipMemcpyAsync(cb_dev_, cb_host_, sizeof(ControlBlock), hipMemcpyHostToDevice, stream_), "memcpy(control block)");
+  return 0;
+}
+
+int HipBackend::history_reserve(int64_t rows) {
+  const int row_len = kMaxStats * 3;
+  if (rows > hist_cap_) {
+    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    if (hist_dev_) (void)hipFree(hist_dev_);
+    hist_dev_ = nullptr;
+    HB_CHECK(hipMalloc((void **)&hist_dev_, (size_t)rows * row_len * sizeof(double)), "hipMalloc(history)");
+    hist_cap_ = rows;
+  }
+  return 0;
+}
+
+int HipBackend::read_history(double *out, int64_t rows, int row_len) {
+  if (rows > hist_cap_) { err_ = "read_history: more rows than reserved"; return -1; }
+  HB_CHECK(hipMemcpyAsync(out, hist_dev_, (size_t)rows * row_len * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(history)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::resample_weights(double delta) {
+  HB_LAUNCH(launch_resample_weights(m_, pop_ptrs(cur_), cb_dev_, (double)sh_.n_global, delta, stream_), "k_resample_weights");
   return 0;
 }
 

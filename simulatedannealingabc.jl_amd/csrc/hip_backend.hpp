@@ -17,17 +17,22 @@ class HipBackend : public Backend {
   int allocate(const ModelDesc &m, const Shard &sh) override;
   double *pop_block() override { return pop_[cur_]; }
   double *rho_block() override { return rho_; }
-  double *sums_buffer() override { return sums_dev_; }
+  double *sums_buffer() override { return cb_dev_ ? cb_dev_->sums : nullptr; }   // address arithmetic only
   double *gather_buffer(int64_t doubles) override;
   int prior_simulate() override;
   int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) override;
   int cdf_population() override;
-  int update_range(const StepCtrl &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+  int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                    int64_t *rows_out) override;
-  int stats(const StepCtrl &c, int64_t *rows_out) override;
+  int stats(int64_t *rows_out) override;
   int reduce_partials(int64_t rows) override;
-  int read_sums(double *host_out) override;
-  int resample_weights(const double *ubar, double delta) override;
+  int control(const ControlArgs &a) override;
+  int wait_notify(int64_t seq, int64_t *n_accept, int *error) override;
+  int read_control(ControlBlock *out) override;
+  int write_control(const ControlBlock &in) override;
+  int history_reserve(int64_t rows) override;
+  int read_history(double *out, int64_t rows, int row_len) override;
+  int resample_weights(double delta) override;
   int resample_draw(const double *gathered_pop, uint64_t iter) override;
   double last_ess() override;
   int download(double *theta, double *u, double *rho) override;
@@ -69,7 +74,10 @@ class HipBackend : public Backend {
   int64_t cdf_len_[kMaxStats] = {0};
   double *partials_ = nullptr;
   int64_t partial_rows_ = 0;
-  double *sums_dev_ = nullptr, *sums_host_ = nullptr;
+  ControlBlock *cb_dev_ = nullptr, *cb_host_ = nullptr;   // device block + pinned staging copy
+  Mailbox *mbox_host_ = nullptr, *mbox_dev_ = nullptr;    // pinned + mapped: device posts, host polls
+  double *hist_dev_ = nullptr;
+  int64_t hist_cap_ = 0;
   double *gather_ = nullptr;
   int64_t gather_cap_ = 0;
   double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr, *totals_host_ = nullptr;

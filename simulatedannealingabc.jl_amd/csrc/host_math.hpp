@@ -1,58 +1,79 @@
-// host_math.hpp -- the O(s) / O(d^3) scalar pieces of a population update that run on the host
-// between kernels: both epsilon schedules (SimulatedAnnealingABC.jl:92-117), the covariance
-// from fused moment sums (proposals.jl:47,59) and its Cholesky factor (implicit in
-// MvNormal(...), proposals.jl:42).  Pure C++: shared by libsabc_hip.so and the CPU engine tests.
+// host_math.hpp -- the O(s) / O(d^3) scalar pieces of a population update: both epsilon schedules
+// (SimulatedAnnealingABC.jl:92-117), the covariance from fused moment sums (proposals.jl:47,59)
+// and its Cholesky factor (implicit in MvNormal(...), proposals.jl:42).  Compiled twice: as device
+// code for the single-lane control kernel (k_control in kernels.hip, so that a population update
+// needs no host round trip) and as plain C++ for the operator entry points and the CPU engine tests.
 #pragma once
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
 
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SABC_HD __host__ __device__
+#else
+#define SABC_HD
+#endif
+
 namespace sabc {
 namespace hostmath {
 
 // update_epsilon_single_eps (:92-95): root of e^2 + v e^1.5 - ubar^2 on (0, ubar).
-// Roots.find_zero with a bracket is bisection down to adjacent floats; same here.
-inline double eps_single(double ubar, double v) {
-  if (ubar <= DBL_EPSILON) return 0.0;
+// With e = x^2 this is g(x) = x^4 + v x^3 - ubar^2, convex and increasing for x > 0 with
+// g(sqrt(ubar)) > 0, so Newton from sqrt(ubar) decreases monotonically onto the root (no sqrt in
+// the loop; a handful of iterations instead of ~70 bisection steps on the single control lane).
+SABC_HD inline double eps_single(double ubar, double v) {
+  if (ubar <= DBL_EPSILON) return 0.0;                      // :93 ubar <= eps()
   const double u2 = ubar * ubar;
-  double lo = 0.0, hi = ubar;   // f(lo) < 0 < f(hi)
-  for (int it = 0; it < 2200; ++it) {
-    const double mid = lo + 0.5 * (hi - lo);
-    if (!(mid > lo && mid < hi)) break;
-    const double f = mid * mid + v * mid * std::sqrt(mid) - u2;
-    if (f > 0.0) hi = mid; else lo = mid;
+  double x = sqrt(ubar);
+  for (int it = 0; it < 200; ++it) {
+    const double x2 = x * x;
+    const double g = x2 * x2 + v * x2 * x - u2;
+    const double gp = 4.0 * x2 * x + 3.0 * v * x2;
+    const double xn = x - g / gp;
+    if (!(xn < x)) break;                                   // stopped decreasing: converged to rounding
+    x = xn;
   }
-  // the bracket is now two neighbouring doubles; return the end with the smaller residual
-  const double fl = std::fabs(lo * lo + v * lo * std::sqrt(lo) - u2);
-  const double fh = std::fabs(hi * hi + v * hi * std::sqrt(hi) - u2);
-  return fl <= fh ? lo : hi;
+  return x * x;
 }
 
 // (1 - e^-b (1 + b)) / (b (1 - e^-b)) of :113, i.e. the mean of the density ~exp(-b u) on [0,1],
 // written as 1/b - 1/(e^b - 1) to avoid the cancellation of the literal form.
-inline double tilted_mean(double b) {
-  if (std::fabs(b) < 1e-2) {
+SABC_HD inline double tilted_mean(double b) {
+  if (fabs(b) < 1e-2) {
     const double b2 = b * b;
     return 0.5 - b / 12.0 + b * b2 / 720.0 - b * b2 * b2 / 30240.0 + b * b2 * b2 * b2 / 1209600.0;
   }
-  return 1.0 / b - 1.0 / std::expm1(b);
+  return 1.0 / b - 1.0 / expm1(b);
 }
 
-// beta_i of :113: tilted_mean(beta) = ubar_i.  Decreasing in beta, 1/2 at 0, < 1/beta for beta > 0.
-inline double multi_eps_beta(double ub) {
+// d/db of tilted_mean
+SABC_HD inline double tilted_mean_deriv(double b) {
+  if (fabs(b) < 1e-2) { const double b2 = b * b; return -1.0 / 12.0 + b2 / 240.0 - b2 * b2 / 6048.0; }
+  const double em = expm1(b);
+  return -1.0 / (b * b) + (em + 1.0) / (em * em);
+}
+
+// beta_i of :113: tilted_mean(beta) = ubar_i.  Decreasing in beta, 1/2 at 0, < 1/beta for beta > 0:
+// the root lies in (0, 1/ubar_i].  Newton kept inside the bracket, bisection when it leaves it.
+SABC_HD inline double multi_eps_beta(double ub) {
   if (ub == 0.5) return 0.0;
-  if (ub > 0.5) return -multi_eps_beta(1.0 - ub);   // tilted_mean(-b) = 1 - tilted_mean(b)
-  double lo = 0.0, hi = 1.0 / ub;                   // f(lo) > 0 > f(hi)
-  for (int it = 0; it < 2200; ++it) {
-    const double mid = lo + 0.5 * (hi - lo);
-    if (!(mid > lo && mid < hi)) break;
-    if (tilted_mean(mid) - ub > 0.0) lo = mid; else hi = mid;
+  const bool mirror = ub > 0.5;                      // tilted_mean(-b) = 1 - tilted_mean(b)
+  if (mirror) ub = 1.0 - ub;
+  double lo = 0.0, hi = 1.0 / ub, b = hi;
+  for (int it = 0; it < 200; ++it) {
+    const double f = tilted_mean(b) - ub;
+    if (f > 0.0) lo = b; else hi = b;
+    double bn = b - f / tilted_mean_deriv(b);
+    if (!(bn > lo && bn < hi)) bn = lo + 0.5 * (hi - lo);
+    if (bn == b || fabs(bn - b) <= 4.0 * DBL_EPSILON * fabs(bn)) { b = bn; break; }
+    b = bn;
   }
-  return std::fabs(tilted_mean(lo) - ub) <= std::fabs(tilted_mean(hi) - ub) ? lo : hi;
+  return mirror ? -b : b;
 }
 
 // update_epsilon_multi_eps (:100-117); returns false when some ubar_i <= eps() (:107-109)
-inline bool eps_multi(const double *ubar, int s, double v, double *eps_out) {
+SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out) {
   double cn = 1.0;                                   // (2s+2)! / ((s+1)! (s+2)!)  (:103)
   for (int k = 1; k <= s + 1; ++k) cn = cn * (double)(s + 1 + k) / (double)k;
   cn /= (double)(s + 2);
@@ -62,17 +83,17 @@ inline bool eps_multi(const double *ubar, int s, double v, double *eps_out) {
     double num = 1.0, prodq = 1.0;
     for (int j = 0; j < s; ++j) {
       const double q = ubar[j] / ui;                 // :110
-      num += std::pow(q, s / 2.0);                   // :111
+      num += pow(q, s / 2.0);                   // :111
       prodq *= q;
     }
-    const double den = cn * (s + 1) * std::pow(ui, 1.0 + s / 2.0) * prodq;   // :112
+    const double den = cn * (s + 1) * pow(ui, 1.0 + s / 2.0) * prodq;   // :112
     eps_out[i] = 1.0 / (multi_eps_beta(ui) + v * num / den);                 // :113-114
   }
   return true;
 }
 
 // row-major lower Cholesky; false if not positive definite
-inline bool cholesky(const double *a, int d, double *l) {
+SABC_HD inline bool cholesky(const double *a, int d, double *l) {
   for (int i = 0; i < d * d; ++i) l[i] = 0.0;
   for (int i = 0; i < d; ++i)
     for (int j = 0; j <= i; ++j) {
@@ -80,7 +101,7 @@ inline bool cholesky(const double *a, int d, double *l) {
       for (int k = 0; k < j; ++k) sum -= l[i * d + k] * l[j * d + k];
       if (i == j) {
         if (!(sum > 0.0)) return false;
-        l[i * d + i] = std::sqrt(sum);
+        l[i * d + i] = sqrt(sum);
       } else {
         l[i * d + j] = sum / l[j * d + j];
       }
@@ -90,7 +111,7 @@ inline bool cholesky(const double *a, int d, double *l) {
 
 // sample covariance (n-1 denominator, StatsBase.cov) from pivot-shifted sums:
 //   S_k = sum (x_k - c_k),  Q_kl = sum (x_k - c_k)(x_l - c_l) (row-major lower, l <= k)
-inline void cov_from_sums(const double *S, const double *Q, int d, double n, double *cov) {
+SABC_HD inline void cov_from_sums(const double *S, const double *Q, int d, double n, double *cov) {
   int q = 0;
   for (int k = 0; k < d; ++k)
     for (int l = 0; l <= k; ++l, ++q) {

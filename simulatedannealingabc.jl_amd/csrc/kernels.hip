@@ -11,6 +11,7 @@
 //    wave shuffles -> LDS across the 4 waves of a block -> one partial row per block, summed
 //    later in a fixed order (bitwise reproducible for a given grid).
 #include <hip/hip_runtime.h>
+#include "control.hpp"
 #include "device_models.hpp"
 #include "kernels.hpp"
 
@@ -38,14 +39,14 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], doub
 }
 
 template <int D, int S>
-__device__ __forceinline__ void moment_terms(const StepCtrl &c, bool accepted, const double *th, const double *u,
-                                             const double *rho, double (&acc)[n_partials(D, S)]) {
+__device__ __forceinline__ void moment_terms(const double *__restrict__ pivot, bool accepted, const double *th,
+                                             const double *u, const double *rho, double (&acc)[n_partials(D, S)]) {
   acc[0] = accepted ? 1.0 : 0.0;
 #pragma unroll
   for (int j = 0; j < S; ++j) { acc[1 + j] = u[j]; acc[1 + S + j] = rho[j]; }
   double dk[D];
 #pragma unroll
-  for (int k = 0; k < D; ++k) { dk[k] = th[k] - c.pivot[k]; acc[1 + 2 * S + k] = dk[k]; }
+  for (int k = 0; k < D; ++k) { dk[k] = th[k] - pivot[k]; acc[1 + 2 * S + k] = dk[k]; }
   int q = 1 + 2 * S + D;
 #pragma unroll
   for (int k = 0; k < D; ++k)
@@ -69,8 +70,8 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
 // ------------------------------------------------------------------------------------------
 template <int MODEL, int D, int S, int PROP>
 __global__ void __launch_bounds__(kBlock)
-k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cdf, const PartnerView pv,
-         const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
+k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
+         const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   double acc[NP];
 #pragma unroll
@@ -101,7 +102,7 @@ k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cd
       for (int k = 0; k < D; ++k) {
         double a = 0.0;
 #pragma unroll
-        for (int l = 0; l <= k; ++l) a += c.chol[k * D + l] * z[l];
+        for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
         thp[k] = th[k] + a;
       }
     } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
@@ -146,7 +147,7 @@ k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cd
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         up[j] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rp[j]);   // :316
-        const double e = (c.eps_len == 1) ? c.eps[0] : c.eps[j];
+        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (u[j] - up[j]) / e;                                             // :319
       }
       log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
@@ -165,7 +166,7 @@ k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cd
         pp.rho[(int64_t)j * pp.cap + li] = rp[j];
       }
     }
-    moment_terms<D, S>(c, accepted, th, u, rho, acc);
+    moment_terms<D, S>(cb->pivot, accepted, th, u, rho, acc);
   }
   block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
 }
@@ -173,7 +174,7 @@ k_update(const ModelDesc m, const StepCtrl c, const PopPtrs pp, const CdfPtrs cd
 // moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
 template <int D, int S>
 __global__ void __launch_bounds__(kBlock)
-k_stats(const StepCtrl c, const PopPtrs pp, double *__restrict__ partials) {
+k_stats(const ControlBlock *__restrict__ cb, const PopPtrs pp, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   double acc[NP];
 #pragma unroll
@@ -188,25 +189,37 @@ k_stats(const StepCtrl c, const PopPtrs pp, double *__restrict__ partials) {
       u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
       rho[j] = pp.rho[(int64_t)j * pp.cap + li];
     }
-    moment_terms<D, S>(c, false, th, u, rho, acc);
+    moment_terms<D, S>(cb->pivot, false, th, u, rho, acc);
   }
   block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
 }
 
-// fixed-order sum of the per-block partial rows (single block)
+// fixed-order sum of the per-block partial rows: block c reduces component c
 __global__ void __launch_bounds__(kBlock)
 k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ sums) {
   __shared__ double sm[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = 0; c < np; ++c) {
-    double v = 0.0;
-    for (int64_t r = threadIdx.x; r < rows; r += kBlock) v += partials[r * np + c];
+  const int c = blockIdx.x;
+  double v = 0.0;
+#pragma unroll 4
+  for (int64_t r = threadIdx.x; r < rows; r += kBlock) v += partials[r * np + c];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) sm[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) sums[c] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
-    __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[c] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+// the state hand-over between two population updates, one lane (control.hpp)
+__global__ void k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *mbox) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  control_step(*cb, a, hist);
+  if (a.notify_seq != 0) {
+    mbox->n_accept = cb->n_accept;
+    mbox->error = cb->error;
+    __threadfence_system();                 // payload before the sequence word, visible to the host
+    mbox->seq = a.notify_seq;
+    __threadfence_system();
   }
 }
 
@@ -240,11 +253,15 @@ __global__ void __launch_bounds__(kBlock) k_cdf_population(const int d, const in
 // K5: resample (SimulatedAnnealingABC.jl:124-137)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
-k_resample_weights(const int d, const int s, const PopPtrs pp, const Vec8 ubar, const double delta) {
+k_resample_weights(const int d, const int s, const PopPtrs pp, const ControlBlock *__restrict__ cb,
+                   const double n_global, const double delta) {
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= pp.n_local) return;
   double a = 0.0;
-  for (int j = 0; j < s; ++j) a += pp.pop[(int64_t)(d + j) * pp.cap + li] * delta / ubar.v[j];   // :127
+  for (int j = 0; j < s; ++j) {
+    const double ubar = cb->sums[1 + j] / n_global;                                         // :126
+    a += pp.pop[(int64_t)(d + j) * pp.cap + li] * delta / ubar;                             // :127
+  }
   pp.pop[(int64_t)(d + s) * pp.cap + li] = exp(-a);
 }
 
@@ -425,6 +442,16 @@ __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, ui
   box_muller(w, normals[0], normals[1]);
 }
 
+__global__ void __launch_bounds__(kBlock)
+k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= m) return;
+  double z0, z1;
+  box_muller(stream_block(seed, pid0 + (uint64_t)i, purpose, iter, k), z0, z1);
+  out[2 * i] = z0;
+  out[2 * i + 1] = z1;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -461,13 +488,13 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
   return SABC_LAUNCH_RC();
 }
 
-int launch_update(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, CdfPtrs cdf, PartnerView pv, int64_t act_lo,
-                  int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
+int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
+                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
   if (act_n <= 0) return 0;
   const dim3 grid((unsigned)n_blocks(act_n)), block(kBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
 #define CALLP(M, D, S, P) \
-  hipLaunchKernelGGL((k_update<M, D, S, P>), grid, block, 0, stream, m, c, pp, cdf, pv, act_lo, act_n, out)
+  hipLaunchKernelGGL((k_update<M, D, S, P>), grid, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out)
 #define CALL(M, D, S)                                                           \
   switch (c.prop_kind) {                                                        \
     case SABC_PROP_RANDOMWALK: CALLP(M, D, S, SABC_PROP_RANDOMWALK); break;     \
@@ -481,24 +508,30 @@ int launch_update(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, CdfPtrs cdf
   return SABC_LAUNCH_RC();
 }
 
-int launch_stats(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, double *partials, hipStream_t stream) {
+int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream) {
   if (pp.n_local <= 0) return 0;
   const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
-#define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, c, pp, partials)
+#define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, cb, pp, partials)
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
   return SABC_LAUNCH_RC();
 }
 
 int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, stream, partials, rows, np, sums);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)np), dim3(kBlock), 0, stream, partials, rows, np, sums);
   return SABC_LAUNCH_RC();
 }
 
-int launch_resample_weights(const ModelDesc &m, PopPtrs pp, Vec8 ubar, double delta, hipStream_t stream) {
+int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream) {
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, stream, cb, a, hist, mbox);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
+                            hipStream_t stream) {
   if (pp.n_local <= 0) return 0;
   hipLaunchKernelGGL(k_resample_weights, dim3((unsigned)n_blocks(pp.n_local)), dim3(kBlock), 0, stream, m.d, m.s, pp,
-                     ubar, delta);
+                     cb, n_global, delta);
   return SABC_LAUNCH_RC();
 }
 
@@ -552,6 +585,13 @@ int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, ui
 #define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out)
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
+  return SABC_LAUNCH_RC();
+}
+
+int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,
+                        hipStream_t stream) {
+  if (m <= 0) return 0;
+  hipLaunchKernelGGL(k_normal_pairs, dim3((unsigned)n_blocks(m)), dim3(kBlock), 0, stream, seed, pid0, purpose, iter, k, m, out);
   return SABC_LAUNCH_RC();
 }
 

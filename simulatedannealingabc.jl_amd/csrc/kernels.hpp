@@ -20,10 +20,6 @@ struct CdfPtrs {
   int64_t len[kMaxStats];
 };
 
-struct Vec8 {
-  double v[kMaxStats];
-};
-
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 
@@ -35,14 +31,17 @@ int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
 int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
 // K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
 // writes one partial row per block at partials[(row0 + blockIdx) * np]
-int launch_update(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, CdfPtrs cdf, PartnerView pv, int64_t act_lo,
-                  int64_t act_n, double *partials, int64_t row0, hipStream_t stream);
+int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
+                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0
-int launch_stats(const ModelDesc &m, const StepCtrl &c, PopPtrs pp, double *partials, hipStream_t stream);
+int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream);
 // sums[c] = sum over rows of partials[row][c] in a fixed order
 int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream);
+// single-lane state hand-over (control.hpp): n_accept, Sigma / Cholesky, eps, pivot, history row
+int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream);
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
-int launch_resample_weights(const ModelDesc &m, PopPtrs pp, Vec8 ubar, double delta, hipStream_t stream);
+int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
+                            hipStream_t stream);
 // K5b: inclusive scan of the global weight vector (gathered layout [world][rows][cap]) -> cum[n_global];
 // totals[0] = sum w, totals[1] = sum w^2                               :129,134
 int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
@@ -63,6 +62,8 @@ int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m
 int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
                           double *rho_out, hipStream_t stream);
+int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,
+                        hipStream_t stream);
 int launch_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k, uint32_t *words,
                         double *normals, hipStream_t stream);
 

@@ -18,17 +18,51 @@ struct ModelDesc {
   uint64_t seed;
 };
 
-// Everything that is constant during one population update (SimulatedAnnealingABC.jl:294-354):
-// eps (:350-354), the proposal's parameters and, for RandomWalk, the Cholesky factor of
-// Sigma (proposals.jl:42,47) hoisted from per-particle to per-update.
-struct StepCtrl {
+// Per-launch arguments of the update kernel that do not live in the control block.
+struct StepArgs {
   uint64_t iter;                 // global population-update index (RNG counter word)
-  int32_t eps_len;               // 1 (:single_eps) or s (:multi_eps)
-  int32_t prop_kind;
-  double eps[kMaxStats];
-  double prop_p0, prop_p1;
-  double chol[kMaxPara * kMaxPara];   // row-major lower factor (1-D: sqrt(Sigma))
-  double pivot[kMaxPara];             // shift used by the fused moment sums
+  int32_t prop_kind, reserved;
+  double prop_p0, prop_p1;       // RandomWalk beta | DE gamma0, sigma_gamma | Stretch a
+};
+
+// Device-resident control block: everything a population update hands to the next one.  Written
+// by the single-lane control kernel (and by the host through the state setters), read by the
+// update kernel through scalar loads.  Keeping it in HBM is what lets the host enqueue several
+// population updates back to back without reading anything back.
+struct ControlBlock {
+  double eps[kMaxStats];                 // state.eps (SimulatedAnnealingABC.jl:29)
+  double chol[kMaxPara * kMaxPara];      // row-major lower Cholesky factor of Sigma (1-D: sqrt(Sigma))
+  double sigma[kMaxPara * kMaxPara];     // RandomWalk.Sigma (proposals.jl:26)
+  double pivot[kMaxPara];                // shift of the fused moment sums
+  double sums[1 + 2 * kMaxStats + kMaxPara + kMaxPara * (kMaxPara + 1) / 2];   // last global sums
+  int64_t n_accept;                      // state.n_accept
+  int64_t hist_rows;                     // rows appended to the device history buffer
+  int32_t error;                         // 0 or a SABC_ERR_* raised on the device
+  int32_t eps_len;
+};
+
+// what the control kernel is asked to do after a reduction
+enum : int32_t {
+  CTRL_ACCUMULATE = 1,    // n_accept += sums[0]                          (:334)
+  CTRL_PROPOSAL = 2,      // Sigma, chol from sums                        (:348, proposals.jl:46-60)
+  CTRL_EPSILON = 4,       // eps from sums                                (:350-354)
+  CTRL_PIVOT = 8,         // pivot += S / n
+  CTRL_HISTORY = 16       // append (eps, mean u, mean rho)               (:367-372)
+};
+
+struct ControlArgs {
+  int32_t mode, d, s, algorithm, prop_kind, reserved;
+  double n_global, v, prop_p0;
+  int64_t hist_capacity;
+  int64_t notify_seq;                    // != 0: post (n_accept, error, seq) to the host mailbox
+};
+
+// Pinned, host-visible words the control kernel posts to so that the host can learn n_accept
+// (the resample test of :340) by polling instead of draining the stream.
+struct Mailbox {
+  volatile int64_t seq;
+  volatile int64_t n_accept;
+  volatile int64_t error;
 };
 
 // Layout of the fused per-update sums ("partials"): one row of `np` doubles.

@@ -179,6 +179,10 @@ class SabcHandle:
         return out
 
     # ---- measurement ----
+    @property
+    def host_syncs(self):
+        return int(self._L.sabc_host_syncs(self._h))
+
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))
 
@@ -231,3 +235,11 @@ def op_philox(seed, pid, purpose, it, k, device=0):
     if rc:
         raise SABCError(rc, _lib.global_error())
     return [int(x) for x in w], z
+
+
+def op_normal_pairs(seed, pid0, m, purpose=1, it=0, k=0, device=0):
+    out = np.empty((int(m), 2))
+    rc = _lib.lib().sabc_op_normal_pairs(device, int(seed), int(pid0), int(purpose), int(it), int(k), int(m), _dp(out))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return out

@@ -60,4 +60,4 @@ def test_hip_reproduces_golden(S, gpu, path):
     for j, (ln, head) in enumerate(zip(g["cdf_len"], g["cdf_knots_head"])):
         kn = st.cdfs_dist_prior.knots(j)
         assert len(kn) == ln
-        np.testing.assert_allclose(kn[:8], head, rtol=1e-12)
+        np.testing.assert_allclose(kn[:8], head, rtol=1e-9, atol=1e-12)   # distances are differences: cancellation

@@ -24,6 +24,18 @@ def test_philox_words_bit_exact(S, O, gpu):
     assert S.op_philox(0, 0, 0, 0, 0)[0] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]   # Random123 KAT
 
 
+def test_normal_pairs_accuracy(S, O, gpu):
+    """The device Box-Muller (range-specialised log / sqrt / sincos in csrc/device_rng.hpp) against the
+    oracle's glibc normals on 200k Philox blocks: same words, so only the f64 math differs."""
+    m = 200_000
+    got = S.op_normal_pairs(SEED, 10**9, m, purpose=1, it=3, k=7)
+    want = np.array([O.normal_pair(SEED, 10**9 + i, 1, 3, 7) for i in range(m)])
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() < 4e-15                      # a few ulp; the oracle's own cos(2 pi u) carries ~7e-16
+    z = got.ravel()
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and abs(z.var() - 1) < 0.01 and np.abs(z).max() < 8.6
+
+
 @pytest.mark.parametrize("name", list(MODELS))
 def test_device_simulators_match_oracle(S, O, gpu, name):
     model, prior = hip_model_prior(S, name)
