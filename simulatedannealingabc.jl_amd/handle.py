@@ -36,13 +36,16 @@ class SabcHandle:
         cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)
         self.cfg = cfg
         self.d, self.s = cfg.n_para, cfg.n_stats
-        self._L = _lib.lib()
+        self._L = self._load_library()
         h = C.c_void_p()
         rc = self._L.sabc_create(C.byref(cfg), C.byref(h))
         if rc:
-            raise SABCError(rc, _lib.global_error())
+            raise SABCError(rc, self._L.sabc_last_global_error().decode("utf-8", "replace"))
         self._h = h
         self._keep = []   # ctypes callbacks must outlive the handle
+
+    def _load_library(self):
+        return _lib.lib()          # libsabc_hip.so; raises if it is missing (no fallback)
 
     # ---- lifetime ----
     def close(self):

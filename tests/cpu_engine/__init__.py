@@ -1,0 +1,52 @@
+"""CPU harness for the product's host engine (TEST INFRASTRUCTURE; see ref_backend.cpp).
+Builds tests/cpu_engine/libsabc_cpu_engine.so with g++ from the product's engine.cpp +
+control.hpp and a Backend made of oracle calls, and exposes it through the same Python handle
+class the product uses."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(_HERE))
+LIB = os.path.join(_HERE, "libsabc_cpu_engine.so")
+_SRCS = [
+    os.path.join(_HERE, "ref_backend.cpp"),
+    os.path.join(ROOT, "simulatedannealingabc.jl_amd", "csrc", "engine.cpp"),
+    os.path.join(ROOT, "oracle", "sabc_oracle.c"),
+]
+_DEPS = _SRCS + [os.path.join(ROOT, "simulatedannealingabc.jl_amd", "csrc", f)
+                 for f in ("engine.hpp", "control.hpp", "host_math.hpp", "sabc_types.hpp")] + \
+        [os.path.join(ROOT, "include", "sabc_hip.h"), os.path.join(ROOT, "oracle", "sabc_oracle.h")]
+
+
+def build():
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(p) for p in _DEPS):
+        return LIB
+    obj = os.path.join(_HERE, "sabc_oracle.o")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-c", _SRCS[2], "-o", obj])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off",
+                           "-o", LIB, _SRCS[0], _SRCS[1], obj, "-lm"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import sabc_amd
+        _lib = sabc_amd._lib.bind(C.CDLL(build()), strict=False)
+    return _lib
+
+
+def handle_class():
+    import sabc_amd
+
+    class CpuEngineHandle(sabc_amd.SabcHandle):
+        """Same host engine, oracle-backed kernels; for tests only."""
+
+        def _load_library(self):
+            return lib()
+
+    return CpuEngineHandle

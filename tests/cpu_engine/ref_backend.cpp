@@ -1,0 +1,401 @@
+// ref_backend.cpp -- TEST INFRASTRUCTURE (never shipped, never loaded by the product package).
+//
+// Runs the product's host engine (simulatedannealingabc.jl_amd/csrc/engine.cpp + control.hpp:
+// sharding arithmetic, run-ahead windows, resample decisions, collectives sequencing, history)
+// on a CPU with a Backend whose "kernels" are loops over the oracle's per-particle functions
+// (oracle/sabc_oracle.c).  Purpose: exercise the world > 1 code path with torch.distributed
+// "gloo" where no GPU exists, and give the sharded HIP runs a reference with the SAME shard
+// colouring.  It exports the subset of include/sabc_hip.h the tests need, under the same names.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sabc_hip.h"
+#include "../../oracle/sabc_oracle.h"
+#include "../../simulatedannealingabc.jl_amd/csrc/control.hpp"
+#include "../../simulatedannealingabc.jl_amd/csrc/engine.hpp"
+
+using namespace sabc;
+
+namespace {
+
+constexpr int kBlockRows = 256;   // same partial-row granularity as the device kernels
+
+class RefBackend : public Backend {
+ public:
+  int allocate(const ModelDesc &m, const Shard &sh) override {
+    m_ = m; sh_ = sh; np_ = n_partials(m.d, m.s);
+    rows_ = m.d + m.s + 1;
+    for (auto &p : pop_) p.assign((size_t)rows_ * sh.cap, 0.0);
+    rho_.assign((size_t)m.s * sh.cap, 0.0);
+    knots_.assign((size_t)m.s * (sh.n_global + 2), 0.0);
+    partials_.assign((size_t)(2 * ((sh.cap + kBlockRows - 1) / kBlockRows) + 4) * np_, 0.0);
+    std::memset(&cb_, 0, sizeof(cb_));
+    std::memset(&oc_, 0, sizeof(oc_));
+    oc_.n_particles = sh.n_global; oc_.n_para = m.d; oc_.n_stats = m.s;
+    oc_.model_id = m.model_id; oc_.n_model_params = m.n_model_params;
+    for (int i = 0; i < ORC_MAX_MODEL_PARAMS; ++i) oc_.model_params[i] = m.p[i];
+    for (int k = 0; k < ORC_MAX_PARA; ++k) { oc_.prior_kind[k] = m.prior_kind[k]; oc_.prior_a[k] = m.prior_a[k]; oc_.prior_b[k] = m.prior_b[k]; }
+    oc_.seed = m.seed;
+    return 0;
+  }
+  double *pop_block() override { return pop_[cur_].data(); }
+  double *rho_block() override { return rho_.data(); }
+  double *sums_buffer() override { return cb_.sums; }
+  double *gather_buffer(int64_t doubles) override {
+    if ((int64_t)gather_.size() < doubles) gather_.resize((size_t)doubles);
+    return gather_.data();
+  }
+
+  int prior_simulate() override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap;
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      double th[ORC_MAX_PARA], r[ORC_MAX_STATS];
+      const uint64_t gid = (uint64_t)(sh_.gid0 + li);
+      orc_prior_sample(&oc_, gid, th);
+      if (orc_simulate(&oc_, th, gid, 0, r)) return -1;
+      for (int k = 0; k < d; ++k) pop_[cur_][(size_t)k * cap + li] = th[k];
+      for (int j = 0; j < s; ++j) rho_[(size_t)j * cap + li] = r[j];
+    }
+    return 0;
+  }
+
+  int build_cdf(const double *g, int64_t *len_out, int *any_negative) override {
+    const int s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
+    *any_negative = 0;
+    std::vector<double> col((size_t)N);
+    for (int j = 0; j < s; ++j) {
+      for (int64_t gid = 0; gid < N; ++gid) {
+        const int64_t r = gid / cap, o = gid - r * cap;
+        col[(size_t)gid] = g[(r * s + j) * cap + o];
+        if (col[(size_t)gid] < 0) *any_negative = 1;
+      }
+      const int64_t len = orc_build_cdf(col.data(), N, knots_.data() + (size_t)j * (N + 2));
+      cdf_len_[j] = len > 0 ? len : 0;
+      len_out[j] = cdf_len_[j];
+    }
+    return 0;
+  }
+
+  int cdf_population() override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
+    for (int j = 0; j < s; ++j)
+      for (int64_t li = 0; li < sh_.n_local; ++li)
+        pop_[cur_][(size_t)(d + j) * cap + li] =
+            orc_cdf_apply(knots_.data() + (size_t)j * (N + 2), cdf_len_[j], rho_[(size_t)j * cap + li]);
+    return 0;
+  }
+
+  static const double *partner(const PartnerView &pv, uint64_t j) {
+    int64_t r = (int64_t)(j / (uint64_t)pv.m_full);
+    if (r > pv.world - 1) r = pv.world - 1;
+    const int64_t o = (int64_t)j - r * pv.m_full;
+    const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
+    return pv.base + r * pv.rank_stride + off + o;
+  }
+  static uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+
+  void moments(bool acc, const double *th, const double *u, const double *rho, double *row) const {
+    const int d = m_.d, s = m_.s;
+    row[0] += acc ? 1.0 : 0.0;
+    for (int j = 0; j < s; ++j) { row[1 + j] += u[j]; row[1 + s + j] += rho[j]; }
+    double dk[ORC_MAX_PARA];
+    for (int k = 0; k < d; ++k) { dk[k] = th[k] - cb_.pivot[k]; row[1 + 2 * s + k] += dk[k]; }
+    int q = 1 + 2 * s + d;
+    for (int k = 0; k < d; ++k) for (int l = 0; l <= k; ++l) row[q++] += dk[k] * dk[l];
+  }
+
+  // the per-particle body, SimulatedAnnealingABC.jl:308-331, with the engine's conventions
+  int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
+                   int64_t *rows_out) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
+    double *pop = pop_[cur_].data();
+    const int64_t rows = (cnt + kBlockRows - 1) / kBlockRows;
+    for (int64_t b = 0; b < rows; ++b) {
+      double *row = &partials_[(size_t)(row0 + b) * np_];
+      for (int q = 0; q < np_; ++q) row[q] = 0.0;
+      for (int64_t t = b * kBlockRows; t < cnt && t < (b + 1) * kBlockRows; ++t) {
+        const int64_t li = lo + t;
+        const uint64_t gid = (uint64_t)(sh_.gid0 + li);
+        double th[ORC_MAX_PARA], u[ORC_MAX_STATS], rho[ORC_MAX_STATS], thp[ORC_MAX_PARA], up[ORC_MAX_STATS] = {0}, rp[ORC_MAX_STATS] = {0};
+        for (int k = 0; k < d; ++k) th[k] = pop[(size_t)k * cap + li];
+        for (int j = 0; j < s; ++j) { u[j] = pop[(size_t)(d + j) * cap + li]; rho[j] = rho_[(size_t)j * cap + li]; }
+        double logf = 0.0;
+        if (c.prop_kind == SABC_PROP_RANDOMWALK) {
+          double z[ORC_MAX_PARA + 1];
+          for (int k = 0; k < d; k += 2) orc_normal_pair(m_.seed, gid, ORC_PURPOSE_PROP, c.iter, (uint32_t)(k / 2), &z[k]);
+          for (int k = 0; k < d; ++k) {
+            double a = 0.0;
+            for (int l = 0; l <= k; ++l) a += cb_.chol[k * d + l] * z[l];
+            thp[k] = th[k] + a;
+          }
+        } else if (c.prop_kind == SABC_PROP_DIFFEVO) {
+          uint64_t i1 = 0, i2 = 0;
+          for (uint32_t a = 0;; ++a) {
+            uint32_t w[4];
+            orc_stream_block(m_.seed, gid, ORC_PURPOSE_PROP, c.iter, a, w);
+            i1 = mulhi64(((uint64_t)w[0] << 32) | w[1], (uint64_t)pv.m_total);
+            i2 = mulhi64(((uint64_t)w[2] << 32) | w[3], (uint64_t)pv.m_total);
+            if (i1 != i2 || a > 64u) break;
+          }
+          double z[2];
+          orc_normal_pair(m_.seed, gid, ORC_PURPOSE_PROP2, c.iter, 0, z);
+          const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z[0]);
+          const double *p1 = partner(pv, i1), *p2 = partner(pv, i2);
+          for (int k = 0; k < d; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+        } else {
+          uint32_t w[4];
+          orc_stream_block(m_.seed, gid, ORC_PURPOSE_PROP, c.iter, 0, w);
+          const uint64_t ip = mulhi64(((uint64_t)w[0] << 32) | w[1], (uint64_t)pv.m_total);
+          const double U = orc_u52(w[2], w[3]);
+          const double tt = (c.prop_p0 - 1.0) * U + 1.0, z = tt * tt / c.prop_p0;
+          const double *p = partner(pv, ip);
+          for (int k = 0; k < d; ++k) { const double pk = p[(int64_t)k * pv.cap]; thp[k] = pk + z * (th[k] - pk); }
+          logf = std::log(z) * (double)(d - 1);
+        }
+        const double lpp = orc_prior_logpdf(&oc_, thp);
+        double log_accept = -INFINITY;
+        if (lpp > -INFINITY) {
+          orc_simulate(&oc_, thp, gid, c.iter, rp);
+          double a = 0.0;
+          for (int j = 0; j < s; ++j) {
+            up[j] = orc_cdf_apply(knots_.data() + (size_t)j * (N + 2), cdf_len_[j], rp[j]);
+            a += (u[j] - up[j]) / (cb_.eps_len == 1 ? cb_.eps[0] : cb_.eps[j]);
+          }
+          log_accept = lpp - orc_prior_logpdf(&oc_, th) + a + logf;
+        }
+        uint32_t wa[4];
+        orc_stream_block(m_.seed, gid, ORC_PURPOSE_ACCEPT, c.iter, 0, wa);
+        const bool accepted = std::log(orc_u52(wa[0], wa[1])) < log_accept;
+        if (accepted) {
+          for (int k = 0; k < d; ++k) { th[k] = thp[k]; pop[(size_t)k * cap + li] = thp[k]; }
+          for (int j = 0; j < s; ++j) { u[j] = up[j]; rho[j] = rp[j]; pop[(size_t)(d + j) * cap + li] = up[j]; rho_[(size_t)j * cap + li] = rp[j]; }
+        }
+        moments(accepted, th, u, rho, row);
+      }
+    }
+    *rows_out = rows;
+    return 0;
+  }
+
+  int stats(int64_t *rows_out) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap;
+    const double *pop = pop_[cur_].data();
+    const int64_t rows = (sh_.n_local + kBlockRows - 1) / kBlockRows;
+    for (int64_t b = 0; b < rows; ++b) {
+      double *row = &partials_[(size_t)b * np_];
+      for (int q = 0; q < np_; ++q) row[q] = 0.0;
+      for (int64_t li = b * kBlockRows; li < sh_.n_local && li < (b + 1) * kBlockRows; ++li) {
+        double th[ORC_MAX_PARA], u[ORC_MAX_STATS], rho[ORC_MAX_STATS];
+        for (int k = 0; k < d; ++k) th[k] = pop[(size_t)k * cap + li];
+        for (int j = 0; j < s; ++j) { u[j] = pop[(size_t)(d + j) * cap + li]; rho[j] = rho_[(size_t)j * cap + li]; }
+        moments(false, th, u, rho, row);
+      }
+    }
+    *rows_out = rows;
+    return 0;
+  }
+
+  int reduce_partials(int64_t rows) override {
+    for (int c = 0; c < np_; ++c) {
+      double v = 0.0;
+      for (int64_t r = 0; r < rows; ++r) v += partials_[(size_t)r * np_ + c];
+      cb_.sums[c] = v;
+    }
+    return 0;
+  }
+
+  int control(const ControlArgs &a) override {
+    control_step(cb_, a, hist_.data());
+    if (a.notify_seq) last_seq_ = a.notify_seq;
+    return 0;
+  }
+  int wait_notify(int64_t seq, int64_t *n_accept, int *error) override {
+    if (seq != last_seq_) return -1;
+    *n_accept = cb_.n_accept; *error = cb_.error;
+    return 0;
+  }
+  int read_control(ControlBlock *out) override { *out = cb_; return 0; }
+  int write_control(const ControlBlock &in) override { cb_ = in; return 0; }
+  int history_reserve(int64_t rows) override {
+    if ((int64_t)hist_.size() < rows * 3 * kMaxStats) hist_.resize((size_t)(rows * 3 * kMaxStats));
+    return 0;
+  }
+  int read_history(double *out, int64_t rows, int row_len) override {
+    std::memcpy(out, hist_.data(), (size_t)(rows * row_len) * sizeof(double));
+    return 0;
+  }
+
+  int resample_weights(double delta) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap;
+    double *pop = pop_[cur_].data();
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      double a = 0.0;
+      for (int j = 0; j < s; ++j) a += pop[(size_t)(d + j) * cap + li] * delta / (cb_.sums[1 + j] / (double)sh_.n_global);
+      pop[(size_t)(d + s) * cap + li] = std::exp(-a);
+    }
+    return 0;
+  }
+
+  int resample_draw(const double *g, uint64_t iter) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
+    std::vector<double> cum((size_t)N);
+    double W = 0.0, W2 = 0.0;
+    for (int64_t gid = 0; gid < N; ++gid) {
+      const int64_t r = gid / cap, o = gid - r * cap;
+      const double w = g[(r * rows_ + (rows_ - 1)) * cap + o];
+      W += w; W2 += w * w;
+      cum[(size_t)gid] = W;
+    }
+    ess_ = W2 > 0 ? W * W / W2 : 0.0;
+    std::vector<double> &dst = pop_[1 - cur_];
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      uint32_t w4[4];
+      orc_stream_block(m_.seed, (uint64_t)(sh_.gid0 + li), ORC_PURPOSE_RESAMPLE, iter, 0, w4);
+      const double t = orc_u52(w4[0], w4[1]) * W;
+      int64_t lo = 0, hi = N;
+      while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (cum[(size_t)mid] > t) hi = mid; else lo = mid + 1; }
+      const int64_t idx = lo < N ? lo : N - 1;
+      const int64_t r = idx / cap, o = idx - r * cap;
+      for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = g[(r * rows_ + row) * cap + o];
+    }
+    cur_ = 1 - cur_;
+    return 0;
+  }
+  double last_ess() override { return ess_; }
+
+  int download(double *theta, double *u, double *rho) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, n = sh_.n_local;
+    for (int k = 0; theta && k < d; ++k) std::memcpy(theta + (size_t)k * n, &pop_[cur_][(size_t)k * cap], (size_t)n * sizeof(double));
+    for (int j = 0; u && j < s; ++j) std::memcpy(u + (size_t)j * n, &pop_[cur_][(size_t)(d + j) * cap], (size_t)n * sizeof(double));
+    for (int j = 0; rho && j < s; ++j) std::memcpy(rho + (size_t)j * n, &rho_[(size_t)j * cap], (size_t)n * sizeof(double));
+    return 0;
+  }
+  int upload(const double *theta, const double *u, const double *rho) override {
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, n = sh_.n_local;
+    for (int k = 0; theta && k < d; ++k) std::memcpy(&pop_[cur_][(size_t)k * cap], theta + (size_t)k * n, (size_t)n * sizeof(double));
+    for (int j = 0; u && j < s; ++j) std::memcpy(&pop_[cur_][(size_t)(d + j) * cap], u + (size_t)j * n, (size_t)n * sizeof(double));
+    for (int j = 0; rho && j < s; ++j) std::memcpy(&rho_[(size_t)j * cap], rho + (size_t)j * n, (size_t)n * sizeof(double));
+    return 0;
+  }
+  int get_knots(int stat, double *out, int64_t len) override {
+    std::memcpy(out, knots_.data() + (size_t)stat * (sh_.n_global + 2), (size_t)len * sizeof(double));
+    return 0;
+  }
+  int set_knots(int stat, const double *k, int64_t len) override {
+    std::memcpy(knots_.data() + (size_t)stat * (sh_.n_global + 2), k, (size_t)len * sizeof(double));
+    cdf_len_[stat] = len;
+    return 0;
+  }
+
+ private:
+  ModelDesc m_{};
+  Shard sh_{};
+  orc_config oc_{};
+  int np_ = 0, rows_ = 0, cur_ = 0;
+  std::vector<double> pop_[2], rho_, knots_, partials_, gather_, hist_;
+  int64_t cdf_len_[kMaxStats] = {0};
+  ControlBlock cb_{};
+  int64_t last_seq_ = 0;
+  double ess_ = 0.0;
+};
+
+class NoColl : public Collectives {
+ public:
+  int allreduce_sum(double *, int64_t) override { return 0; }
+  int allgather(const double *, double *, int64_t) override { return -1; }
+};
+
+class HookColl : public Collectives {
+ public:
+  HookColl(sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx) : ar_(ar), ag_(ag), ctx_(ctx) {}
+  int allreduce_sum(double *buf, int64_t count) override { return ar_(ctx_, buf, count, nullptr); }
+  int allgather(const double *send, double *recv, int64_t count) override { return ag_(ctx_, send, recv, count, nullptr); }
+ private:
+  sabc_allreduce_fn ar_; sabc_allgather_fn ag_; void *ctx_;
+};
+
+thread_local std::string g_err;
+
+}  // namespace
+
+struct sabc_handle {
+  Engine *eng = nullptr;
+  RefBackend *be = nullptr;
+  Collectives *coll = nullptr;
+  std::string err;
+};
+
+extern "C" {
+
+int sabc_abi_version(void) { return SABC_ABI_VERSION; }
+const char *sabc_last_global_error(void) { return g_err.c_str(); }
+int sabc_device_count(void) { return 0; }
+
+void sabc_destroy(sabc_handle *h) {
+  if (!h) return;
+  delete h->eng; delete h->coll; delete h->be; delete h;
+}
+
+int sabc_create(const sabc_config *cfg, sabc_handle **out) {
+  *out = nullptr;
+  sabc_handle *h = new sabc_handle();
+  h->be = new RefBackend();
+  h->coll = new NoColl();
+  h->eng = new Engine(*cfg, h->be, h->coll);
+  const int rc = h->eng->validate();
+  if (rc) { g_err = h->eng->error(); sabc_destroy(h); return rc; }
+  h->be->allocate(h->eng->model(), h->eng->shard());
+  *out = h;
+  return 0;
+}
+
+const char *sabc_last_error(const sabc_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, int) {
+  delete h->coll;
+  h->coll = new HookColl(ar, ag, ctx);
+  h->eng->set_collectives(h->coll);
+  return 0;
+}
+
+int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
+  const int rc = h->eng->initialize(n_simulation);
+  if (rc) h->err = h->eng->error();
+  return rc;
+}
+int sabc_update(sabc_handle *h, const sabc_update_args *a) {
+  const int rc = h->eng->update(*a);
+  if (rc) h->err = h->eng->error();
+  return rc;
+}
+int64_t sabc_n_local(const sabc_handle *h) { return h->eng->shard().n_local; }
+int64_t sabc_local_offset(const sabc_handle *h) { return h->eng->shard().gid0; }
+int sabc_get_population(sabc_handle *h, double *t, double *u, double *r) { return h->be->download(t, u, r); }
+int sabc_set_population(sabc_handle *h, const double *t, const double *u, const double *r) {
+  h->be->upload(t, u, r); h->eng->mark_initialized(); return 0;
+}
+int sabc_get_counters(const sabc_handle *h, int64_t out[4]) { h->eng->counters(out); return 0; }
+int sabc_set_counters(sabc_handle *h, const int64_t in[4]) { h->eng->set_counters(in); return 0; }
+int sabc_get_epsilon(const sabc_handle *h, double *eps, int32_t *len) {
+  for (int i = 0; i < h->eng->eps_len(); ++i) eps[i] = h->eng->eps()[i];
+  if (len) *len = h->eng->eps_len();
+  return 0;
+}
+int sabc_set_epsilon(sabc_handle *h, const double *eps, int32_t len) { return h->eng->set_eps(eps, len); }
+int64_t sabc_history_len(const sabc_handle *h) { return h->eng->history_len(); }
+int sabc_get_history(const sabc_handle *h, double *e, double *u, double *r) { h->eng->history(e, u, r); return 0; }
+int sabc_clear_history(sabc_handle *h) { h->eng->clear_history(); return 0; }
+int64_t sabc_cdf_len(const sabc_handle *h, int32_t stat) { return h->eng->cdf_len()[stat]; }
+int sabc_get_cdf_knots(sabc_handle *h, int32_t stat, double *out) { return h->be->get_knots(stat, out, h->eng->cdf_len()[stat]); }
+int sabc_get_proposal_sigma(const sabc_handle *h, double *sigma) {
+  const int d = h->eng->model().d;
+  for (int i = 0; i < d * d; ++i) sigma[i] = h->eng->sigma()[i];
+  return 0;
+}
+double sabc_last_ess(const sabc_handle *h) { return h->be->last_ess(); }
+int64_t sabc_host_syncs(const sabc_handle *h) { return h->eng->host_syncs(); }
+
+}  // extern "C"

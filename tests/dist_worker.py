@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One rank of a sharded SABC run (launched by tests/test_distributed.py, one process per rank).
+
+  python tests/dist_worker.py --engine cpu|hip --backend gloo|nccl --case NAME --alg A --prop P
+                              --n N --updates K --out FILE
+
+engine=cpu : the product's host engine over the oracle-backed Backend (tests/cpu_engine) -- no GPU.
+engine=hip : libsabc_hip.so; with --backend gloo all ranks may share one GPU (host-staged hooks).
+Rank 0 writes the gathered global population, counters, eps and histories to FILE (npz)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--engine", default="cpu")
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--case", default="gauss1_cfg2")
+    ap.add_argument("--alg", default="single_eps")
+    ap.add_argument("--prop", default="rw")
+    ap.add_argument("--n", type=int, default=1001)
+    ap.add_argument("--updates", type=int, default=10)
+    ap.add_argument("--resample", type=float, default=0.0)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sabc_amd as S
+    from sabc_amd.dist import install_collectives
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = 0
+    if a.engine == "hip":
+        ndev = torch.cuda.device_count()
+        device = local % max(ndev, 1)
+        torch.cuda.set_device(device)
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
+
+    if a.engine == "cpu":
+        from tests import cpu_engine
+        Handle = cpu_engine.handle_class()
+    else:
+        Handle = S.SabcHandle
+    model, prior = hip_model_prior(S, a.case)
+    d = len(MODELS[a.case]["prior"])
+    alg = S._lib.ALG_MULTI_EPS if a.alg == "multi_eps" else S._lib.ALG_SINGLE_EPS
+    h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
+    if world > 1:
+        install_collectives(h, device)
+    h.initialize((a.updates + 1) * a.n)
+    h.update(n_simulation=a.updates * a.n, proposal=hip_proposal(S, a.prop, d),
+             resample=a.resample if a.resample > 0 else None)
+    th, u, rho = h.get_population()
+    parts = [None] * world
+    dist.all_gather_object(parts, (h.local_offset, th, u, rho))
+    if rank == 0:
+        parts.sort(key=lambda p: p[0])
+        e, uh, rh = h.history
+        np.savez(a.out, theta=np.concatenate([p[1] for p in parts], 1), u=np.concatenate([p[2] for p in parts], 1),
+                 rho=np.concatenate([p[3] for p in parts], 1), eps=h.eps, eps_hist=e, u_hist=uh, rho_hist=rh,
+                 counters=np.array([h.counters[k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]),
+                 sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]))
+    dist.barrier()
+    h.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

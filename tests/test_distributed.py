@@ -1,0 +1,141 @@
+"""The N > 1 path: one process per shard, torch.distributed collectives.
+
+CPU (gloo, world_size 2 and 3): the product's host engine (engine.cpp, control.hpp: shard geometry,
+partner views, allreduce of the fused sums, allgather-based resample, run-ahead windows) runs over
+the oracle-backed Backend of tests/cpu_engine.  With RandomWalk the sharded run must reproduce the
+single-shard run (RNG is keyed by global particle id); with DE / Stretch the shards are coloured
+locally, so it is compared for determinism and sanity here and against the sharded HIP run on the
+GPU box (same colouring on both sides).
+
+GPU (gloo, both ranks on the one MI355X of the box): libsabc_hip.so sharded over 2 processes ==
+its own single-process run (RandomWalk) and == the CPU-engine run with the same sharding."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(world, out, timeout=600, **kw):
+    """One process per rank on 127.0.0.1 (no torchrun: explicit env, like the driver's launcher)."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        cmd = [sys.executable, WORKER, "--out", out] + [x for k, v in kw.items() for x in (f"--{k}", str(v))]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return np.load(out if out.endswith(".npz") else out + ".npz")
+
+
+def single(S, Handle, case, alg, prop, n, updates, resample=None):
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+    model, prior = hip_model_prior(S, case)
+    d = len(MODELS[case]["prior"])
+    h = Handle(n_particles=n, model=model, prior=prior, seed=SEED,
+               algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
+    h.initialize((updates + 1) * n)
+    h.update(n_simulation=updates * n, proposal=hip_proposal(S, prop, d), resample=resample)
+    out = dict(zip(("theta", "u", "rho"), h.get_population()), eps=h.eps, counters=h.counters, hist=h.history)
+    h.close()
+    return out
+
+
+@pytest.mark.parametrize("world,case,alg,n", [(2, "gauss1_cfg2", "single_eps", 1001), (3, "gauss2_2stats", "multi_eps", 1000),
+                                               (2, "gauss2d_cfg3", "single_eps", 777)])
+def test_cpu_engine_sharded_randomwalk_equals_single_shard(S, tmp_path, world, case, alg, n):
+    from tests import cpu_engine
+    ref = single(S, cpu_engine.handle_class(), case, alg, "rw", n, 10, resample=n // 4)
+    got = launch(world, str(tmp_path / "o.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop="rw", n=n,
+                 updates=10, resample=n // 4)
+    assert list(got["counters"]) == [ref["counters"][k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]
+    assert got["counters"][2] >= 2                       # the allgather-based resample ran
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(got["u"], ref["u"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(got["rho"], ref["rho"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(got["eps"], ref["eps"], rtol=1e-10)
+    np.testing.assert_allclose(got["eps_hist"], ref["hist"][0], rtol=1e-10)
+    cap = -(-n // world)
+    assert list(got["offsets"]) == [r * cap for r in range(world)]
+
+
+@pytest.mark.parametrize("prop", ["de", "stretch"])
+def test_cpu_engine_sharded_partner_proposals(S, O, tmp_path, prop):
+    """Partners are drawn from the inactive halves of ALL shards (exact global semantics); the run is
+    deterministic and anneals like the single-shard one."""
+    n, k = 1000, 12
+    a = launch(2, str(tmp_path / "a.npz"), engine="cpu", backend="gloo", case="gauss1_cfg2", prop=prop, n=n, updates=k)
+    b = launch(2, str(tmp_path / "b.npz"), engine="cpu", backend="gloo", case="gauss1_cfg2", prop=prop, n=n, updates=k)
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    assert list(a["counters"]) == list(b["counters"]) and a["counters"][3] == k
+    from tests import cpu_engine
+    one = single(S, cpu_engine.handle_class(), "gauss1_cfg2", "single_eps", prop, n, k)
+    assert abs(a["counters"][1] / one["counters"]["n_accept"] - 1) < 0.15     # same acceptance regime
+    assert abs(a["theta"].mean() - one["theta"].mean()) < 0.35 and 0.5 < a["eps"][0] / one["eps"][0] < 2.0   # early annealing: the population sd is still ~1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 20001), ("gauss2_2stats", "multi_eps", "de", 10000),
+                                              ("gauss2d_cfg3", "single_eps", "stretch", 10000)])
+def test_hip_two_shards_on_one_gpu(S, gpu, tmp_path, case, alg, prop, n):
+    """libsabc_hip.so with world = 2 (gloo hooks, both ranks on this GPU) against the CPU engine with the
+    same sharding, and for RandomWalk against its own single-process run."""
+    k = 10
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    tol = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}[prop]
+    assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["rho"], ref["rho"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)
+    if prop == "rw":
+        one = single(S, S.SabcHandle, case, alg, prop, n, k, resample=n // 4)
+        assert list(got["counters"]) == [one["counters"][q] for q in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]
+        np.testing.assert_allclose(got["theta"], one["theta"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_nccl_hooks_single_rank(S, gpu):
+    """The torch.distributed "nccl" (= RCCL) hooks take raw device pointers on the library's stream:
+    exercised here on a 1-rank group (this box has one GPU; the multi-rank transport is the driver's run)."""
+    import torch
+    import torch.distributed as dist
+    from sabc_amd.dist import make_hooks
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ar, ag, on_device = make_hooks(0)
+        assert on_device
+        x = torch.arange(8, dtype=torch.float64, device="cuda")
+        y = torch.zeros(8, dtype=torch.float64, device="cuda")
+        s = torch.cuda.Stream()
+        assert ar(None, x.data_ptr(), 8, s.cuda_stream) == 0
+        assert ag(None, x.data_ptr(), y.data_ptr(), 8, s.cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(x, torch.arange(8, dtype=torch.float64, device="cuda")) and torch.equal(x, y)
+    finally:
+        dist.destroy_process_group()
