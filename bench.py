@@ -51,7 +51,13 @@ def cpu_baseline(n, updates, threads):
                       f"{dt:.1f} s; CPU restatement, not the Julia reference"}
 
 
-def load_traffic(workload_n):
+def load_traffic(workload_n, config="cfg2"):
+    if config != "cfg2":
+        return None
+    return _load_traffic(workload_n)
+
+
+def _load_traffic(workload_n):
     """HBM bytes per launch of the update kernel from a committed rocprofv3 --pmc pass, if any."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -72,6 +78,9 @@ def main():
     ap.add_argument("--n-particles", type=int, default=1_000_000)
     ap.add_argument("--particles-per-gpu", type=int, default=0, help="weak scaling: this many particles per rank")
     ap.add_argument("--proposal", default="randomwalk", choices=["randomwalk", "de", "stretch"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 is the headline workload (BASELINE configs[1]); the others are secondary measurements")
+    ap.add_argument("--algorithm", default="single_eps", choices=["single_eps", "multi_eps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=10)
@@ -97,12 +106,28 @@ def main():
     weak = args.particles_per_gpu > 0
     n = args.particles_per_gpu * world if weak else args.n_particles
     K, W = args.steps, args.warmup
-    model = S.GaussianIID(n_obs=100, sd=1.0, obs_mean=observed_mean())
-    prior = S.Normal(0.0, 2.0)
-    proposal = {"randomwalk": S.RandomWalk(n_para=1), "de": S.DifferentialEvolution(n_para=1),
+    if args.config == "cfg2":
+        model, prior = S.GaussianIID(n_obs=100, sd=1.0, obs_mean=observed_mean()), S.Normal(0.0, 2.0)
+        normals_per_sim = 100
+    elif args.config == "cfg3":       # 2-D correlated Gaussian, 3 statistics
+        model = S.Gaussian2D(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)
+        prior = S.product_distribution([S.Normal(0, 3), S.Normal(0, 3)])
+        normals_per_sim = 100
+    elif args.config == "cfg4":       # g-and-k, 4 order statistics; truth (3, 1, 2, 0.5)
+        model = S.GandK(n_draws=128, c=0.8, ranks=(16, 48, 80, 112), obs=(1.9, 2.7, 3.6, 6.4))
+        prior = S.product_distribution([S.Uniform(0, 10)] * 4)
+        normals_per_sim = 128
+    else:                             # stochastic Lotka-Volterra, 256 Euler-Maruyama steps
+        model = S.LotkaVolterra(n_steps=256, dt=0.05, σ=0.1, x0=50.0, y0=50.0, obs=(18.0, 17.0, 14.0, 12.0))
+        prior = S.product_distribution([S.Uniform(0, 2), S.Uniform(0, 0.1), S.Uniform(0, 2)])
+        normals_per_sim = 512
+    d, s = len(prior), model.n_stats
+    proposal = {"randomwalk": S.RandomWalk(n_para=d), "de": S.DifferentialEvolution(n_para=d),
                 "stretch": S.StretchMove()}[args.proposal]
+    alg = S._lib.ALG_MULTI_EPS if args.algorithm == "multi_eps" else S._lib.ALG_SINGLE_EPS
 
-    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, device=local_rank, rank=rank, world=world)
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=local_rank, rank=rank,
+                     world=world)
     if world > 1:
         from sabc_amd.dist import install_collectives
         install_collectives(h, local_rank)
@@ -138,7 +163,6 @@ def main():
     th, _, _ = h.get_population(u=False, rho=False)
 
     if rank == 0:
-        d, s = 1, 1
         bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
         sims_per_launch = h.n_local * (K / max(launches, 1)) if launches else 0
         avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
@@ -146,8 +170,10 @@ def main():
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
         yb = observed_mean()
         post_var = 1.0 / (1.0 / 4.0 + 100.0)
+        analytic = {"analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var} \
+            if args.config == "cfg2" else {}
         out = {
-            "metric": "particle-simulations/sec at n_particles=1e6",
+            "metric": "particle-simulations/sec at n_particles=1e6" if args.config == "cfg2" else f"particle-simulations/sec ({args.config})",
             "value": K * n / dt,
             "unit": "particle-simulations/s",
             "n_gpus": world,
@@ -160,9 +186,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: 1-D Gaussian-mean ABC (Normal(0,2) prior, |mean(x)-mean(y_obs)|, "
-                            f"100 draws per simulation), n_particles={n}, proposal={args.proposal}, single_eps",
-                "n_particles": n, "n_obs": 100, "proposal": args.proposal, "algorithm": "single_eps",
+                "workload": (f"BASELINE configs[1]: 1-D Gaussian-mean ABC (Normal(0,2) prior, |mean(x)-mean(y_obs)|, "
+                             f"100 draws per simulation), n_particles={n}, proposal={args.proposal}, {args.algorithm}")
+                if args.config == "cfg2" else f"{args.config} ({type(model).__name__}, d={d}, s={s}), n_particles={n}, "
+                                              f"proposal={args.proposal}, {args.algorithm}",
+                "n_particles": n, "proposal": args.proposal, "algorithm": args.algorithm,
                 "particles_per_gpu": h.n_local, "seed": SEED,
             },
             "roofline": {
@@ -171,15 +199,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
-                "traffic": load_traffic(n),
-                "kernel": "k_update<GAUSS_IID,1,1,RandomWalk>" if args.proposal == "randomwalk" else "k_update",
+                "traffic": load_traffic(n, args.config),
+                "kernel": f"k_update<{type(model).__name__},{d},{s},{args.proposal}>",
                 "avg_launch_us": avg_launch_s * 1e6 if launches else None,
                 "launches": launches,
                 "algorithmic_bytes_per_sim": bytes_per_sim,
-                "note": "not HBM-bound by construction: 100 f64 normals (50 Philox4x32-10 blocks + 50 Box-Muller "
-                        "log/sqrt/sincospi) per 40 algorithmic bytes; see normals_per_s",
+                "note": f"not HBM-bound by construction: {normals_per_sim} f64 normals ({normals_per_sim // 2} Philox4x32-10 "
+                        f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; see normals_per_s",
             },
-            "normals_per_s": 100.0 * K * n / dt,
+            "normals_per_s": float(normals_per_sim) * K * n / dt,
             "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": res_n,
@@ -187,10 +215,9 @@ def main():
             "init_s": t_init,
             "state": {"n_accept": c["n_accept"], "n_resampling": c["n_resampling"],
                       "n_population_updates": c["n_population_updates"], "eps": h.eps.tolist(),
-                      "shard0_mean": float(th.mean()), "shard0_var": float(th.var()),
-                      "analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var},
+                      "shard0_mean": th.mean(1).tolist(), "shard0_var": th.var(1).tolist(), **analytic},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
             threads = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_updates, threads)
         print(json.dumps(out), flush=True)

@@ -122,32 +122,61 @@ struct Sim<SABC_MODEL_GAUSS2D, D, S> {
 };
 
 // g-and-k: x = A + B (1 + c tanh(g z / 2)) (1 + z^2)^k z; rho_j = |x_(rank_j) - obs_j|.
-// Thread-per-particle stopgap: insertion sort in private memory (the wave-cooperative
-// ranking kernel replaces this; see DESIGN.md "next").
-template <int D, int S>
-struct Sim<SABC_MODEL_GK, D, S> {
-  static constexpr int kMaxDraws = 128;
-  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
-                                             double *rho) {
-    int n_draws = (int)m.p[0];
-    if (n_draws > kMaxDraws) n_draws = kMaxDraws;
-    const double c = m.p[1];
-    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
-    double x[kMaxDraws];
-    for (int k = 0; k < n_draws; ++k) {
-      const double z = ns.next();
-      const double v = th[0] + th[1] * (1.0 + c * tanh(th[2] * z / 2.0)) * pow(1.0 + z * z, th[3]) * z;
-      int j = k;
-      while (j > 0 && x[j - 1] > v) { x[j] = x[j - 1]; --j; }   // NaN stays where it is inserted
-      x[j] = v;
-    }
+// Wave-cooperative: ONE WAVEFRONT PER PARTICLE.  Lane l draws Philox block l of the particle's
+// SIM stream = normals 2l and 2l+1 = draws 2l and 2l+1 (n_draws <= 128 = 64 lanes x 2); the 128
+// values are sorted in registers by a bitonic network across the wave (cross-lane exchanges via
+// __shfl_xor) and the requested order statistics are read out of the owning lanes.  All 64 lanes
+// must call this with the same (th, pid, iter).
+constexpr int kGkMaxDraws = 128;
+constexpr int kGkParticlesPerWave = 16;
+
+// (1 + z^2)^k as exp(k log(1 + z^2)): the argument of the log is >= 1 and normal, so the
+// range-specialised log of device_rng.hpp applies (relative error ~ k log(1+z^2) * 2e-16)
+__device__ __forceinline__ double gk_quantile(const double *th, double c, double z) {
+  const double w = exp(th[3] * log_fast(fma(z, z, 1.0)));
+  return th[0] + th[1] * (1.0 + c * tanh(th[2] * z / 2.0)) * w * z;
+}
+
+template <int S>
+__device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                                 double *rho) {
+  const int lane = threadIdx.x & 63;
+  const int n_draws = (int)m.p[0];
+  const double c = m.p[1];
+  double z0, z1;
+  box_muller(stream_block(m.seed, pid, PURPOSE_SIM, iter, (uint32_t)lane), z0, z1);
+  const int i0 = 2 * lane, i1 = 2 * lane + 1;
+  const double a = i0 < n_draws ? gk_quantile(th, c, z0) : INFINITY;
+  const double b = i1 < n_draws ? gk_quantile(th, c, z1) : INFINITY;
+  // bitonic sorting network over the 128 values, two per lane (element index = 2*lane + slot):
+  // 28 compare-exchange steps, 7 of them inside the lane, 21 with the lane at distance j/2
+  double v0 = a, v1 = b;
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const int rank = (int)m.p[2 + j];
-      rho[j] = finite_or_big(fabs(x[rank - 1] - m.p[2 + S + j]));
+  for (int k = 2; k <= kGkMaxDraws; k <<= 1) {
+    const bool up = ((2 * lane) & k) == 0;              // k = 128: always ascending
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j == 1) {
+        const double lo = fmin(v0, v1), hi = fmax(v0, v1);
+        v0 = up ? lo : hi;
+        v1 = up ? hi : lo;
+      } else {
+        const int dist = j >> 1;
+        const double p0 = __shfl_xor(v0, dist, 64), p1 = __shfl_xor(v1, dist, 64);
+        const bool keep_min = ((lane & dist) == 0) == up;
+        v0 = keep_min ? fmin(v0, p0) : fmax(v0, p0);
+        v1 = keep_min ? fmin(v1, p1) : fmax(v1, p1);
+      }
     }
   }
-};
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
+    const double lo = __shfl(v0, want >> 1, 64), hi = __shfl(v1, want >> 1, 64);
+    rho[j] = finite_or_big(fabs(((want & 1) ? hi : lo) - m.p[2 + S + j]));
+  }
+}
+
 
 // stochastic Lotka-Volterra, Euler-Maruyama; rho = |mean/sd of prey and predator paths - obs|
 template <int D, int S>

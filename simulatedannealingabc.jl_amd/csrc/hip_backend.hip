@@ -92,7 +92,12 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
   knot_stride_ = (int64_t)N + 2;
   HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (N + 2) * sizeof(double)), "hipMalloc(knots)");
-  partial_rows_ = 2 * n_blocks(sh.cap) + 4;
+  {   // k_update writes one row per workgroup; its granularity depends on the model's kernel
+    const int64_t per_half = update_rows(m, (sh.cap + 1) / 2) + 1, whole = update_rows(m, sh.cap);
+    partial_rows_ = 2 * per_half > whole ? 2 * per_half : whole;
+    if (partial_rows_ < n_blocks(sh.cap)) partial_rows_ = n_blocks(sh.cap);
+    partial_rows_ += 4;
+  }
   HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");
   HB_CHECK(hipMalloc((void **)&cb_dev_, sizeof(ControlBlock)), "hipMalloc(control block)");
   HB_CHECK(hipMemsetAsync(cb_dev_, 0, sizeof(ControlBlock), stream_), "hipMemset(control block)");
@@ -207,7 +212,7 @@ int HipBackend::cdf_population() {
 
 int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                              int64_t *rows_out) {
-  const int64_t rows = n_blocks(cnt);
+  const int64_t rows = update_rows(m_, cnt);
   if (lo < 0 || cnt < 0 || lo + cnt > sh_.n_local || row0 + rows > partial_rows_) {
     err_ = "update_range: range outside the shard";
     return -1;

@@ -171,6 +171,220 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
   block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
 }
 
+// ------------------------------------------------------------------------------------------
+// g-and-k (BASELINE config 4): wave-per-particle variants.  A block of 4 waves covers
+// 4 * kGkParticlesPerWave consecutive particles; scalar work (proposal, prior, accept) is done
+// redundantly by all lanes of the wave (same counters -> same values, no broadcast needed), the
+// simulator and the 4 ECDF lookups are spread over the lanes.
+// ------------------------------------------------------------------------------------------
+constexpr int kGkD = 4, kGkS = 4;
+constexpr int kGkPerBlock = (kBlock / 64) * kGkParticlesPerWave;
+
+// per-wave staging of what phase 1 (propose + simulate) hands to phase 2 (ECDF) and 3 (accept)
+struct GkStage {
+  double thp[kGkParticlesPerWave][kGkD];
+  double rp[kGkParticlesPerWave][kGkS];
+  double up[kGkParticlesPerWave][kGkS];
+  double lpp[kGkParticlesPerWave];
+  double logf[kGkParticlesPerWave];
+};
+
+template <int PROP>
+__global__ void __launch_bounds__(kBlock, 2)
+k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
+            const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
+  constexpr int D = kGkD, S = kGkS, NP = n_partials(D, S), PW = kGkParticlesPerWave;
+  static_assert(PW * S == 64, "phase 2 maps one (particle, statistic) pair to each lane");
+  __shared__ GkStage stage[kBlock / 64];
+  __shared__ double red[kBlock / 64][NP];
+  __shared__ double term_lds[kBlock / 64][NP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  GkStage &st = stage[wave];
+  const int64_t t0 = (int64_t)blockIdx.x * kGkPerBlock + wave * PW;
+
+  // ---- phase 1: proposal (:311), prior gate (:314), simulate (:315); scalar work is done by all
+  //      lanes redundantly (same counters, same values), the 128 draws and their sort are spread
+  //      over the lanes
+  for (int it = 0; it < PW; ++it) {
+    const int64_t t = t0 + it;
+    if (t >= act_n) break;                              // uniform over the wave
+    const int64_t li = act_lo + t;
+    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+    double th[D], thp[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+    double logf = 0.0;
+    if (PROP == SABC_PROP_RANDOMWALK) {
+      NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
+      double z[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) z[k] = ns.next();
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
+        thp[k] = th[k] + a;
+      }
+    } else if (PROP == SABC_PROP_DIFFEVO) {
+      uint64_t i1 = 0, i2 = 0;
+      for (uint32_t a = 0;; ++a) {
+        const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
+        i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+        i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
+        if (i1 != i2 || a > 64u) break;
+      }
+      double z0, z1;
+      box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
+      const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);
+      const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
+#pragma unroll
+      for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+    } else {
+      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
+      const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+      const double U = u52(w.z, w.w);
+      const double a = c.prop_p0;
+      const double tt = (a - 1.0) * U + 1.0;
+      const double z = tt * tt / a;
+      const double *p = partner_ptr(pv, ip);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double pk = p[(int64_t)k * pv.cap];
+        thp[k] = pk + z * (th[k] - pk);
+      }
+      logf = log(z) * (double)(D - 1);
+    }
+    const double lpp = prior_logpdf<D>(m, thp);
+    double rp[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) rp[j] = 0.0;
+    if (lpp > -INFINITY) gk_simulate_wave<S>(m, thp, gid, c.iter, rp);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) st.thp[it][k] = thp[k];
+#pragma unroll
+      for (int j = 0; j < S; ++j) st.rp[it][j] = rp[j];
+      st.lpp[it] = lpp;
+      st.logf[it] = logf;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 2: all 16 x 4 ECDF lookups of the wave at once, one per lane (:316); the 20-step
+  //      dependent search is paid once per 16 particles instead of once per particle
+  {
+    const int it = lane >> 2, j = lane & 3;
+    double upv = 0.0;
+    if (t0 + it < act_n && st.lpp[it] > -INFINITY) {
+      int64_t len = cdf.len[0];
+#pragma unroll
+      for (int q = 1; q < S; ++q)
+        if (j == q) len = cdf.len[q];
+      upv = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, len, st.rp[it][j]);
+    }
+    st.up[it][j] = upv;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 3: acceptance (:318-329) and the fused sums; lane q < NP accumulates component q
+  double acc = 0.0;
+  for (int it = 0; it < PW; ++it) {
+    const int64_t t = t0 + it;
+    if (t >= act_n) break;
+    const int64_t li = act_lo + t;
+    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+    double th[D], u[S], rho[S], thp[D], up[S], rp[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { th[k] = pp.pop[(int64_t)k * pp.cap + li]; thp[k] = st.thp[it][k]; }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
+      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
+      up[j] = st.up[it][j];
+      rp[j] = st.rp[it][j];
+    }
+    const double lpp = st.lpp[it];
+    double log_accept = -INFINITY;
+    if (lpp > -INFINITY) {
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
+        a += (u[j] - up[j]) / e;
+      }
+      log_accept = lpp - prior_logpdf<D>(m, th) + a + st.logf[it];
+    }
+    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
+    const bool accepted = log(u52(wa.x, wa.y)) < log_accept;
+    if (accepted) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) th[k] = thp[k];
+#pragma unroll
+      for (int j = 0; j < S; ++j) { u[j] = up[j]; rho[j] = rp[j]; }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) pp.pop[(int64_t)k * pp.cap + li] = thp[k];
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+          pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+        }
+      }
+    }
+    {
+      double term[NP];
+      moment_terms<D, S>(cb->pivot, accepted, th, u, rho, term);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) term_lds[wave][q] = term[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < NP) acc += term_lds[wave][lane];
+    }
+  }
+  if (lane < NP) red[wave][lane] = acc;
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int q = threadIdx.x;
+    partials[(int64_t)blockIdx.x * NP + q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+  }
+}
+
+// one wave per row of theta: used for the prior sample at initialization and for sabc_op_simulate
+__global__ void __launch_bounds__(kBlock)
+k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int64_t n, const int64_t stride,
+              const uint64_t pid0, const uint64_t iter, const int sample_prior, double *__restrict__ theta_out,
+              double *__restrict__ rho_out, const int64_t out_stride) {
+  constexpr int D = kGkD, S = kGkS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < kGkParticlesPerWave; ++it) {
+    const int64_t i = (int64_t)blockIdx.x * kGkPerBlock + wave * kGkParticlesPerWave + it;
+    if (i >= n) break;
+    const uint64_t pid = pid0 + (uint64_t)i;
+    double th[D], rho[S];
+    if (sample_prior) {
+      prior_sample<D>(m, pid, th);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; ++k) th[k] = theta_in[(int64_t)k * stride + i];
+    }
+    gk_simulate_wave<S>(m, th, pid, iter, rho);
+    if (lane == 0) {
+      if (theta_out) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) theta_out[(int64_t)k * out_stride + i] = th[k];
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) rho_out[(int64_t)j * out_stride + i] = rho[j];
+    }
+  }
+}
+
 // moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
 template <int D, int S>
 __global__ void __launch_bounds__(kBlock)
@@ -467,14 +681,20 @@ k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, ui
       case SABC_MODEL_GAUSS_IID * 100 + 21: { CALL(SABC_MODEL_GAUSS_IID, 2, 1); break; }          \
       case SABC_MODEL_GAUSS_IID * 100 + 22: { CALL(SABC_MODEL_GAUSS_IID, 2, 2); break; }          \
       case SABC_MODEL_GAUSS2D * 100 + 23: { CALL(SABC_MODEL_GAUSS2D, 2, 3); break; }              \
-      case SABC_MODEL_GK * 100 + 44: { CALL(SABC_MODEL_GK, 4, 4); break; }                        \
       case SABC_MODEL_LV * 100 + 34: { CALL(SABC_MODEL_LV, 3, 4); break; }                        \
       default: return (int)hipErrorInvalidValue;                                                  \
     }                                                                                             \
   } while (0)
 
+inline unsigned gk_blocks(int64_t n) { return (unsigned)((n + kGkPerBlock - 1) / kGkPerBlock); }
+
 int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
   if (pp.n_local <= 0) return 0;
+  if (m.model_id == SABC_MODEL_GK) {
+    hipLaunchKernelGGL(k_simulate_gk, dim3(gk_blocks(pp.n_local)), dim3(kBlock), 0, stream, m, (const double *)nullptr,
+                       pp.n_local, pp.cap, (uint64_t)pp.gid0, (uint64_t)0, 1, pp.pop, pp.rho, pp.cap);
+    return SABC_LAUNCH_RC();
+  }
   const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
 #define CALL(M, D, S) hipLaunchKernelGGL((k_prior_simulate<M, D, S>), grid, block, 0, stream, m, pp)
   SABC_DISPATCH_MODEL(m, CALL);
@@ -488,11 +708,26 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
   return SABC_LAUNCH_RC();
 }
 
+int64_t update_rows(const ModelDesc &m, int64_t act_n) {
+  if (act_n <= 0) return 0;
+  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_blocks(act_n) : n_blocks(act_n);
+}
+
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
   if (act_n <= 0) return 0;
   const dim3 grid((unsigned)n_blocks(act_n)), block(kBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
+  if (m.model_id == SABC_MODEL_GK) {
+    const dim3 g(gk_blocks(act_n));
+    switch (c.prop_kind) {
+      case SABC_PROP_RANDOMWALK: hipLaunchKernelGGL((k_update_gk<SABC_PROP_RANDOMWALK>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
+      case SABC_PROP_DIFFEVO: hipLaunchKernelGGL((k_update_gk<SABC_PROP_DIFFEVO>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
+      case SABC_PROP_STRETCH: hipLaunchKernelGGL((k_update_gk<SABC_PROP_STRETCH>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+    return SABC_LAUNCH_RC();
+  }
 #define CALLP(M, D, S, P) \
   hipLaunchKernelGGL((k_update<M, D, S, P>), grid, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out)
 #define CALL(M, D, S)                                                           \
@@ -512,6 +747,7 @@ int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double 
   if (pp.n_local <= 0) return 0;
   const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
 #define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, cb, pp, partials)
+  if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
   return SABC_LAUNCH_RC();
@@ -581,6 +817,11 @@ int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, do
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
                           double *rho_out, hipStream_t stream) {
   if (n <= 0) return 0;
+  if (m.model_id == SABC_MODEL_GK) {
+    hipLaunchKernelGGL(k_simulate_gk, dim3(gk_blocks(n)), dim3(kBlock), 0, stream, m, theta, n, n, pid0, iter, 0,
+                       (double *)nullptr, rho_out, n);
+    return SABC_LAUNCH_RC();
+  }
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
 #define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out)
   SABC_DISPATCH_MODEL(m, CALL);

@@ -33,6 +33,8 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 // writes one partial row per block at partials[(row0 + blockIdx) * np]
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream);
+// number of partial rows launch_update() writes for act_n particles (depends on the kernel's granularity)
+int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0
 int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream);
 // sums[c] = sum over rows of partials[row][c] in a fixed order
