@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 is the headline workload (BASELINE configs[1]); the others are secondary measurements")
     ap.add_argument("--algorithm", default="single_eps", choices=["single_eps", "multi_eps"])
+    ap.add_argument("--n-obs", type=int, default=100, help="cfg2 only: draws per simulation (100 is the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=10)
@@ -107,8 +108,8 @@ def main():
     n = args.particles_per_gpu * world if weak else args.n_particles
     K, W = args.steps, args.warmup
     if args.config == "cfg2":
-        model, prior = S.GaussianIID(n_obs=100, sd=1.0, obs_mean=observed_mean()), S.Normal(0.0, 2.0)
-        normals_per_sim = 100
+        model, prior = S.GaussianIID(n_obs=args.n_obs, sd=1.0, obs_mean=observed_mean()), S.Normal(0.0, 2.0)
+        normals_per_sim = args.n_obs
     elif args.config == "cfg3":       # 2-D correlated Gaussian, 3 statistics
         model = S.Gaussian2D(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)
         prior = S.product_distribution([S.Normal(0, 3), S.Normal(0, 3)])
@@ -128,9 +129,10 @@ def main():
 
     h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=local_rank, rank=rank,
                      world=world)
+    transport = "none"
     if world > 1:
         from sabc_amd.dist import install_collectives
-        install_collectives(h, local_rank)
+        transport = install_collectives(h, local_rank)
     t_init0 = time.perf_counter()
     h.initialize(n)
     torch.cuda.synchronize()
@@ -191,7 +193,7 @@ def main():
                 if args.config == "cfg2" else f"{args.config} ({type(model).__name__}, d={d}, s={s}), n_particles={n}, "
                                               f"proposal={args.proposal}, {args.algorithm}",
                 "n_particles": n, "proposal": args.proposal, "algorithm": args.algorithm,
-                "particles_per_gpu": h.n_local, "seed": SEED,
+                "particles_per_gpu": h.n_local, "seed": SEED, "collectives": transport,
             },
             "roofline": {
                 "bound": "hbm",

@@ -122,6 +122,8 @@ SABC_API int         sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, 
                                           int device_buffers);
 SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
 SABC_API int         sabc_comm_unique_id(void *out_128b);
+/* one allreduce + one allgather through the installed collectives, checked on the host */
+SABC_API int         sabc_comm_selftest(sabc_handle *h);
 
 /* ---- the hot path ---- */
 /* initialization(), SimulatedAnnealingABC.jl:151-227.  n_simulation is sabc()'s budget (:155). */

@@ -120,6 +120,7 @@ def bind(L, strict=True):
         "sabc_set_collectives": ([vp, ALLREDUCE_FN, ALLGATHER_FN, vp, C.c_int], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),
         "sabc_comm_unique_id": ([vp], C.c_int),
+        "sabc_comm_selftest": ([vp], C.c_int),
         "sabc_initialize": ([vp, C.c_int64], C.c_int),
         "sabc_update": ([vp, C.POINTER(UpdateArgs)], C.c_int),
         "sabc_n_local": ([vp], C.c_int64),

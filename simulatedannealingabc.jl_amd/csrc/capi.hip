@@ -230,6 +230,34 @@ int sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b) {
   return 0;
 }
 
+// Exercise the installed collectives once (allreduce of rank+1, allgather of rank-tagged words) and
+// check the result on the host: validates the transport before the first population update.
+int sabc_comm_selftest(sabc_handle *h) {
+  if (!h) return SABC_ERR_STATE;
+  const Shard &sh = h->eng->shard();
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  const int world = sh.world;
+  double *g = h->be->gather_buffer((int64_t)(world + 1) * 4);
+  if (!g) return hset(h, SABC_ERR_HIP, "out of memory for the self-test buffer");
+  double send[4] = {(double)(sh.rank + 1), 2.0, 3.0, (double)(100 + sh.rank)};
+  std::vector<double> back((size_t)(world + 1) * 4, 0.0);
+  hipStream_t s = h->be->stream();
+  if (hipMemcpyAsync(g, send, sizeof(send), hipMemcpyHostToDevice, s) != hipSuccess) return hset(h, SABC_ERR_HIP, "memcpy failed");
+  if (world > 1) {
+    if (h->coll->allgather(g, g + 4, 4)) return hset(h, SABC_ERR_COMM, "self-test allgather failed");
+    if (h->coll->allreduce_sum(g, 4)) return hset(h, SABC_ERR_COMM, "self-test allreduce failed");
+  }
+  if (hipMemcpyAsync(back.data(), g, back.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return hset(h, SABC_ERR_HIP, "memcpy failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return hset(h, SABC_ERR_HIP, "stream sync failed");
+  if (world > 1) {
+    if (back[0] != 0.5 * world * (world + 1) || back[1] != 2.0 * world) return hset(h, SABC_ERR_COMM, "self-test allreduce gave a wrong sum");
+    for (int r = 0; r < world; ++r)
+      if (back[4 + 4 * r] != (double)(r + 1) || back[4 + 4 * r + 3] != (double)(100 + r))
+        return hset(h, SABC_ERR_COMM, "self-test allgather gave wrong words");
+  }
+  return 0;
+}
+
 int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
   if (!h) return SABC_ERR_STATE;
   if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");

@@ -70,6 +70,51 @@ def make_hooks(device, group=None):
     return allreduce, allgather, on_device
 
 
-def install_collectives(handle, device, group=None):
+def _all_ok(ok, device, group=None):
+    """True on every rank iff `ok` is true on every rank."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
+def install_collectives(handle, device, group=None, prefer=None):
+    """Give `handle` its allreduce / allgather.
+
+    prefer="rccl": RCCL bound inside the library (ncclAllReduce / ncclAllGather enqueued on the
+    library's stream with no Python in the per-update path); the unique id travels over the
+    existing torch.distributed group.  Used by default when the group's backend is "nccl"; if any
+    rank fails to set it up or the self-test fails, every rank falls back to the hooks.
+    prefer="hooks": torch.distributed collectives through the C-ABI hooks (the only choice for "gloo").
+    Returns the transport in use."""
+    import os
+    import torch.distributed as dist
+    from .handle import rccl_unique_id
+
+    if prefer is None:
+        prefer = os.environ.get("SABC_COLLECTIVES", "rccl" if dist.get_backend(group) == "nccl" else "hooks")
+    if prefer == "rccl":
+        ok = True
+        try:
+            box = [rccl_unique_id() if dist.get_rank(group) == 0 else None]
+        except Exception as e:
+            print(f"[sabc] RCCL unique id failed: {e!r}", flush=True)
+            box, ok = [None], False
+        dist.broadcast_object_list(box, src=0, group=group)
+        ok = ok and box[0] is not None
+        if _all_ok(ok, device, group):
+            try:
+                handle.comm_init_rccl(box[0])
+                handle.comm_selftest()
+            except Exception as e:
+                print(f"[sabc] RCCL setup failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
+                ok = False
+            if _all_ok(ok, device, group):
+                return "rccl"
     ar, ag, on_device = make_hooks(device, group)
     handle.set_collectives(ar, ag, on_device)
+    handle.comm_selftest()
+    return "hooks"

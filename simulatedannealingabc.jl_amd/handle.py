@@ -83,6 +83,13 @@ class SabcHandle:
         self._keep += [ar, ag]
         self._check(self._L.sabc_set_collectives(self._h, ar, ag, None, int(device_buffers)))
 
+    def comm_init_rccl(self, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._L.sabc_comm_init_rccl(self._h, C.cast(buf, C.c_void_p)))
+
+    def comm_selftest(self):
+        self._check(self._L.sabc_comm_selftest(self._h))
+
     # ---- state ----
     @property
     def n_local(self):
@@ -246,3 +253,12 @@ def op_normal_pairs(seed, pid0, m, purpose=1, it=0, k=0, device=0):
     if rc:
         raise SABCError(rc, _lib.global_error())
     return out
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library's own RCCL binding (rank 0 calls it, then broadcasts)."""
+    buf = C.create_string_buffer(128)
+    rc = _lib.lib().sabc_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return buf.raw

@@ -361,6 +361,19 @@ int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn
   return 0;
 }
 
+int sabc_comm_selftest(sabc_handle *h) {
+  const Shard &sh = h->eng->shard();
+  const int world = sh.world;
+  if (world == 1) return 0;
+  double *g = h->be->gather_buffer((int64_t)(world + 1) * 4);
+  g[0] = sh.rank + 1; g[1] = 2.0; g[2] = 3.0; g[3] = 100 + sh.rank;
+  if (h->coll->allgather(g, g + 4, 4) || h->coll->allreduce_sum(g, 4)) { h->err = "self-test collective failed"; return SABC_ERR_COMM; }
+  bool ok = g[0] == 0.5 * world * (world + 1) && g[1] == 2.0 * world;
+  for (int r = 0; r < world; ++r) ok = ok && g[4 + 4 * r] == (double)(r + 1) && g[4 + 4 * r + 3] == (double)(100 + r);
+  if (!ok) { h->err = "self-test collective gave wrong values"; return SABC_ERR_COMM; }
+  return 0;
+}
+
 int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
   const int rc = h->eng->initialize(n_simulation);
   if (rc) h->err = h->eng->error();

@@ -130,6 +130,15 @@ def test_nccl_hooks_single_rank(S, gpu):
     try:
         ar, ag, on_device = make_hooks(0)
         assert on_device
+        # the library's own RCCL binding: unique id, ncclCommInitRank on a 1-rank communicator
+        from tests.cases import hip_model_prior
+        from sabc_amd.handle import rccl_unique_id
+        h = S.SabcHandle(n_particles=256, model=hip_model_prior(S, "gauss1_cfg2")[0], prior=S.Normal(0, 2))
+        uid = rccl_unique_id()
+        assert len(uid) == 128 and any(uid)
+        h.comm_init_rccl(uid)
+        h.comm_selftest()
+        h.close()
         x = torch.arange(8, dtype=torch.float64, device="cuda")
         y = torch.zeros(8, dtype=torch.float64, device="cuda")
         s = torch.cuda.Stream()
