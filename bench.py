@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--algorithm", default="single_eps", choices=["single_eps", "multi_eps"])
     ap.add_argument("--n-obs", type=int, default=100, help="cfg2 only: draws per simulation (100 is the BASELINE workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=10)
     args = ap.parse_args()
@@ -145,9 +146,10 @@ def main():
 
     if W > 0:
         h.update(n_simulation=W * n, proposal=proposal)
-    h.profile_enable(not args.no_kernel_events)
+    h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else 1))
     barrier()
     syncs0 = h.host_syncs
+    resampling0 = h.counters["n_resampling"]
     t0 = time.perf_counter()
     h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
     barrier()
@@ -166,8 +168,11 @@ def main():
 
     if rank == 0:
         bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
-        sims_per_launch = h.n_local * (K / max(launches, 1)) if launches else 0
-        avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
+        # launches that ran: K (RandomWalk: one per update) or 2K; launches beyond that were queued ahead of a
+        # resample decision that fired and returned at once (their ~2 us are in kern_ms but they did no work)
+        real_launches = K if args.proposal == "randomwalk" else 2 * K
+        aborted = max(launches - real_launches, 0)
+        avg_launch_s = (kern_ms / real_launches) * 1e-3 if launches else float("nan")
         sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
         yb = observed_mean()
@@ -204,7 +209,7 @@ def main():
                 "traffic": load_traffic(n, args.config),
                 "kernel": f"k_update<{type(model).__name__},{d},{s},{args.proposal}>",
                 "avg_launch_us": avg_launch_s * 1e6 if launches else None,
-                "launches": launches,
+                "launches": real_launches, "aborted_launches": aborted,
                 "algorithmic_bytes_per_sim": bytes_per_sim,
                 "note": f"not HBM-bound by construction: {normals_per_sim} f64 normals ({normals_per_sim // 2} Philox4x32-10 "
                         f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; see normals_per_s",
@@ -212,7 +217,7 @@ def main():
             "normals_per_s": float(normals_per_sim) * K * n / dt,
             "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
-            "resamples_in_timed_region": res_n,
+            "resamples_in_timed_region": c["n_resampling"] - resampling0,
             "host_syncs_in_timed_region": syncs,
             "init_s": t_init,
             "state": {"n_accept": c["n_accept"], "n_resampling": c["n_resampling"],

@@ -182,8 +182,9 @@ SABC_API int sabc_op_normal_pairs(int32_t device, uint64_t seed, uint64_t pid0, 
 /* ---- measurement ---- */
 enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
        SABC_KERNEL_COUNT = 4 };
-/* HIP-event timing of the named kernel on the library's stream, accumulated since enable */
-SABC_API int sabc_profile_enable(sabc_handle *h, int32_t on);
+/* HIP-event timing of kernels on the library's stream, accumulated since enable.
+   level 0 off, 1 = SABC_KERNEL_UPDATE only (each event is a marker packet the queue drains), 2 = all */
+SABC_API int sabc_profile_enable(sabc_handle *h, int32_t level);
 SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
 /* how many times update()/initialize() had to wait for the device so far (run-ahead windows) */
 SABC_API int64_t sabc_host_syncs(const sabc_handle *h);

@@ -457,7 +457,7 @@ int64_t sabc_host_syncs(const sabc_handle *h) { return h ? h->eng->host_syncs() 
 
 int sabc_profile_enable(sabc_handle *h, int32_t on) {
   if (!h) return SABC_ERR_STATE;
-  h->be->profile_enable(on != 0);
+  h->be->profile_enable(on);
   return 0;
 }
 

@@ -9,12 +9,26 @@
 
 namespace sabc {
 
-SABC_HD inline void control_step(ControlBlock &cb, const ControlArgs &a, double *hist) {
+// returns false when the step was a no-op (guarded and halted): nothing must be posted then
+// `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
+// control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
+SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in) {
+  if ((a.mode & CTRL_GUARDED) && cb.halt) return false;
+  if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
   const int d = a.d, s = a.s;
+  for (int q = 0; q < n_partials(d, s); ++q) cb.sums[q] = sums_in[q];
   const double n = a.n_global;
   const double *S = &cb.sums[1 + 2 * s], *Q = &cb.sums[1 + 2 * s + d];
 
   if (a.mode & CTRL_ACCUMULATE) cb.n_accept += (int64_t)(cb.sums[0] + 0.5);          // :334
+
+  // the resample test of :340, on the device: when it fires, eps / Sigma must come from the RESAMPLED
+  // population, so stop here; everything queued behind this step sees `halt` and does nothing until
+  // the host has run the resample and cleared the flag
+  if ((a.mode & CTRL_CHECK) && (double)cb.n_accept >= a.resample_threshold) {
+    cb.halt = 1;
+    return true;
+  }
 
   if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK) {            // update_proposal!
     double cov[kMaxPara * kMaxPara];
@@ -39,7 +53,7 @@ SABC_HD inline void control_step(ControlBlock &cb, const ControlArgs &a, double 
     } else {
       double tot = 0.0;
       for (int j = 0; j < s; ++j) tot += cb.sums[1 + j];
-      cb.eps[0] = hostmath::eps_single(tot / (n * (double)s), a.v);                  // mean(u), :353
+      cb.eps[0] = hostmath::eps_single(tot / (n * (double)s), a.v, cb.eps[0]);       // mean(u), :353
     }
   }
 
@@ -58,6 +72,7 @@ SABC_HD inline void control_step(ControlBlock &cb, const ControlArgs &a, double 
   // keep the moment sums centred: the sums in hand are relative to the old pivot, so this goes last
   if (a.mode & CTRL_PIVOT)
     for (int k = 0; k < d; ++k) cb.pivot[k] += S[k] / n;
+  return true;
 }
 
 }  // namespace sabc

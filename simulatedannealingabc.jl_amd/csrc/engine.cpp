@@ -93,8 +93,8 @@ void Engine::history(double *e, double *u, double *r) const {
 }
 
 // block partials -> shard sums (ControlBlock::sums) -> allreduce over shards; nothing is read back
-int Engine::global_reduce(int64_t rows) {
-  if (be_->reduce_partials(rows)) return fail(SABC_ERR_HIP, "reduce_partials failed");
+int Engine::global_reduce(int64_t rows, bool guarded) {
+  if (be_->reduce_partials(rows, guarded)) return fail(SABC_ERR_HIP, "reduce_partials failed");
   if (sh_.world > 1 && coll_->allreduce_sum(be_->sums_buffer(), np_))
     return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
   return 0;
@@ -106,7 +106,7 @@ int Engine::stats_reduce() {
   return global_reduce(rows);
 }
 
-int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool notify) {
+int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool notify, double threshold, int64_t *seq_out) {
   ControlArgs c;
   std::memset(&c, 0, sizeof(c));
   c.mode = mode;
@@ -118,13 +118,15 @@ int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool noti
   c.v = v;
   c.hist_capacity = hist_capacity_;
   c.notify_seq = notify ? ++notify_seq_ : 0;
+  c.resample_threshold = threshold;
+  if (seq_out) *seq_out = c.notify_seq;
   if (be_->control(c)) return fail(SABC_ERR_HIP, "control kernel failed");
   return 0;
 }
 
-int Engine::wait_accept(int64_t *known_accept) {
+int Engine::wait_step(int64_t seq, int64_t *n_accept, int *halted) {
   int err = 0;
-  if (be_->wait_notify(notify_seq_, known_accept, &err)) return fail(SABC_ERR_HIP, "waiting for the control step failed");
+  if (be_->wait_notify(seq, n_accept, &err, halted)) return fail(SABC_ERR_HIP, "waiting for the control step failed");
   host_syncs_ += 1;
   if (err) { cb_.error = err; return sync_control(); }
   return 0;
@@ -230,6 +232,7 @@ int Engine::initialize(int64_t n_simulation) {
   if (be_->cdf_population()) return fail(SABC_ERR_HIP, "ECDF transform kernel failed");                   // :190-192
   int rc = stats_reduce();
   if (rc) return rc;
+  if ((rc = control(0, nullptr, cfg_.v))) return rc;                        // takes the sums over (ubar for the weights)
   if ((rc = resample(cfg_.delta, 0))) return rc;                            // :197
   if ((rc = control(CTRL_EPSILON | CTRL_HISTORY | CTRL_PIVOT, nullptr, cfg_.v))) return rc;   // :200-208
   if ((rc = sync_control())) return rc;
@@ -243,7 +246,7 @@ int Engine::initialize(int64_t n_simulation) {
 
 // one population update, enqueued only: the per-particle kernels (:304-331), the fused sums and
 // their allreduce.  Nothing is read back here.
-int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter) {
+int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded) {
   const int d = m_.d;
   StepArgs c;
   std::memset(&c, 0, sizeof(c));
@@ -275,7 +278,7 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter) {
       rows += r;
     }
   }
-  return global_reduce(rows);
+  return global_reduce(rows, guarded);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -315,43 +318,43 @@ int Engine::update(const sabc_update_args &a) {
         return fail(SABC_ERR_BAD_CONFIG, "too few particles in a half batch for this proposal");
   }
 
+  // The loop of :294-375 with the host two updates ahead of the device.  Every update is enqueued as
+  //   k_update (x1 or x2) -> k_reduce_partials -> [allreduce] -> k_control(ACCUMULATE | CHECK | ...)
+  // where the control step evaluates the resample test of :340 ON THE DEVICE.  If it does not fire, the
+  // control step goes on to Sigma / eps / pivot / history and the next update -- already queued -- runs
+  // without the GPU ever waiting for the host.  If it fires, it sets ControlBlock::halt; the kernels of
+  // the update queued behind it see the flag and do nothing; the host learns it from the mailbox,
+  // runs the resample (:341), finishes the control step, clears the flag and re-enqueues.
   const int32_t after_update = CTRL_PROPOSAL | CTRL_EPSILON | CTRL_PIVOT;   // :348-354
-  int64_t known_accept = cb_.n_accept;     // exact as of the last time the host looked
-  int64_t ix = 1;
-  while (ix <= n_pop) {                                                     // :294
-    // The resample test of :340 needs n_accept.  Each update adds at most N accepts, so for the next
-    // W updates the threshold provably cannot be reached and the host need not look: it enqueues
-    // them back to back (eps, Sigma, history are produced on the device) and reads n_accept once.
-    const double threshold = (double)(n_resampling_ + 1) * a.resample;
-    const double slack = threshold - (double)known_accept;
-    int64_t W = n_pop - ix + 1;
-    if (slack < (double)W * (double)N) {
-      W = slack > 0 ? (int64_t)std::ceil(slack / (double)N) - 1 : 0;
-      if (W < 0) W = 0;
+  constexpr int kDepth = 2;
+  int64_t seqs[kDepth + 1] = {0};
+  int64_t next_enqueue = 1, next_confirm = 1;
+  auto hist_flag = [&](int64_t ix) { return (cph > 0 && ix % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };
+  while (next_confirm <= n_pop) {                                           // :294
+    while (next_enqueue <= n_pop && next_enqueue - next_confirm < kDepth) {
+      const int64_t ix = next_enqueue;
+      if ((rc = enqueue_update(a, (uint64_t)(n_population_updates_ + ix), /*guarded=*/true))) return rc;
+      const double threshold = (double)(n_resampling_ + 1) * a.resample;    // :340
+      if ((rc = control(CTRL_GUARDED | CTRL_ACCUMULATE | CTRL_CHECK | after_update | hist_flag(ix), &a, a.v,
+                        /*notify=*/true, threshold, &seqs[ix % (kDepth + 1)])))
+        return rc;
+      ++next_enqueue;
     }
-    if (W >= 1) {
-      for (int64_t w = 0; w < W; ++w, ++ix) {
-        if ((rc = enqueue_update(a, (uint64_t)(n_population_updates_ + ix)))) return rc;
-        int32_t mode = CTRL_ACCUMULATE | after_update;
-        if (cph > 0 && ix % cph == 0) { mode |= CTRL_HISTORY; last_checkpoint = ix; }   // :367-372
-        if ((rc = control(mode, &a, a.v, /*notify=*/w == W - 1 && ix < n_pop))) return rc;
-      }
-      if (ix <= n_pop && (rc = wait_accept(&known_accept))) return rc;
-    } else {
-      // this update may cross the threshold: look at n_accept before deciding (:334,340)
+    const int64_t ix = next_confirm;
+    int64_t n_accept_now = 0;
+    int halted = 0;
+    if ((rc = wait_step(seqs[ix % (kDepth + 1)], &n_accept_now, &halted))) return rc;
+    if (halted) {
+      // n_accept >= (n_resampling + 1) * resample after update ix (:340): resample, then the part of
+      // the control step that was skipped; updates queued behind ix were no-ops and are enqueued again
       const uint64_t iter = (uint64_t)(n_population_updates_ + ix);
-      if ((rc = enqueue_update(a, iter))) return rc;
-      if ((rc = control(CTRL_ACCUMULATE, &a, a.v, /*notify=*/true))) return rc;
-      if ((rc = wait_accept(&known_accept))) return rc;
-      if ((double)known_accept >= threshold) {                              // :340
-        if ((rc = resample(a.delta, iter))) return rc;                      // :341
-        n_resampling_ += 1;                                                 // :342
-      }
-      int32_t mode = after_update;
-      if (cph > 0 && ix % cph == 0) { mode |= CTRL_HISTORY; last_checkpoint = ix; }
-      if ((rc = control(mode, &a, a.v))) return rc;
-      ++ix;
+      if ((rc = resample(a.delta, iter))) return rc;                        // :341
+      n_resampling_ += 1;                                                   // :342
+      if ((rc = control(CTRL_CLEAR_HALT | after_update | hist_flag(ix), &a, a.v))) return rc;
+      next_enqueue = ix + 1;
     }
+    if (cph > 0 && ix % cph == 0) last_checkpoint = ix;                     // :371
+    ++next_confirm;
   }
   if (last_checkpoint != n_pop) {                                           // :378-382
     if ((rc = control(CTRL_HISTORY, &a, a.v))) return rc;

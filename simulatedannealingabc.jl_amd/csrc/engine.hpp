@@ -29,7 +29,7 @@ class Backend {
   // blocks in backend memory; pop_block() may change after resample_draw()
   virtual double *pop_block() = 0;                  // [(d+s+1)][cap]: theta rows, u rows, weight row
   virtual double *rho_block() = 0;                  // [s][cap]
-  virtual double *sums_buffer() = 0;                // ControlBlock::sums in backend memory (allreduce target)
+  virtual double *sums_buffer() = 0;                // staging for the fused sums: reduction and allreduce target
   virtual double *gather_buffer(int64_t doubles) = 0;
   // K1
   virtual int prior_simulate() = 0;
@@ -42,11 +42,12 @@ class Backend {
   virtual int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                            int64_t *rows_out) = 0;
   virtual int stats(int64_t *rows_out) = 0;
-  virtual int reduce_partials(int64_t rows) = 0;    // -> ControlBlock::sums
+  // -> ControlBlock::sums; guarded: part of a queued-ahead step (no-op while ControlBlock::halt is set)
+  virtual int reduce_partials(int64_t rows, bool guarded) = 0;
   // state hand-over between updates (control.hpp), enqueued like a kernel
   virtual int control(const ControlArgs &a) = 0;
   // wait until the control step enqueued with notify_seq == seq has run; cheap (mailbox poll)
-  virtual int wait_notify(int64_t seq, int64_t *n_accept, int *error) = 0;
+  virtual int wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) = 0;
   virtual int read_control(ControlBlock *out) = 0;  // blocks until the stream has drained
   virtual int write_control(const ControlBlock &in) = 0;
   virtual int history_reserve(int64_t rows) = 0;    // capacity of the device-side history buffer
@@ -92,13 +93,15 @@ class Engine {
 
  private:
   int fail(int code, const std::string &msg) { err_ = msg; return code; }
-  int global_reduce(int64_t rows);                  // block partials -> shard sums -> allreduce
+  int global_reduce(int64_t rows, bool guarded = false);   // block partials -> shard sums -> allreduce
   int stats_reduce();                               // sums of the population as it stands
-  int control(int32_t mode, const sabc_update_args *a, double v, bool notify = false);
-  int wait_accept(int64_t *known_accept);           // poll the mailbox of the last notifying control step
+  // enqueue a control step; returns its mailbox sequence number through seq_out when notify is set
+  int control(int32_t mode, const sabc_update_args *a, double v, bool notify = false, double threshold = 0.0,
+              int64_t *seq_out = nullptr);
+  int wait_step(int64_t seq, int64_t *n_accept, int *halted);   // poll the mailbox ring
   int sync_control();                               // device -> cb_, raises device-side errors
   int resample(double delta, uint64_t iter);        // :124-137
-  int enqueue_update(const sabc_update_args &a, uint64_t iter);
+  int enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded);
   int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
 

@@ -26,7 +26,8 @@ HipBackend::~HipBackend() {
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, hist_dev_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
@@ -102,8 +103,10 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&cb_dev_, sizeof(ControlBlock)), "hipMalloc(control block)");
   HB_CHECK(hipMemsetAsync(cb_dev_, 0, sizeof(ControlBlock), stream_), "hipMemset(control block)");
   HB_CHECK(hipHostMalloc((void **)&cb_host_, sizeof(ControlBlock)), "hipHostMalloc(control block)");
-  HB_CHECK(hipHostMalloc((void **)&mbox_host_, sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
-  mbox_host_->seq = 0; mbox_host_->n_accept = 0; mbox_host_->error = 0;
+  HB_CHECK(hipMalloc((void **)&sums_stage_, kMaxPartials * sizeof(double)), "hipMalloc(sums staging)");
+  HB_CHECK(hipMemsetAsync(sums_stage_, 0, kMaxPartials * sizeof(double), stream_), "hipMemset(sums staging)");
+  HB_CHECK(hipHostMalloc((void **)&mbox_host_, kMailboxRing * sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
+  for (int i = 0; i < kMailboxRing; ++i) { mbox_host_[i].seq = 0; mbox_host_[i].n_accept = 0; mbox_host_[i].error = 0; mbox_host_[i].halted = 0; }
   HB_CHECK(hipHostGetDevicePointer((void **)&mbox_dev_, mbox_host_, 0), "hipHostGetDevicePointer(mailbox)");
   const size_t nb = (N + kScanChunk - 1) / kScanChunk;
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
@@ -132,23 +135,33 @@ double *HipBackend::host_stage(int64_t doubles) {
   return stage_.data();
 }
 
-void HipBackend::profile_enable(bool on) {
-  prof_ = on;
-  if (on)
+// level 1: bracket only the dominant kernel (k_update) -- every hipEventRecord is a marker packet the
+// queue has to drain, ~4 us of GPU time each, so the other kernels are bracketed only at level 2
+void HipBackend::profile_enable(int level) {
+  prof_ = level;
+  if (level)
     for (int k = 0; k < SABC_KERNEL_COUNT; ++k) { prof_ms_[k] = 0.0; prof_n_[k] = 0; }
+  while (level && ev_pool_.size() < 256) {       // created outside the timed region
+    EvPair e;
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) break;
+    ev_pool_.push_back(e);
+  }
 }
 
 void HipBackend::prof_begin(int kernel) {
-  if (!prof_) return;
+  if (!prof_ || (prof_ < 2 && kernel != SABC_KERNEL_UPDATE)) return;
   EvPair e;
-  if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+  if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); }
+  else if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
   (void)hipEventRecord(e.a, stream_);
   ev_[kernel].push_back(e);
+  prof_open_ = kernel;
 }
 
 void HipBackend::prof_end(int kernel) {
-  if (!prof_ || ev_[kernel].empty()) return;
+  if (prof_open_ != kernel || ev_[kernel].empty()) return;
   (void)hipEventRecord(ev_[kernel].back().b, stream_);
+  prof_open_ = -1;
 }
 
 int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
@@ -157,8 +170,7 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
   for (auto &e : ev_[kernel]) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { prof_ms_[kernel] += ms; prof_n_[kernel] += 1; }
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
+    ev_pool_.push_back(e);
   }
   ev_[kernel].clear();
   if (total_ms) *total_ms = prof_ms_[kernel];
@@ -230,28 +242,58 @@ int HipBackend::stats(int64_t *rows_out) {
   return 0;
 }
 
-int HipBackend::reduce_partials(int64_t rows) {
+// The reduction is deferred: if the next thing is the control step (one shard: no allreduce in
+// between), both run as one launch (k_reduce_control); anything that needs the staged sums earlier
+// (sums_buffer() for the allreduce) flushes it as its own kernel.
+int HipBackend::reduce_partials(int64_t rows, bool guarded) {
+  if (pending_rows_ >= 0 && flush_reduce()) return -1;
+  pending_rows_ = rows;
+  pending_guarded_ = guarded;
+  return 0;
+}
+
+int HipBackend::flush_reduce() {
+  if (pending_rows_ < 0) return 0;
+  const int64_t rows = pending_rows_;
+  pending_rows_ = -1;
   prof_begin(SABC_KERNEL_REDUCE);
-  HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, cb_dev_->sums, stream_), "k_reduce_partials");
+  HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, sums_stage_, pending_guarded_ ? &cb_dev_->halt : nullptr, stream_),
+            "k_reduce_partials");
   prof_end(SABC_KERNEL_REDUCE);
   return 0;
 }
 
+double *HipBackend::sums_buffer() {
+  (void)flush_reduce();
+  return sums_stage_;
+}
+
 int HipBackend::control(const ControlArgs &a) {
-  HB_LAUNCH(launch_control(cb_dev_, a, hist_dev_, mbox_dev_, stream_), "k_control");
+  if (pending_rows_ >= 0 && np_ <= 64 && pending_rows_ * np_ <= kFuseReduceMaxDoubles) {
+    const int64_t rows = pending_rows_;
+    pending_rows_ = -1;
+    prof_begin(SABC_KERNEL_REDUCE);
+    HB_LAUNCH(launch_reduce_control(partials_, rows, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_),
+              "k_reduce_control");
+    prof_end(SABC_KERNEL_REDUCE);
+    return 0;
+  }
+  if (flush_reduce()) return -1;
+  HB_LAUNCH(launch_control(cb_dev_, a, hist_dev_, mbox_dev_, sums_stage_, stream_), "k_control");
   return 0;
 }
 
 // Poll the mailbox.  A stream that has drained without the sequence word arriving means the
 // control kernel never ran (a fault upstream): report instead of spinning forever.
-int HipBackend::wait_notify(int64_t seq, int64_t *n_accept, int *error) {
+int HipBackend::wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) {
+  Mailbox *mb = mbox_host_ + (seq % kMailboxRing);
   for (uint64_t spins = 1;; ++spins) {
-    if (mbox_host_->seq == seq) break;
+    if (mb->seq == seq) break;
     __builtin_ia32_pause();
     if ((spins & 0x3FFF) == 0) {
       const hipError_t q = hipStreamQuery(stream_);
       if (q == hipSuccess) {
-        if (mbox_host_->seq == seq) break;
+        if (mb->seq == seq) break;
         err_ = "control step did not report back although the stream is idle";
         return -1;
       }
@@ -259,8 +301,9 @@ int HipBackend::wait_notify(int64_t seq, int64_t *n_accept, int *error) {
     }
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  *n_accept = mbox_host_->n_accept;
-  *error = (int)mbox_host_->error;
+  *n_accept = mb->n_accept;
+  *error = (int)mb->error;
+  *halted = (int)mb->halted;
   return 0;
 }
 

@@ -17,7 +17,7 @@ class HipBackend : public Backend {
   int allocate(const ModelDesc &m, const Shard &sh) override;
   double *pop_block() override { return pop_[cur_]; }
   double *rho_block() override { return rho_; }
-  double *sums_buffer() override { return cb_dev_ ? cb_dev_->sums : nullptr; }   // address arithmetic only
+  double *sums_buffer() override;
   double *gather_buffer(int64_t doubles) override;
   int prior_simulate() override;
   int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) override;
@@ -25,9 +25,9 @@ class HipBackend : public Backend {
   int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                    int64_t *rows_out) override;
   int stats(int64_t *rows_out) override;
-  int reduce_partials(int64_t rows) override;
+  int reduce_partials(int64_t rows, bool guarded) override;
   int control(const ControlArgs &a) override;
-  int wait_notify(int64_t seq, int64_t *n_accept, int *error) override;
+  int wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) override;
   int read_control(ControlBlock *out) override;
   int write_control(const ControlBlock &in) override;
   int history_reserve(int64_t rows) override;
@@ -49,7 +49,7 @@ class HipBackend : public Backend {
   void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
   int cdf_apply_host(const double *rho, int64_t m, double *u_out);
   int simulate_host(const double *theta, int64_t n, uint64_t pid0, uint64_t iter, double *rho_out);
-  void profile_enable(bool on);
+  void profile_enable(int level);
   int profile_get(int kernel, double *total_ms, int64_t *launches);
   // host staging for collectives that cannot take device pointers
   double *host_stage(int64_t doubles);
@@ -77,6 +77,10 @@ class HipBackend : public Backend {
   ControlBlock *cb_dev_ = nullptr, *cb_host_ = nullptr;   // device block + pinned staging copy
   Mailbox *mbox_host_ = nullptr, *mbox_dev_ = nullptr;    // pinned + mapped: device posts, host polls
   double *hist_dev_ = nullptr;
+  int flush_reduce();                                     // launch a deferred k_reduce_partials
+  int64_t pending_rows_ = -1;                             // >= 0: a reduction waits to be fused into k_control
+  bool pending_guarded_ = false;
+  double *sums_stage_ = nullptr;                          // reduction / allreduce target, taken over by k_control
   int64_t hist_cap_ = 0;
   double *gather_ = nullptr;
   int64_t gather_cap_ = 0;
@@ -86,9 +90,10 @@ class HipBackend : public Backend {
   size_t sort_tmp_bytes_ = 0;
   int64_t *meta_dev_ = nullptr;
   std::vector<double> stage_;
-  bool prof_ = false;
+  int prof_ = 0, prof_open_ = -1;
   struct EvPair { hipEvent_t a, b; };
   std::vector<EvPair> ev_[SABC_KERNEL_COUNT];
+  std::vector<EvPair> ev_pool_;
   double prof_ms_[SABC_KERNEL_COUNT] = {0};
   int64_t prof_n_[SABC_KERNEL_COUNT] = {0};
 };

@@ -22,10 +22,16 @@ namespace hostmath {
 // With e = x^2 this is g(x) = x^4 + v x^3 - ubar^2, convex and increasing for x > 0 with
 // g(sqrt(ubar)) > 0, so Newton from sqrt(ubar) decreases monotonically onto the root (no sqrt in
 // the loop; a handful of iterations instead of ~70 bisection steps on the single control lane).
-SABC_HD inline double eps_single(double ubar, double v) {
+SABC_HD inline double eps_single(double ubar, double v, double eps_hint = -1.0) {
   if (ubar <= DBL_EPSILON) return 0.0;                      // :93 ubar <= eps()
   const double u2 = ubar * ubar;
   double x = sqrt(ubar);
+  // warm start: the previous eps is usually just right of the new root (eps falls while annealing);
+  // it is a valid monotone start whenever g(sqrt(hint)) >= 0 and it lies inside the bracket
+  if (eps_hint > 0.0 && eps_hint < ubar) {
+    const double xh = sqrt(eps_hint), xh2 = xh * xh;
+    if (xh2 * xh2 + v * xh2 * xh - u2 >= 0.0) x = xh;
+  }
   for (int it = 0; it < 200; ++it) {
     const double x2 = x * x;
     const double g = x2 * x2 + v * x2 * x - u2;

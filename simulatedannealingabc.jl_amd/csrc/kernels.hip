@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(kBlock)
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
+  if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   double acc[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) acc[q] = 0.0;
@@ -195,11 +196,13 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
             const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int D = kGkD, S = kGkS, NP = n_partials(D, S), PW = kGkParticlesPerWave;
   static_assert(PW * S == 64, "phase 2 maps one (particle, statistic) pair to each lane");
+  if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   __shared__ GkStage stage[kBlock / 64];
   __shared__ double red[kBlock / 64][NP];
   __shared__ double term_lds[kBlock / 64][NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GkStage &st = stage[wave];
+  double acc = 0.0;                                     // lane q < NP accumulates component q
   const int64_t t0 = (int64_t)blockIdx.x * kGkPerBlock + wave * PW;
 
   // ---- phase 1: proposal (:311), prior gate (:314), simulate (:315); scalar work is done by all
@@ -290,7 +293,6 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   __builtin_amdgcn_wave_barrier();
 
   // ---- phase 3: acceptance (:318-329) and the fused sums; lane q < NP accumulates component q
-  double acc = 0.0;
   for (int it = 0; it < PW; ++it) {
     const int64_t t = t0 + it;
     if (t >= act_n) break;
@@ -410,8 +412,10 @@ k_stats(const ControlBlock *__restrict__ cb, const PopPtrs pp, double *__restric
 
 // fixed-order sum of the per-block partial rows: block c reduces component c
 __global__ void __launch_bounds__(kBlock)
-k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ sums) {
+k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ sums,
+                  const int *__restrict__ halt) {
   __shared__ double sm[kBlock / 64];
+  if (halt && *halt) return;               // guarded: part of a step queued ahead of a fired resample test
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x;
   double v = 0.0;
@@ -425,15 +429,53 @@ k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const
 }
 
 // the state hand-over between two population updates, one lane (control.hpp)
-__global__ void k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *mbox) {
+__global__ void k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, const double *sums_in) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  control_step(*cb, a, hist);
+  if (!control_step(*cb, a, hist, sums_in)) return;
   if (a.notify_seq != 0) {
+    Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
     mbox->n_accept = cb->n_accept;
     mbox->error = cb->error;
+    mbox->halted = cb->halt;
     __threadfence_system();                 // payload before the sequence word, visible to the host
     mbox->seq = a.notify_seq;
+  }
+}
+
+// k_reduce_partials + k_control in one launch, for the case that no allreduce sits between them
+// (one shard).  1024 threads: thread (g, c) sums rows g, g+G, ... of column c (consecutive threads
+// read consecutive addresses), LDS combines the G row groups in a fixed order, lane 0 runs the
+// control step on the staged sums.
+__global__ void __launch_bounds__(1024)
+k_reduce_control(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ stage,
+                 const int reduce_guarded, ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring) {
+  __shared__ double sm[1024];
+  const bool skip_reduce = reduce_guarded && cb->halt;
+  const int G = 1024 / np;
+  const int g = threadIdx.x / np, c = threadIdx.x - g * np;
+  if (!skip_reduce) {
+    double v = 0.0;
+    if (g < G)
+      for (int64_t r = g; r < rows; r += G) v += partials[r * np + c];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < np) {
+      double t = 0.0;
+      for (int q = 0; q < G; ++q) t += sm[q * np + threadIdx.x];
+      stage[threadIdx.x] = t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  __threadfence();                          // the staged sums written by other lanes of this block
+  if (!control_step(*cb, a, hist, stage)) return;
+  if (a.notify_seq != 0) {
+    Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
+    mbox->n_accept = cb->n_accept;
+    mbox->error = cb->error;
+    mbox->halted = cb->halt;
     __threadfence_system();
+    mbox->seq = a.notify_seq;
   }
 }
 
@@ -508,24 +550,32 @@ k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, con
   }
 }
 
-// pass 2 (single block of 1024): exclusive scan of the chunk sums in place; totals
+// pass 2 (single block of 1024): exclusive scan of the chunk sums in place; totals.  Thread t owns
+// `per` consecutive chunks; the 1024 thread totals are scanned in LDS by a fixed-shape
+// Hillis-Steele network (same result on every run and every shard).
 __global__ void __launch_bounds__(1024)
 k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int64_t nb, double *__restrict__ totals) {
-  __shared__ double sm[2][1024];
+  __shared__ double sa[2][1024];
+  __shared__ double sq[1024];
   const int t = threadIdx.x;
   const int64_t per = (nb + 1023) / 1024;
   const int64_t lo = (int64_t)t * per, hi = (lo + per < nb) ? lo + per : nb;
   double s = 0.0, q = 0.0;
   for (int64_t b = lo; b < hi; ++b) { s += bs[b]; q += bq[b]; }
-  sm[0][t] = s; sm[1][t] = q;
+  sa[0][t] = s; sq[t] = q;
   __syncthreads();
-  if (t == 0) {                       // 1024 sequential adds: fixed order, negligible time
-    double rs = 0.0, rq = 0.0;
-    for (int k = 0; k < 1024; ++k) { const double v = sm[0][k]; sm[0][k] = rs; rs += v; rq += sm[1][k]; }
-    totals[0] = rs; totals[1] = rq;
+  int cur = 0;
+  for (int off = 1; off < 1024; off <<= 1) {          // inclusive scan of the thread totals
+    sa[1 - cur][t] = t >= off ? sa[cur][t] + sa[cur][t - off] : sa[cur][t];
+    cur = 1 - cur;
+    __syncthreads();
   }
-  __syncthreads();
-  double run = sm[0][t];
+  for (int off = 512; off > 0; off >>= 1) {           // tree sum of the squares
+    if (t < off) sq[t] += sq[t + off];
+    __syncthreads();
+  }
+  if (t == 0) { totals[0] = sa[cur][1023]; totals[1] = sq[0]; }
+  double run = t > 0 ? sa[cur][t - 1] : 0.0;          // exclusive offset of this thread's first chunk
   for (int64_t b = lo; b < hi; ++b) { const double v = bs[b]; bs[b] = run; run += v; }
 }
 
@@ -708,18 +758,20 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
   return SABC_LAUNCH_RC();
 }
 
+// workgroups (= partial rows) of one k_update launch over act_n particles
 int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   if (act_n <= 0) return 0;
-  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_blocks(act_n) : n_blocks(act_n);
+  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_blocks(act_n)   // 64 particles per workgroup (wave per particle)
+                                     : n_blocks(act_n);            // 256 particles per workgroup
 }
 
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
   if (act_n <= 0) return 0;
-  const dim3 grid((unsigned)n_blocks(act_n)), block(kBlock);
+  const dim3 grid((unsigned)update_rows(m, act_n)), block(kBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
   if (m.model_id == SABC_MODEL_GK) {
-    const dim3 g(gk_blocks(act_n));
+    const dim3 g((unsigned)update_rows(m, act_n));
     switch (c.prop_kind) {
       case SABC_PROP_RANDOMWALK: hipLaunchKernelGGL((k_update_gk<SABC_PROP_RANDOMWALK>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
       case SABC_PROP_DIFFEVO: hipLaunchKernelGGL((k_update_gk<SABC_PROP_DIFFEVO>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
@@ -753,13 +805,22 @@ int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double 
   return SABC_LAUNCH_RC();
 }
 
-int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)np), dim3(kBlock), 0, stream, partials, rows, np, sums);
+int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, const int *halt,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)np), dim3(kBlock), 0, stream, partials, rows, np, sums, halt);
   return SABC_LAUNCH_RC();
 }
 
-int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream) {
-  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, stream, cb, a, hist, mbox);
+int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
+                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_control, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, reduce_guarded ? 1 : 0, cb,
+                     a, hist, mbox);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, const double *sums_in,
+                   hipStream_t stream) {
+  hipLaunchKernelGGL(k_control, dim3(1), dim3(64), 0, stream, cb, a, hist, mbox, sums_in);
   return SABC_LAUNCH_RC();
 }
 

@@ -22,6 +22,11 @@ struct CdfPtrs {
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
+// (a grid-stride variant of k_update with <= 1024 workgroups cost 20 more VGPRs and 11 % of its speed:
+// one workgroup per 256 particles and dynamic workgroup scheduling stay)
+// partial-row matrices up to this many doubles are summed inside the control kernel (one launch,
+// one CU); larger ones by the np-workgroup reduction first
+constexpr int64_t kFuseReduceMaxDoubles = 8192;
 
 inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 
@@ -38,9 +43,15 @@ int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0
 int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream);
 // sums[c] = sum over rows of partials[row][c] in a fixed order
-int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, hipStream_t stream);
+// halt != nullptr: guarded (no-op while *halt is set)
+int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, const int *halt,
+                           hipStream_t stream);
 // single-lane state hand-over (control.hpp): n_accept, Sigma / Cholesky, eps, pivot, history row
-int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream);
+int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, const double *sums_in,
+                   hipStream_t stream);
+// both of the above in one launch (no collective in between)
+int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
+                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream);
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
 int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
                             hipStream_t stream);

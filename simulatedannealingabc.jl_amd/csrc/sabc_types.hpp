@@ -39,6 +39,8 @@ struct ControlBlock {
   int64_t hist_rows;                     // rows appended to the device history buffer
   int32_t error;                         // 0 or a SABC_ERR_* raised on the device
   int32_t eps_len;
+  int32_t halt;                          // set when the resample test (:340) fires: queued-ahead kernels become no-ops
+  int32_t reserved;
 };
 
 // what the control kernel is asked to do after a reduction
@@ -47,14 +49,18 @@ enum : int32_t {
   CTRL_PROPOSAL = 2,      // Sigma, chol from sums                        (:348, proposals.jl:46-60)
   CTRL_EPSILON = 4,       // eps from sums                                (:350-354)
   CTRL_PIVOT = 8,         // pivot += S / n
-  CTRL_HISTORY = 16       // append (eps, mean u, mean rho)               (:367-372)
+  CTRL_HISTORY = 16,      // append (eps, mean u, mean rho)               (:367-372)
+  CTRL_CHECK = 32,        // n_accept >= threshold ? set halt and stop here  (:340)
+  CTRL_CLEAR_HALT = 64,   // after the host-driven resample
+  CTRL_GUARDED = 128      // no-op while halt is set (a step that was queued ahead of the decision)
 };
 
 struct ControlArgs {
   int32_t mode, d, s, algorithm, prop_kind, reserved;
   double n_global, v, prop_p0;
   int64_t hist_capacity;
-  int64_t notify_seq;                    // != 0: post (n_accept, error, seq) to the host mailbox
+  int64_t notify_seq;                    // != 0: post (n_accept, error, halted, seq) to the host mailbox
+  double resample_threshold;             // (n_resampling + 1) * resample for CTRL_CHECK
 };
 
 // Pinned, host-visible words the control kernel posts to so that the host can learn n_accept
@@ -62,8 +68,10 @@ struct ControlArgs {
 struct Mailbox {
   volatile int64_t seq;
   volatile int64_t n_accept;
-  volatile int64_t error;
+  volatile int32_t error;
+  volatile int32_t halted;
 };
+constexpr int kMailboxRing = 8;          // slot = seq % kMailboxRing; the host lags by at most 2 steps
 
 // Layout of the fused per-update sums ("partials"): one row of `np` doubles.
 //   [0]                n_accept

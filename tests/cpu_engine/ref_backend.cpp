@@ -43,7 +43,7 @@ class RefBackend : public Backend {
   }
   double *pop_block() override { return pop_[cur_].data(); }
   double *rho_block() override { return rho_.data(); }
-  double *sums_buffer() override { return cb_.sums; }
+  double *sums_buffer() override { return stage_; }
   double *gather_buffer(int64_t doubles) override {
     if ((int64_t)gather_.size() < doubles) gather_.resize((size_t)doubles);
     return gather_.data();
@@ -113,6 +113,8 @@ class RefBackend : public Backend {
     const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
     double *pop = pop_[cur_].data();
     const int64_t rows = (cnt + kBlockRows - 1) / kBlockRows;
+    *rows_out = rows;
+    if (cb_.halt) return 0;          // queued ahead of a resample decision that fired
     for (int64_t b = 0; b < rows; ++b) {
       double *row = &partials_[(size_t)(row0 + b) * np_];
       for (int q = 0; q < np_; ++q) row[q] = 0.0;
@@ -198,23 +200,28 @@ class RefBackend : public Backend {
     return 0;
   }
 
-  int reduce_partials(int64_t rows) override {
+  int reduce_partials(int64_t rows, bool guarded) override {
+    if (guarded && cb_.halt) return 0;
     for (int c = 0; c < np_; ++c) {
       double v = 0.0;
       for (int64_t r = 0; r < rows; ++r) v += partials_[(size_t)r * np_ + c];
-      cb_.sums[c] = v;
+      stage_[c] = v;
     }
     return 0;
   }
 
   int control(const ControlArgs &a) override {
-    control_step(cb_, a, hist_.data());
-    if (a.notify_seq) last_seq_ = a.notify_seq;
+    if (!control_step(cb_, a, hist_.data(), stage_)) return 0;
+    if (a.notify_seq) {
+      Mailbox &mb = ring_[a.notify_seq % kMailboxRing];
+      mb.n_accept = cb_.n_accept; mb.error = cb_.error; mb.halted = cb_.halt; mb.seq = a.notify_seq;
+    }
     return 0;
   }
-  int wait_notify(int64_t seq, int64_t *n_accept, int *error) override {
-    if (seq != last_seq_) return -1;
-    *n_accept = cb_.n_accept; *error = cb_.error;
+  int wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) override {
+    const Mailbox &mb = ring_[seq % kMailboxRing];
+    if (mb.seq != seq) return -1;    // the synchronous backend must already have posted it
+    *n_accept = mb.n_accept; *error = mb.error; *halted = mb.halted;
     return 0;
   }
   int read_control(ControlBlock *out) override { *out = cb_; return 0; }
@@ -298,7 +305,8 @@ class RefBackend : public Backend {
   std::vector<double> pop_[2], rho_, knots_, partials_, gather_, hist_;
   int64_t cdf_len_[kMaxStats] = {0};
   ControlBlock cb_{};
-  int64_t last_seq_ = 0;
+  Mailbox ring_[kMailboxRing] = {};
+  double stage_[kMaxPartials] = {0};
   double ess_ = 0.0;
 };
 
