@@ -225,7 +225,8 @@ def main():
                       "shard0_mean": th.mean(1).tolist(), "shard0_var": th.var(1).tolist(), **analytic},
         }
         if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
-            threads = os.cpu_count() or 1
+            # the GPU box shows 256 logical CPUs but a one-GPU job's CPU share is 16: use that many threads
+            threads = min(os.cpu_count() or 1, int(os.environ.get("SABC_CPU_THREADS", "16")))
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_updates, threads)
         print(json.dumps(out), flush=True)
     h.close()

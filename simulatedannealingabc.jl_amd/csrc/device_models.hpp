@@ -3,6 +3,7 @@
 // (cdf_estimators.jl:39-42,68-70) as gfx950 device functions.
 #pragma once
 #include "device_rng.hpp"
+#include "kernels.hpp"
 #include "sabc_types.hpp"
 
 namespace sabc {
@@ -51,6 +52,35 @@ __device__ __forceinline__ double cdf_apply(const double *__restrict__ T, int64_
   while (lo < hi) {
     const int64_t mid = lo + ((hi - lo) >> 1);
     if (T[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  const int64_t i0 = lo > 0 ? lo - 1 : 0;
+  const double L1 = (double)(len - 1);
+  const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
+  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
+  return y0 + slope * (x - T[i0]);
+}
+
+// Same function, two-level search: C is the LDS copy of the coarse index (C[k] = T[k << shift], +inf
+// padded to kCdfCoarse, a power of two), so the first log2(kCdfCoarse) steps are LDS reads and only
+// `shift` steps touch the knot table in global memory.
+__device__ __forceinline__ double cdf_apply_2level(const double *__restrict__ T, int64_t len, int shift,
+                                                   const double *C, double x) {
+  if (!(x >= T[0])) return (x != x) ? x : 0.0;
+  if (x > T[len - 1]) return 1.0;
+  int c = 0;                               // c = #coarse entries < x
+#pragma unroll
+  for (int step = kCdfCoarse >> 1; step >= 1; step >>= 1)
+    if (C[c + step - 1] < x) c += step;
+  if (C[c] < x) c += 1;                    // the last entry (index kCdfCoarse-1) is only reachable here
+  int64_t lo = 0;                          // lo = #knots < x
+  if (c > 0) {
+    lo = ((int64_t)(c - 1) << shift) + 1;
+    int64_t hi = (int64_t)c << shift;
+    if (hi > len) hi = len;
+    while (lo < hi) {
+      const int64_t mid = lo + ((hi - lo) >> 1);
+      if (T[mid] < x) lo = mid + 1; else hi = mid;
+    }
   }
   const int64_t i0 = lo > 0 ? lo - 1 : 0;
   const double L1 = (double)(len - 1);

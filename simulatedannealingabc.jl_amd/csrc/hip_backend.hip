@@ -27,7 +27,7 @@ HipBackend::~HipBackend() {
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
@@ -70,7 +70,8 @@ CdfPtrs HipBackend::cdf_ptrs() const {
   CdfPtrs c;
   c.knots = knots_;
   c.stride = knot_stride_;
-  for (int j = 0; j < kMaxStats; ++j) c.len[j] = cdf_len_[j];
+  c.coarse = coarse_;
+  for (int j = 0; j < kMaxStats; ++j) { c.len[j] = cdf_len_[j]; c.shift[j] = cdf_shift_[j]; }
   return c;
 }
 
@@ -91,6 +92,7 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   }
   HB_CHECK(hipMalloc((void **)&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
   HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
+  HB_CHECK(hipMalloc((void **)&coarse_, (size_t)m.s * kCdfCoarse * sizeof(double)), "hipMalloc(coarse)");
   knot_stride_ = (int64_t)N + 2;
   HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (N + 2) * sizeof(double)), "hipMalloc(knots)");
   {   // k_update writes one row per workgroup; its granularity depends on the model's kernel
@@ -210,6 +212,7 @@ int HipBackend::build_cdf(const double *gathered_rho, int64_t *len_out, int *any
     cdf_len_[j] = mpos > 0 ? mpos + 2 : 0;
     len_out[j] = cdf_len_[j];
     if (meta[2 * j + 1]) *any_negative = 1;
+    if (cdf_len_[j] > 0 && build_coarse(j)) return -1;
   }
   // the sort scratch is only needed once per result
   (void)hipFree(col_a_); (void)hipFree(col_b_); (void)hipFree(sort_tmp_);
@@ -350,7 +353,7 @@ int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
   prof_begin(SABC_KERNEL_RESAMPLE);
   HB_LAUNCH(launch_weight_scan(gathered_pop, rows, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, stream_), "weight scan");
   const int nxt = 1 - cur_;
-  HB_LAUNCH(launch_resample_gather(m_, gathered_pop, rows, sh_.cap, sh_.n_global, cum_, totals_dev_, iter, pop_ptrs(nxt), stream_),
+  HB_LAUNCH(launch_resample_gather(m_, gathered_pop, rows, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_),
             "k_resample_gather");
   prof_end(SABC_KERNEL_RESAMPLE);
   HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
@@ -397,6 +400,16 @@ int HipBackend::set_knots(int stat, const double *knots, int64_t len) {
   HB_CHECK(hipMemcpyAsync(knots_ + (int64_t)stat * knot_stride_, knots, (size_t)len * sizeof(double), hipMemcpyHostToDevice, stream_), "memcpy(knots)");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   cdf_len_[stat] = len;
+  return build_coarse(stat);
+}
+
+// coarse level of the two-level ECDF search: the smallest shift with ceil(len / 2^shift) <= kCdfCoarse
+int HipBackend::build_coarse(int stat) {
+  int shift = 0;
+  while ((((int64_t)cdf_len_[stat] + ((int64_t)1 << shift) - 1) >> shift) > kCdfCoarse) ++shift;
+  cdf_shift_[stat] = shift;
+  HB_LAUNCH(launch_cdf_coarse(knots_ + (int64_t)stat * knot_stride_, cdf_len_[stat], shift, coarse_ + (int64_t)stat * kCdfCoarse, stream_),
+            "k_cdf_coarse");
   return 0;
 }
 

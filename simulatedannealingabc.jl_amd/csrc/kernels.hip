@@ -74,6 +74,9 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
+  __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
+  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
+  __syncthreads();
   double acc[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) acc[q] = 0.0;
@@ -147,7 +150,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
       double a = 0.0;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        up[j] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rp[j]);   // :316
+        up[j] = cdf_apply_2level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j], rp[j]);   // :316
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (u[j] - up[j]) / e;                                             // :319
       }
@@ -609,18 +612,35 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
   }
 }
 
-// n_local categorical draws + gather of theta and u rows (rho is NOT permuted, :131-132)
+// n_local categorical draws + gather of theta and u rows (rho is NOT permuted, :131-132).
+// Inverse CDF by a two-level search: the exclusive chunk offsets `bs` of the weight scan (one per 1024
+// weights) are the coarse level and sit in LDS, the 10 remaining steps search `cum` inside the chunk.
+constexpr int kGatherCoarseMax = 4096;     // chunks held in LDS (n <= 4.2e6); beyond that bs is searched in global memory
 __global__ void __launch_bounds__(kBlock)
 k_resample_gather(const uint64_t seed, const int d, const int s, const double *__restrict__ g, const int rows,
-                  const int64_t cap, const int64_t n, const double *__restrict__ cum,
-                  const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
+                  const int64_t cap, const int64_t n, const double *__restrict__ cum, const double *__restrict__ bs,
+                  const int64_t nb, const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
+  extern __shared__ double bs_lds[];
+  const bool in_lds = nb <= kGatherCoarseMax;
+  if (in_lds) {
+    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    __syncthreads();
+  }
+  const double *B = in_lds ? bs_lds : bs;
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= dst.n_local) return;
   const uint64_t gid = (uint64_t)(dst.gid0 + li);
   const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
   const double t = u52(w.x, w.y) * totals[0];
-  int64_t lo = 0, hi = n;             // first k with cum[k] > t
-  while (lo < hi) {
+  int64_t blo = 0, bhi = nb;              // first chunk whose offset exceeds t; bs[0] = 0 <= t
+  while (blo < bhi) {
+    const int64_t mid = blo + ((bhi - blo) >> 1);
+    if (B[mid] > t) bhi = mid; else blo = mid + 1;
+  }
+  const int64_t chunk = blo - 1;
+  int64_t lo = chunk * kScanChunk, hi = lo + kScanChunk;
+  if (hi > n) hi = n;
+  while (lo < hi) {                       // first k in the chunk with cum[k] > t
     const int64_t mid = lo + ((hi - lo) >> 1);
     if (cum[mid] > t) hi = mid; else lo = mid + 1;
   }
@@ -654,6 +674,14 @@ k_cdf_fill(const double *__restrict__ sorted, const int64_t n, const int64_t *__
     knots[0] = 0.0;
     if (mpos > 0) knots[mpos + 1] = sorted[n - 1] * 1.5;
   }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_cdf_coarse(const double *__restrict__ knots, const int64_t len, const int shift, double *__restrict__ coarse) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= kCdfCoarse) return;
+  const int64_t p = (int64_t)k << shift;
+  coarse[k] = p < len ? knots[p] : INFINITY;
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -843,16 +871,24 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
 }
 
 int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
-                           const double *cum, const double *totals, uint64_t iter, PopPtrs dst, hipStream_t stream) {
+                           const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
+                           hipStream_t stream) {
   if (dst.n_local <= 0) return 0;
-  hipLaunchKernelGGL(k_resample_gather, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), 0, stream, m.seed, m.d,
-                     m.s, gathered, rows, cap, n_global, cum, totals, iter, dst);
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
+  hipLaunchKernelGGL(k_resample_gather, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
+                     m.s, gathered, rows, cap, n_global, cum, block_sums, nb, totals, iter, dst);
   return SABC_LAUNCH_RC();
 }
 
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream) {
   hipLaunchKernelGGL(k_cdf_meta, dim3(1), dim3(64), 0, stream, sorted, n, meta);
   hipLaunchKernelGGL(k_cdf_fill, dim3((unsigned)n_blocks(n > 0 ? n : 1)), dim3(kBlock), 0, stream, sorted, n, meta, knots);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_cdf_coarse(const double *knots, int64_t len, int shift, double *coarse, hipStream_t stream) {
+  hipLaunchKernelGGL(k_cdf_coarse, dim3((kCdfCoarse + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, knots, len, shift, coarse);
   return SABC_LAUNCH_RC();
 }
 

@@ -14,10 +14,16 @@ struct PopPtrs {
   int64_t cap, n_local, gid0;
 };
 
+// coarse level of the two-level ECDF search: every 2^shift-th knot, kCdfCoarse entries per statistic
+// (padded with +inf), small enough to sit in LDS for the lifetime of a workgroup
+constexpr int kCdfCoarse = 1024;
+
 struct CdfPtrs {
   const double *knots;   // [s][stride]
   int64_t stride;
   int64_t len[kMaxStats];
+  const double *coarse;  // [s][kCdfCoarse]
+  int32_t shift[kMaxStats];
 };
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64
@@ -61,10 +67,13 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
                        double *cum, double *totals, hipStream_t stream);
 // K5c: n_local categorical draws by inverse CDF + gather of theta and u (not rho)   :129-132
 int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
-                           const double *cum, const double *totals, uint64_t iter, PopPtrs dst, hipStream_t stream);
+                           const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
+                           hipStream_t stream);
 // K2: knots = [0; sorted positives; 1.5 max] from an ascending-sorted column         cdf_estimators.jl:29-33
 // meta[0] = number of non-positive entries, meta[1] = 1 if any entry is negative
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream);
+// coarse[k] = knots[k << shift] for k << shift < len, +inf beyond
+int launch_cdf_coarse(const double *knots, int64_t len, int shift, double *coarse, hipStream_t stream);
 // compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
 int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
                           hipStream_t stream);
