@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
-    ap.add_argument("--cpu-updates", type=int, default=10)
+    ap.add_argument("--cpu-updates", type=int, default=100, help="population updates of the CPU baseline sample (~15 s on 16 cores)")
     args = ap.parse_args()
 
     import torch
