@@ -6,7 +6,8 @@ Public surface = the reference's exports (`sabc`, `update_population!` -> `updat
 (hand-written gfx950 HIP kernels behind the C-ABI of include/sabc_hip.h); there is no CPU path.
 """
 from ._lib import SABCError, build, lib  # noqa: F401
-from .api import SABCresult, SABCstate, initialization, is_logging, sabc, update_population_  # noqa: F401
+from .api import (SABCresult, SABCstate, initialization, is_logging, load_result, sabc, save_result,  # noqa: F401
+                  update_population_)
 from .distributions import Normal, Product, Uniform, product_distribution  # noqa: F401
 from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
                      op_normal_pairs, op_philox)
@@ -14,7 +15,7 @@ from .models import DeviceDistance, GandK, Gaussian2D, GaussianIID, LotkaVolterr
 from .proposals import DifferentialEvolution, Proposal, RandomWalk, StretchMove  # noqa: F401
 
 __all__ = [
-    "sabc", "update_population_", "initialization", "SABCresult", "SABCstate", "SABCError",
+    "sabc", "update_population_", "initialization", "save_result", "load_result", "SABCresult", "SABCstate", "SABCError",
     "RandomWalk", "DifferentialEvolution", "StretchMove", "Proposal",
     "Normal", "Uniform", "Product", "product_distribution",
     "DeviceDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",

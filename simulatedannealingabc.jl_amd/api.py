@@ -115,9 +115,10 @@ def _refresh(res: SABCresult, first=False):
     st.n_simulation, st.n_accept = c["n_simulation"], c["n_accept"]
     st.n_resampling, st.n_population_updates = c["n_resampling"], c["n_population_updates"]
     e, uh, rh = h.history
-    st.ϵ_history = [row.copy() for row in e]
-    st.u_history = [row.copy() for row in uh]
-    st.ρ_history = [row.copy() for row in rh]
+    pre = getattr(res, "_history_prefix", ([], [], []))
+    st.ϵ_history = list(pre[0]) + [row.copy() for row in e]
+    st.u_history = list(pre[1]) + [row.copy() for row in uh]
+    st.ρ_history = list(pre[2]) + [row.copy() for row in rh]
 
 
 def _dist_env(distributed):
@@ -236,6 +237,45 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         proposal.Σ = float(sg[0, 0]) if len(prior) == 1 else sg                       # rw.Σ, proposals.jl:47,59
     _refresh(res)
     log.info("All particles have been updated %d times.", n_pop)                      # :399
+    return res
+
+
+def save_result(path, res: SABCresult):
+    """Serialise a result, ECDF knots included, so that `update_population_` can resume from it in
+    another process (the reference only resumes in memory, SimulatedAnnealingABC.jl:264-271)."""
+    st, h = res.state, res._handle
+    knots = [st.cdfs_dist_prior.knots(j) for j in range(h.s)]
+    np.savez_compressed(
+        path, population=res.population, u=res.u, rho=res.ρ, eps=np.asarray(st.ϵ), algorithm=st.algorithm,
+        eps_history=np.array(st.ϵ_history), u_history=np.array(st.u_history), rho_history=np.array(st.ρ_history),
+        counters=np.array([st.n_simulation, st.n_accept, st.n_resampling, st.n_population_updates], dtype=np.int64),
+        seed=np.uint64(res.seed), n_particles=np.int64(h.cfg.n_particles), knot_len=np.array([len(k) for k in knots]),
+        **{f"knots_{j}": k for j, k in enumerate(knots)})
+
+
+def load_result(path, f_dist, prior, device=0) -> SABCresult:
+    """Rebuild a device-resident SABCresult from `save_result` output (single shard)."""
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+    alg = str(z["algorithm"])
+    n = int(z["n_particles"])
+    h = SabcHandle(n_particles=n, model=f_dist, prior=prior, algorithm=_ALGORITHMS[alg], seed=int(z["seed"]), device=device)
+    pop = z["population"]
+    th = pop.reshape(1, -1) if prior.univariate else np.ascontiguousarray(pop.T)
+    for j in range(h.s):
+        h.set_cdf_knots(j, z[f"knots_{j}"])
+    h.set_population(th, np.ascontiguousarray(z["u"].T), np.ascontiguousarray(z["rho"].T))
+    h.set_eps(z["eps"])
+    h.set_counters(*[int(c) for c in z["counters"]])
+    state = SABCstate()
+    state.algorithm = alg
+    state.cdfs_dist_prior = CdfTransform(h)
+    res = SABCresult(None, None, None, state, h, f_dist, prior, int(z["seed"]))
+    _refresh(res, first=True)
+    # the handle starts with an empty history: keep the stored one in front of what later updates append
+    res._history_prefix = ([r.copy() for r in z["eps_history"]], [r.copy() for r in z["u_history"]],
+                           [r.copy() for r in z["rho_history"]])
+    st = res.state
+    st.ϵ_history, st.u_history, st.ρ_history = (list(x) for x in res._history_prefix)
     return res
 
 

@@ -185,3 +185,54 @@ def test_negative_distance_and_device_errors(S, gpu):
     with pytest.raises(S.SABCError) as e:
         S.sabc(S.GaussianIID(), S.Uniform(-1, 1), n_particles=100, n_simulation=1000, device=99)
     assert e.value.code == -20
+
+
+def test_save_load_resume(S, O, gpu, tmp_path):
+    """a stored result (ECDF knots included) resumes in a fresh handle exactly where the
+    original would have continued (the RNG streams are keyed by the global update index)."""
+    n, name, d = 777, "gauss2_2stats", 2
+    model, prior = hip_model_prior(S, name)
+    p = S.RandomWalk(n_para=d)
+    a = S.sabc(model, prior, n_particles=n, n_simulation=7 * n, algorithm="multi_eps", proposal=p, seed=SEED)
+    S.save_result(str(tmp_path / "res"), a)
+    b = S.load_result(str(tmp_path / "res"), model, prior)
+    assert b.state.n_population_updates == 6 and len(b.state.ϵ_history) == 7
+    np.testing.assert_array_equal(b.population, a.population)
+    for r in (a, b):
+        S.update_population_(r, model, prior, n_simulation=6 * n, proposal=S.RandomWalk(n_para=d))
+    assert (a.state.n_accept, a.state.n_resampling, a.state.n_population_updates) == \
+        (b.state.n_accept, b.state.n_resampling, b.state.n_population_updates)
+    np.testing.assert_allclose(b.population, a.population, rtol=1e-12)
+    np.testing.assert_allclose(b.state.ϵ, a.state.ϵ, rtol=1e-12)
+    assert len(b.state.ϵ_history) == len(a.state.ϵ_history) == 13
+    run = oracle_run(O, name, n, 7 * n, algorithm="multi_eps", prop="rw")
+    run.update(O.make_update_args(n_simulation=6 * n, n_para=d, n_particles=n, proposal=oracle_proposal(O, "rw", d)))
+    compare(b, run, d, "rw")
+
+
+def test_show_checkpoint_chunking_keeps_the_history(S, gpu, caplog):
+    """`show_checkpoint` (SimulatedAnnealingABC.jl:359-364) only splits the call into chunks; counters,
+    histories and particles are those of the unsplit call."""
+    import logging
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    kw = dict(n_particles=500, n_simulation=500 * 13, proposal=S.RandomWalk(n_para=1), seed=SEED, checkpoint_history=2)
+    a = S.sabc(model, prior, **kw)
+    with caplog.at_level(logging.INFO, logger="SimulatedAnnealingABC"):
+        b = S.sabc(model, prior, show_checkpoint=4, **kw)
+    assert any("Update 4 of 12" in r.message for r in caplog.records)
+    assert len(a.state.ϵ_history) == len(b.state.ϵ_history) == 1 + 6
+    np.testing.assert_allclose(b.population, a.population, rtol=1e-12)
+    assert a.state.n_accept == b.state.n_accept
+
+
+def test_effective_sample_size(S, O, gpu):
+    """ess = (sum w)^2 / sum w^2 of the last resample (:134), returned by the reference and unused by its callers."""
+    n = 2000
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+    h.initialize(n)
+    from tests.cases import oracle_config
+    run = O.OracleRun(oracle_config(O, "gauss1_cfg2", n))
+    run.initialize(n)
+    assert 0 < h.ess <= n and h.ess == pytest.approx(run.ess, rel=1e-9)
+    h.close()
