@@ -39,7 +39,8 @@ extern "C" {
 
 /* device-coded simulators: the `f_dist` argument of sabc() (SimulatedAnnealingABC.jl:451)
    as data; definitions in DESIGN.md "Simulators" */
-enum { SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4 };
+enum { SABC_MODEL_HOST = 0,   /* f_dist stays a host callable (sabc_set_host_simulator): any d, s within the maxima */
+       SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4 };
 /* `prior` argument as data: product of univariate Normal / Uniform */
 enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1 };
 /* `proposal` argument (proposals.jl:24 RandomWalk, :85 DifferentialEvolution, :132 StretchMove) */
@@ -63,7 +64,8 @@ enum {
   SABC_ERR_NO_DEVICE = -20,
   SABC_ERR_HIP = -21,
   SABC_ERR_COMM = -22,
-  SABC_ERR_STATE = -23
+  SABC_ERR_STATE = -23,
+  SABC_ERR_CALLBACK = -24        /* the host simulator returned non-zero */
 };
 
 typedef struct sabc_handle sabc_handle;
@@ -109,6 +111,13 @@ typedef struct {
 typedef int (*sabc_allreduce_fn)(void *ctx, void *buf, int64_t count_f64, void *stream);
 typedef int (*sabc_allgather_fn)(void *ctx, const void *send, void *recv, int64_t count_f64_per_rank, void *stream);
 
+/* The user's f_dist (SimulatedAnnealingABC.jl:164,175,315) as a host callback, for models that are not
+   device-coded: called with the m proposals that passed the prior gate (theta column-major m x d,
+   ids = their global particle ids, iter = population-update index, 0 during initialization); writes rho
+   column-major m x s (non-negative).  Everything else of the update stays on the device. */
+typedef int (*sabc_simulate_fn)(void *ctx, const double *theta, const int64_t *ids, int64_t m, uint64_t iter,
+                                double *rho_out);
+
 SABC_API int         sabc_abi_version(void);
 SABC_API const char *sabc_last_global_error(void);          /* for failures with no handle */
 SABC_API int         sabc_device_count(void);
@@ -120,6 +129,7 @@ SABC_API const char *sabc_last_error(const sabc_handle *h);
 SABC_API int         sabc_set_stream(sabc_handle *h, void *hip_stream);
 SABC_API int         sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx,
                                           int device_buffers);
+SABC_API int         sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx);   /* SABC_MODEL_HOST */
 SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
 SABC_API int         sabc_comm_unique_id(void *out_128b);
 /* one allreduce + one allgather through the installed collectives, checked on the host */

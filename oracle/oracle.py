@@ -17,7 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsabc_oracle.so")
 
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
-MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 1, 2, 3, 4
+MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
+SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
+                          C.POINTER(C.c_double))
 PRIOR_NORMAL, PRIOR_UNIFORM = 0, 1
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
@@ -51,6 +53,8 @@ class Config(C.Structure):
         ("v", C.c_double),
         ("delta", C.c_double),
         ("seed", C.c_uint64),
+        ("host_fn", SIMULATE_FN),
+        ("host_ctx", C.c_void_p),
     ]
 
 
@@ -137,8 +141,23 @@ def _dp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def host_simulator(fn, d, s):
+    """Wrap fn(theta[d], particle_id, iter) -> rho[s] as the oracle's ORC_MODEL_HOST callback."""
+    def cb(ctx, theta, ids, m, it, rho_out):
+        try:
+            for i in range(m):
+                r = np.atleast_1d(np.asarray(fn(np.array([theta[k * m + i] for k in range(d)]), int(ids[i]), int(it)), dtype=float))
+                for j in range(s):
+                    rho_out[j * m + i] = r[j]
+            return 0
+        except Exception as e:   # never raise through the C frame
+            print(f"[oracle] host simulator failed: {e!r}", flush=True)
+            return -1
+    return SIMULATE_FN(cb)
+
+
 def make_config(*, n_particles, n_para, n_stats, model_id, model_params, prior, algorithm=ALG_SINGLE_EPS,
-                v=1.0, delta=0.1, seed=20241220) -> Config:
+                v=1.0, delta=0.1, seed=20241220, host_fn=None) -> Config:
     """prior: list of (kind, a, b) per dimension."""
     cfg = Config()
     cfg.n_particles, cfg.n_para, cfg.n_stats = int(n_particles), int(n_para), int(n_stats)
@@ -149,6 +168,8 @@ def make_config(*, n_particles, n_para, n_stats, model_id, model_params, prior, 
     for k, (kind, a, b) in enumerate(prior):
         cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
     cfg.algorithm, cfg.v, cfg.delta, cfg.seed = int(algorithm), float(v), float(delta), int(seed)
+    if host_fn is not None:
+        cfg.host_fn = host_fn      # keep a reference to the CFUNCTYPE object alive in the caller
     return cfg
 
 

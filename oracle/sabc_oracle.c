@@ -166,6 +166,12 @@ int orc_simulate(const orc_config *cfg, const double *th, uint64_t pid, uint64_t
   const int s = cfg->n_stats, d = cfg->n_para;
   nstream ns = ns_open(cfg->seed, pid, ORC_PURPOSE_SIM, iter);
   switch (cfg->model_id) {
+  case ORC_MODEL_HOST: {
+    /* the user's f_dist itself (SimulatedAnnealingABC.jl:175,315) */
+    int64_t id = (int64_t)pid;
+    if (!cfg->host_fn) return -1;
+    return cfg->host_fn(cfg->host_ctx, th, &id, 1, iter, rho);
+  }
   case ORC_MODEL_GAUSS_IID: {
     /* test/runtests.jl:35,86,128-131,167-170: y ~ Normal(theta1, sd)^n_obs;
        rho1 = |obs_mean - mean(y)|, rho2 = |obs_m2 - mean(y.^2)| */

@@ -33,7 +33,7 @@ extern "C" {
 #define ORC_MAX_MODEL_PARAMS 32
 
 /* model ids (device-coded simulators; see DESIGN.md "Simulators") */
-enum { ORC_MODEL_GAUSS_IID = 1, ORC_MODEL_GAUSS2D = 2, ORC_MODEL_GK = 3, ORC_MODEL_LV = 4 };
+enum { ORC_MODEL_HOST = 0, ORC_MODEL_GAUSS_IID = 1, ORC_MODEL_GAUSS2D = 2, ORC_MODEL_GK = 3, ORC_MODEL_LV = 4 };
 /* prior kinds (per dimension; product distribution) */
 enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1 };
 /* proposal kinds (proposals.jl:24,85,132) */
@@ -75,6 +75,9 @@ typedef struct {
   double  v;                      /* used by initialization for eps_0 */
   double  delta;                  /* used by initialization's resample */
   uint64_t seed;
+  /* ORC_MODEL_HOST: f_dist as a host callback, one particle per call (m = 1) */
+  int (*host_fn)(void *ctx, const double *theta, const int64_t *ids, int64_t m, uint64_t iter, double *rho_out);
+  void *host_ctx;
 } orc_config;
 
 typedef struct {

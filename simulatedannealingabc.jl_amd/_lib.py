@@ -17,7 +17,7 @@ HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
 ABI_VERSION = 1
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
-MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 1, 2, 3, 4
+MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
 PRIOR_NORMAL, PRIOR_UNIFORM = 0, 1
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
@@ -26,7 +26,7 @@ KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT = 0, 1, 2, 3
 ERR_NAMES = {
     -1: "NSIM_TOO_SMALL", -2: "NEG_DISTANCE", -3: "BAD_V", -4: "BAD_DELTA", -5: "BAD_ALGORITHM", -6: "BAD_BETA",
     -7: "ZERO_MEAN_U", -8: "BAD_CONFIG", -9: "NOT_POSDEF", -10: "EMPTY_CDF", -11: "ROOT", -20: "NO_DEVICE",
-    -21: "HIP", -22: "COMM", -23: "STATE",
+    -21: "HIP", -22: "COMM", -23: "STATE", -24: "CALLBACK",
 }
 
 
@@ -59,6 +59,8 @@ class UpdateArgs(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
+                          C.POINTER(C.c_double))
 
 
 def sources_newer_than_lib() -> bool:
@@ -118,6 +120,7 @@ def bind(L, strict=True):
         "sabc_last_error": ([vp], C.c_char_p),
         "sabc_set_stream": ([vp, vp], C.c_int),
         "sabc_set_collectives": ([vp, ALLREDUCE_FN, ALLGATHER_FN, vp, C.c_int], C.c_int),
+        "sabc_set_host_simulator": ([vp, SIMULATE_FN, vp], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),
         "sabc_comm_unique_id": ([vp], C.c_int),
         "sabc_comm_selftest": ([vp], C.c_int),

@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import SABCError
 from .distributions import Distribution
 from .handle import SabcHandle
-from .models import DeviceDistance
+from .models import DeviceDistance, HostDistance
 from .proposals import DifferentialEvolution, Proposal, RandomWalk
 
 log = logging.getLogger("SimulatedAnnealingABC")
@@ -136,6 +136,24 @@ def _dist_env(distributed):
     return 0, 1, None
 
 
+_HOST_WRAPPERS = {}
+
+
+def as_host_distance(f_dist, prior, args=(), kwargs=None):
+    """Wrap a plain callable as a HostDistance.  Like the reference (:163-165) the number of statistics is
+    found by calling it once on a draw from the prior; that call is not counted as a simulation (:213-214)."""
+    key = (id(f_dist), id(prior))
+    if key in _HOST_WRAPPERS and _HOST_WRAPPERS[key].fn is f_dist:
+        return _HOST_WRAPPERS[key]
+    rng = np.random.default_rng()
+    θ = np.array([rng.normal(a, b) if k == _lib.PRIOR_NORMAL else rng.uniform(a, b) for k, a, b in prior.descriptors()])
+    probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
+    hd = HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
+                      univariate=prior.univariate, args=args, kwargs=kwargs)
+    _HOST_WRAPPERS[key] = hd
+    return hd
+
+
 def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.1, algorithm="single_eps",
                    seed=None, device=None, distributed=None, **kwargs):
     """SimulatedAnnealingABC.jl:151-227 -> SABCresult."""
@@ -147,10 +165,10 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     if not isinstance(prior, Distribution):
         raise TypeError("prior must be Normal, Uniform or product_distribution([...]) of those")
     if not isinstance(f_dist, DeviceDistance):
-        raise NotImplementedError(
-            "f_dist must be a device-coded DeviceDistance (models.py); running an arbitrary host callable "
-            "through the GPU loop is the next item of SURVEY.md section 8f and is not built"
-        )
+        if not callable(f_dist):
+            raise TypeError("f_dist must be a DeviceDistance or a callable f_dist(θ, *args, **kwargs)")
+        f_dist = as_host_distance(f_dist, prior, args, kwargs)               # :163-165 shape probe
+        args, kwargs = (), {}
     if args or kwargs:
         raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
     if len(prior) not in f_dist.n_para:
@@ -193,6 +211,11 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
     if not δ > 0:
         raise SABCError(-4, "Resamping intensity `δ` must be positive.")            # :262
     res = population_state
+    if not isinstance(f_dist, DeviceDistance) and callable(f_dist):
+        if not (isinstance(res._model, HostDistance) and res._model.fn is f_dist):
+            raise ValueError("f_dist differs from the one this SABCresult was initialised with")
+        res._model.args, res._model.kwargs = tuple(args), dict(kwargs)      # forwarded to f_dist, like :315
+        f_dist, args, kwargs = res._model, (), {}
     if args or kwargs:
         raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
     if f_dist is not res._model or prior is not res._prior:

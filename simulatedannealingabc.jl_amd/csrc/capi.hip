@@ -208,6 +208,13 @@ int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn
   return 0;
 }
 
+int sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx) {
+  if (!h || !fn) return hset(h, SABC_ERR_BAD_CONFIG, "null host simulator");
+  if (h->eng->model().model_id != SABC_MODEL_HOST) return hset(h, SABC_ERR_BAD_CONFIG, "the handle was not created with SABC_MODEL_HOST");
+  h->be->set_host_simulator(fn, ctx);
+  return 0;
+}
+
 int sabc_comm_unique_id(void *out_128b) {
   RcclApi *a = rccl_api();
   if (!a) { g_err = "librccl.so could not be loaded"; return SABC_ERR_COMM; }

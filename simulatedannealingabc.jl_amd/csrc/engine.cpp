@@ -42,7 +42,11 @@ int Engine::validate() {
       if (shard_n_local(sh_, r) < 2) return fail(SABC_ERR_BAD_CONFIG, "every shard needs at least two particles");
   const double *p = cfg_.model_params;
   bool ok = false;
+  host_mode_ = cfg_.model_id == SABC_MODEL_HOST;
   switch (cfg_.model_id) {
+    case SABC_MODEL_HOST:
+      ok = true;                                   // any d, s within the maxima; f_dist is the caller's
+      break;
     case SABC_MODEL_GAUSS_IID:
       ok = (d == 1 || d == 2) && (s == 1 || s == 2) && cfg_.n_model_params >= 4 && p[0] >= 1;
       break;
@@ -216,7 +220,11 @@ int Engine::initialize(int64_t n_simulation) {
   hist_capacity_ = 4;
   if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
   if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
-  if (be_->prior_simulate()) return fail(SABC_ERR_HIP, "prior sample / simulate kernel failed");   // :172-179
+  if (host_mode_) {
+    if (be_->host_prior_simulate()) return fail(SABC_ERR_CALLBACK, "prior sample / host simulator failed");   // :172-179
+  } else if (be_->prior_simulate()) {
+    return fail(SABC_ERR_HIP, "prior sample / simulate kernel failed");   // :172-179
+  }
   const double *gathered_rho = be_->rho_block();
   if (sh_.world > 1) {
     double *g = be_->gather_buffer((int64_t)sh_.world * s * sh_.cap);
@@ -253,6 +261,33 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
   c.iter = iter;
   c.prop_kind = a.proposal_kind; c.prop_p0 = a.proposal_p0; c.prop_p1 = a.proposal_p1;
   int64_t rows = 0, r = 0;
+  if (host_mode_) {
+    // f_dist on the host: propose on the device, simulate in the callback, accept on the device; the
+    // sums come from a stats pass afterwards.  Synchronous by nature (the callback sits in the middle).
+    if (a.proposal_kind == SABC_PROP_RANDOMWALK) {
+      PartnerView none;
+      std::memset(&none, 0, sizeof(none));
+      if (be_->host_update_range(c, none, 0, sh_.n_local)) return fail(SABC_ERR_CALLBACK, "host-simulator update failed");
+    } else {
+      const int64_t h = sh_.n_local / 2;
+      for (int half = 0; half < 2; ++half) {
+        const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
+        const double *base = be_->pop_block();
+        int64_t stride = 0;
+        if (sh_.world > 1) {
+          double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
+          if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
+          if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
+          base = g;
+          stride = (int64_t)d * sh_.cap;
+        }
+        if (be_->host_update_range(c, partner_view(base, stride, 1 - half), lo, cnt))
+          return fail(SABC_ERR_CALLBACK, "host-simulator update failed");
+      }
+    }
+    if (be_->host_stats(&rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
+    return global_reduce(rows, false);
+  }
   if (a.proposal_kind == SABC_PROP_RANDOMWALK) {
     // RandomWalk ignores the inactive half (proposals.jl:40,52), so both half batches of :304
     // are independent given eps and Sigma: one launch over the whole shard is the same update.
@@ -326,8 +361,9 @@ int Engine::update(const sabc_update_args &a) {
   // the update queued behind it see the flag and do nothing; the host learns it from the mailbox,
   // runs the resample (:341), finishes the control step, clears the flag and re-enqueues.
   const int32_t after_update = CTRL_PROPOSAL | CTRL_EPSILON | CTRL_PIVOT;   // :348-354
-  constexpr int kDepth = 2;
-  int64_t seqs[kDepth + 1] = {0};
+  constexpr int kMaxDepth = 2;
+  const int kDepth = host_mode_ ? 1 : kMaxDepth;     // a host simulator leaves nothing to queue ahead
+  int64_t seqs[kMaxDepth + 1] = {0};
   int64_t next_enqueue = 1, next_confirm = 1;
   auto hist_flag = [&](int64_t ix) { return (cph > 0 && ix % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };
   while (next_confirm <= n_pop) {                                           // :294
@@ -336,14 +372,14 @@ int Engine::update(const sabc_update_args &a) {
       if ((rc = enqueue_update(a, (uint64_t)(n_population_updates_ + ix), /*guarded=*/true))) return rc;
       const double threshold = (double)(n_resampling_ + 1) * a.resample;    // :340
       if ((rc = control(CTRL_GUARDED | CTRL_ACCUMULATE | CTRL_CHECK | after_update | hist_flag(ix), &a, a.v,
-                        /*notify=*/true, threshold, &seqs[ix % (kDepth + 1)])))
+                        /*notify=*/true, threshold, &seqs[ix % (kMaxDepth + 1)])))
         return rc;
       ++next_enqueue;
     }
     const int64_t ix = next_confirm;
     int64_t n_accept_now = 0;
     int halted = 0;
-    if ((rc = wait_step(seqs[ix % (kDepth + 1)], &n_accept_now, &halted))) return rc;
+    if ((rc = wait_step(seqs[ix % (kMaxDepth + 1)], &n_accept_now, &halted))) return rc;
     if (halted) {
       // n_accept >= (n_resampling + 1) * resample after update ix (:340): resample, then the part of
       // the control step that was skipped; updates queued behind ix were no-ops and are enqueued again

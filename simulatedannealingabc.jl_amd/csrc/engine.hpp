@@ -31,6 +31,11 @@ class Backend {
   virtual double *rho_block() = 0;                  // [s][cap]
   virtual double *sums_buffer() = 0;                // staging for the fused sums: reduction and allreduce target
   virtual double *gather_buffer(int64_t doubles) = 0;
+  // host-simulator mode (SABC_MODEL_HOST): f_dist is a host callback; a backend without it says so
+  virtual int set_host_simulator(sabc_simulate_fn, void *) { return -1; }
+  virtual int host_prior_simulate() { return -1; }                      // :172-179 with f_dist on the host
+  virtual int host_update_range(const StepArgs &, const PartnerView &, int64_t, int64_t) { return -1; }   // :308-331
+  virtual int host_stats(int64_t *) { return -1; }                      // moment sums + the update's accept count
   // K1
   virtual int prior_simulate() = 0;
   // K2: gathered_rho is [world][s][cap]; len_out[j] = knot count (<= 0: no positive entry)
@@ -114,6 +119,7 @@ class Engine {
   bool initialized_ = false;
 
   int np_ = 0, eps_len_ = 1;
+  bool host_mode_ = false;                          // f_dist is a host callback (SABC_MODEL_HOST)
   ControlBlock cb_;                                 // host mirror, current after every public call
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};

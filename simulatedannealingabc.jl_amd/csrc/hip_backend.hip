@@ -30,6 +30,10 @@ HipBackend::~HipBackend() {
   double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
+  if (host_thp_dev_) (void)hipFree(host_thp_dev_);
+  if (host_aux_dev_) (void)hipFree(host_aux_dev_);
+  if (host_rho_dev_) (void)hipFree(host_rho_dev_);
+  if (host_acc_dev_) (void)hipFree(host_acc_dev_);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (meta_dev_) (void)hipFree(meta_dev_);
   if (cb_dev_) (void)hipFree(cb_dev_);
@@ -177,6 +181,74 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
   ev_[kernel].clear();
   if (total_ms) *total_ms = prof_ms_[kernel];
   if (launches) *launches = prof_n_[kernel];
+  return 0;
+}
+
+// ---- host-simulator mode (SABC_MODEL_HOST) ---------------------------------------------------
+int HipBackend::ensure_host_buffers() {
+  if (host_thp_dev_) return 0;
+  const size_t cap = (size_t)sh_.cap;
+  HB_CHECK(hipMalloc((void **)&host_thp_dev_, (size_t)m_.d * cap * sizeof(double)), "hipMalloc(host thp)");
+  HB_CHECK(hipMalloc((void **)&host_aux_dev_, 2 * cap * sizeof(double)), "hipMalloc(host aux)");
+  HB_CHECK(hipMalloc((void **)&host_rho_dev_, (size_t)m_.s * cap * sizeof(double)), "hipMalloc(host rho)");
+  HB_CHECK(hipMalloc((void **)&host_acc_dev_, sizeof(unsigned long long)), "hipMalloc(host accept counter)");
+  HB_CHECK(hipMemsetAsync(host_acc_dev_, 0, sizeof(unsigned long long), stream_), "hipMemset");
+  return 0;
+}
+
+int HipBackend::host_prior_simulate() {
+  if (!host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
+  if (ensure_host_buffers()) return -1;
+  const int d = m_.d, s = m_.s;
+  const int64_t n = sh_.n_local;
+  HB_LAUNCH(launch_host_prior(m_, pop_ptrs(cur_), stream_), "k_host_prior");
+  std::vector<double> th((size_t)(d * n)), rho((size_t)(s * n), 0.0);
+  std::vector<int64_t> ids((size_t)n);
+  for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = sh_.gid0 + i;
+  const size_t w = (size_t)n * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
+  if (n > 0) HB_CHECK(hipMemcpy2DAsync(th.data(), w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  if (n > 0 && host_fn_(host_ctx_, th.data(), ids.data(), n, 0, rho.data())) { err_ = "the host simulator (f_dist) failed"; return -1; }
+  if (n > 0) HB_CHECK(hipMemcpy2DAsync(rho_, pitch, rho.data(), w, w, (size_t)s, hipMemcpyHostToDevice, stream_), "upload rho");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt) {
+  if (!host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
+  if (lo < 0 || cnt < 0 || lo + cnt > sh_.n_local) { err_ = "host_update_range: range outside the shard"; return -1; }
+  if (cnt == 0) return 0;
+  if (ensure_host_buffers()) return -1;
+  const int d = m_.d, s = m_.s;
+  HB_LAUNCH(launch_host_propose(m_, c, cb_dev_, pop_ptrs(cur_), pv, lo, cnt, host_thp_dev_, host_aux_dev_, stream_), "k_host_propose");
+  std::vector<double> thp((size_t)(d * cnt)), aux((size_t)(2 * cnt));
+  HB_CHECK(hipMemcpyAsync(thp.data(), host_thp_dev_, thp.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download proposals");
+  HB_CHECK(hipMemcpyAsync(aux.data(), host_aux_dev_, aux.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download aux");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  // only proposals inside the prior's support are simulated (:314-315)
+  std::vector<int64_t> ids, where;
+  for (int64_t t = 0; t < cnt; ++t)
+    if (aux[(size_t)t] > -INFINITY) { ids.push_back(sh_.gid0 + lo + t); where.push_back(t); }
+  const int64_t mv = (int64_t)ids.size();
+  std::vector<double> thv((size_t)(d * mv)), rhov((size_t)(s * mv), 0.0), rho((size_t)(s * cnt), 0.0);
+  for (int k = 0; k < d; ++k)
+    for (int64_t i = 0; i < mv; ++i) thv[(size_t)(k * mv + i)] = thp[(size_t)(k * cnt + where[(size_t)i])];
+  if (mv > 0 && host_fn_(host_ctx_, thv.data(), ids.data(), mv, c.iter, rhov.data())) { err_ = "the host simulator (f_dist) failed"; return -1; }
+  for (int j = 0; j < s; ++j)
+    for (int64_t i = 0; i < mv; ++i) rho[(size_t)(j * cnt + where[(size_t)i])] = rhov[(size_t)(j * mv + i)];
+  HB_CHECK(hipMemcpyAsync(host_rho_dev_, rho.data(), rho.size() * sizeof(double), hipMemcpyHostToDevice, stream_), "upload rho");
+  prof_begin(SABC_KERNEL_UPDATE);
+  HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, host_thp_dev_, host_aux_dev_, host_rho_dev_,
+                               host_acc_dev_, stream_), "k_host_accept");
+  prof_end(SABC_KERNEL_UPDATE);
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");      // the staging vectors go out of scope
+  return 0;
+}
+
+int HipBackend::host_stats(int64_t *rows_out) {
+  if (ensure_host_buffers()) return -1;
+  HB_LAUNCH(launch_stats_rt(m_, cb_dev_, pop_ptrs(cur_), partials_, host_acc_dev_, stream_), "k_stats_rt");
+  *rows_out = n_blocks(sh_.n_local);
   return 0;
 }
 

@@ -19,6 +19,10 @@ class HipBackend : public Backend {
   double *rho_block() override { return rho_; }
   double *sums_buffer() override;
   double *gather_buffer(int64_t doubles) override;
+  int set_host_simulator(sabc_simulate_fn fn, void *ctx) override { host_fn_ = fn; host_ctx_ = ctx; return 0; }
+  int host_prior_simulate() override;
+  int host_update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt) override;
+  int host_stats(int64_t *rows_out) override;
   int prior_simulate() override;
   int build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) override;
   int cdf_population() override;
@@ -92,6 +96,12 @@ class HipBackend : public Backend {
   size_t sort_tmp_bytes_ = 0;
   int64_t *meta_dev_ = nullptr;
   std::vector<double> stage_;
+  // host-simulator mode
+  sabc_simulate_fn host_fn_ = nullptr;
+  void *host_ctx_ = nullptr;
+  double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr;
+  unsigned long long *host_acc_dev_ = nullptr;
+  int ensure_host_buffers();
   int prof_ = 0, prof_open_ = -1;
   struct EvPair { hipEvent_t a, b; };
   std::vector<EvPair> ev_[SABC_KERNEL_COUNT];

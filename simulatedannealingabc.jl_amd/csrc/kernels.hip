@@ -390,6 +390,178 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Host-simulator mode (SABC_MODEL_HOST): f_dist is a host callable, so the per-particle
+// body (:308-331) is cut at the simulator.  k_host_propose does :311-314 (proposal, prior gate),
+// the host evaluates f_dist for the proposals that passed the gate, k_host_accept does :316-329
+// (ECDF, annealed MH test, store).  d and s are run-time values here (any model within the
+// maxima); these kernels are host-bound by construction, so they are written for generality.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
+  double lp = 0.0;
+  for (int k = 0; k < m.d; ++k) {
+    const double x = th[k];
+    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
+      const double z = (x - m.prior_a[k]) / m.prior_b[k];
+      lp += -(z * z + SABC_LOG2PI) / 2.0 - log(m.prior_b[k]);
+    } else {
+      if (x >= m.prior_a[k] && x <= m.prior_b[k]) lp += -log(m.prior_b[k] - m.prior_a[k]);
+      else lp = -INFINITY;
+    }
+  }
+  return lp;
+}
+
+// rand(prior) for the shard (:174); theta goes to the population rows
+__global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const PopPtrs pp) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  for (int k = 0; k < m.d; ++k) {
+    const u32x4 w = stream_block(m.seed, gid, PURPOSE_PRIOR, 0, (uint32_t)k);
+    double v;
+    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
+      double z0, z1;
+      box_muller(w, z0, z1);
+      v = m.prior_a[k] + m.prior_b[k] * z0;
+    } else {
+      v = m.prior_a[k] + (m.prior_b[k] - m.prior_a[k]) * u52(w.x, w.y);
+    }
+    pp.pop[(int64_t)k * pp.cap + li] = v;
+  }
+}
+
+// thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor)
+__global__ void __launch_bounds__(kBlock)
+k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp,
+               const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ thp_out,
+               double *__restrict__ aux) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= act_n) return;
+  const int d = m.d;
+  const int64_t li = act_lo + t;
+  const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  double th[kMaxPara], thp[kMaxPara];
+  for (int k = 0; k < d; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+  double logf = 0.0;
+  if (c.prop_kind == SABC_PROP_RANDOMWALK) {
+    NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
+    double z[kMaxPara];
+    for (int k = 0; k < d; ++k) z[k] = ns.next();
+    for (int k = 0; k < d; ++k) {
+      double a = 0.0;
+      for (int l = 0; l <= k; ++l) a += cb->chol[k * d + l] * z[l];
+      thp[k] = th[k] + a;
+    }
+  } else if (c.prop_kind == SABC_PROP_DIFFEVO) {
+    uint64_t i1 = 0, i2 = 0;
+    for (uint32_t a = 0;; ++a) {
+      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
+      i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+      i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
+      if (i1 != i2 || a > 64u) break;
+    }
+    double z0, z1;
+    box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
+    const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);
+    const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
+    for (int k = 0; k < d; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+  } else {
+    const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
+    const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+    const double U = u52(w.z, w.w);
+    const double a = c.prop_p0;
+    const double tt = (a - 1.0) * U + 1.0;
+    const double z = tt * tt / a;
+    const double *p = partner_ptr(pv, ip);
+    for (int k = 0; k < d; ++k) {
+      const double pk = p[(int64_t)k * pv.cap];
+      thp[k] = pk + z * (th[k] - pk);
+    }
+    logf = log(z) * (double)(d - 1);
+  }
+  for (int k = 0; k < d; ++k) thp_out[(int64_t)k * act_n + t] = thp[k];
+  aux[t] = prior_logpdf_rt(m, thp);
+  aux[act_n + t] = logf;
+}
+
+// rho_prop [s][act_n] from the host; n_accept is counted with an integer atomic (exact, order-free)
+__global__ void __launch_bounds__(kBlock)
+k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
+              const int64_t act_lo, const int64_t act_n, const double *__restrict__ thp_in,
+              const double *__restrict__ aux, const double *__restrict__ rho_prop, unsigned long long *n_accept) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool accepted = false;
+  if (t < act_n) {
+    const int d = m.d, s = m.s;
+    const int64_t li = act_lo + t;
+    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+    const double lpp = aux[t], logf = aux[act_n + t];
+    double log_accept = -INFINITY;
+    double up[kMaxStats];
+    if (lpp > -INFINITY) {
+      double th[kMaxPara];
+      for (int k = 0; k < d; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+      double a = 0.0;
+      for (int j = 0; j < s; ++j) {
+        up[j] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rho_prop[(int64_t)j * act_n + t]);
+        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
+        a += (pp.pop[(int64_t)(d + j) * pp.cap + li] - up[j]) / e;
+      }
+      log_accept = lpp - prior_logpdf_rt(m, th) + a + logf;
+    }
+    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
+    accepted = log(u52(wa.x, wa.y)) < log_accept;
+    if (accepted) {
+      for (int k = 0; k < d; ++k) pp.pop[(int64_t)k * pp.cap + li] = thp_in[(int64_t)k * act_n + t];
+      for (int j = 0; j < s; ++j) {
+        pp.pop[(int64_t)(d + j) * pp.cap + li] = up[j];
+        pp.rho[(int64_t)j * pp.cap + li] = rho_prop[(int64_t)j * act_n + t];
+      }
+    }
+  }
+  const unsigned long long votes = __ballot(accepted);
+  if ((threadIdx.x & 63) == 0 && votes) atomicAdd(n_accept, (unsigned long long)__popcll(votes));
+}
+
+// moment sums with run-time d and s (same partial-row layout as k_stats); block 0 also folds the
+// accept counter of the host-mode update into component 0 and clears it
+__global__ void __launch_bounds__(kBlock)
+k_stats_rt(const int d, const int s, const ControlBlock *__restrict__ cb, const PopPtrs pp, double *__restrict__ partials,
+           unsigned long long *n_accept) {
+  __shared__ double sm[kBlock / 64];
+  const int np = n_partials(d, s);
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = li < pp.n_local;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double dk[kMaxPara];
+  for (int k = 0; k < d; ++k) dk[k] = live ? pp.pop[(int64_t)k * pp.cap + li] - cb->pivot[k] : 0.0;
+  for (int q = 0; q < np; ++q) {
+    double v = 0.0;
+    if (live) {
+      if (q == 0) v = 0.0;
+      else if (q < 1 + s) v = pp.pop[(int64_t)(d + q - 1) * pp.cap + li];
+      else if (q < 1 + 2 * s) v = pp.rho[(int64_t)(q - 1 - s) * pp.cap + li];
+      else if (q < 1 + 2 * s + d) v = dk[q - 1 - 2 * s];
+      else {
+        int r = q - (1 + 2 * s + d), kk = 0;          // row-major lower index -> (kk, ll)
+        while (r > kk) { r -= kk + 1; ++kk; }
+        v = dk[kk] * dk[r];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+      if (q == 0 && blockIdx.x == 0 && n_accept) { tot = (double)*n_accept; *n_accept = 0ull; }
+      partials[(int64_t)blockIdx.x * np + q] = tot;
+    }
+    __syncthreads();
+  }
+}
+
 // moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
 template <int D, int S>
 __global__ void __launch_bounds__(kBlock)
@@ -823,8 +995,40 @@ int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb,
   return SABC_LAUNCH_RC();
 }
 
+int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_host_prior, dim3((unsigned)n_blocks(pp.n_local)), dim3(kBlock), 0, stream, m, pp);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
+                        int64_t act_lo, int64_t act_n, double *thp, double *aux, hipStream_t stream) {
+  if (act_n <= 0) return 0;
+  hipLaunchKernelGGL(k_host_propose, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, pv, act_lo, act_n,
+                     thp, aux);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
+                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop,
+                       unsigned long long *n_accept, hipStream_t stream) {
+  if (act_n <= 0) return 0;
+  hipLaunchKernelGGL(k_host_accept, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, cdf, act_lo, act_n,
+                     thp, aux, rho_prop, n_accept);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, unsigned long long *n_accept,
+                    hipStream_t stream) {
+  if (pp.n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_stats_rt, dim3((unsigned)n_blocks(pp.n_local)), dim3(kBlock), 0, stream, m.d, m.s, cb, pp, partials,
+                     n_accept);
+  return SABC_LAUNCH_RC();
+}
+
 int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream) {
   if (pp.n_local <= 0) return 0;
+  if (m.model_id == SABC_MODEL_HOST) return launch_stats_rt(m, cb, pp, partials, nullptr, stream);
   const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
 #define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, cb, pp, partials)
   if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }

@@ -79,6 +79,15 @@ int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, 
                           hipStream_t stream);
 // ascending sort of n doubles (rocPRIM radix sort); query tmp size with tmp == nullptr
 int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream);
+// host-simulator mode (SABC_MODEL_HOST): the per-particle body cut at f_dist
+int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
+int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
+                        int64_t act_lo, int64_t act_n, double *thp, double *aux, hipStream_t stream);
+int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
+                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop,
+                       unsigned long long *n_accept, hipStream_t stream);
+int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, unsigned long long *n_accept,
+                    hipStream_t stream);
 // operators
 int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m, double *out, hipStream_t stream);
 int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);

@@ -43,6 +43,14 @@ class SabcHandle:
             raise SABCError(rc, self._L.sabc_last_global_error().decode("utf-8", "replace"))
         self._h = h
         self._keep = []   # ctypes callbacks must outlive the handle
+        self._host_model = None
+        if getattr(model, "model_id", None) == _lib.MODEL_HOST:
+            cb = model.callback()
+            self._keep.append(cb)
+            self._host_model = model
+            rc = self._L.sabc_set_host_simulator(self._h, cb, None)
+            if rc:
+                raise SABCError(rc, self._L.sabc_last_error(self._h).decode("utf-8", "replace"))
 
     def _load_library(self):
         return _lib.lib()          # libsabc_hip.so; raises if it is missing (no fallback)
@@ -60,6 +68,9 @@ class SabcHandle:
             pass
 
     def _check(self, rc):
+        if rc and self._host_model is not None and self._host_model.error is not None:
+            err, self._host_model.error = self._host_model.error, None
+            raise err                     # the exception f_dist raised inside the host callback
         if rc:
             raise SABCError(rc, self._L.sabc_last_error(self._h).decode("utf-8", "replace"))
 

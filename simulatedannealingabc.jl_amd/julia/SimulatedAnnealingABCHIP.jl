@@ -112,6 +112,36 @@ params(m::Gaussian2D) = Float64[m.n_obs, m.r, m.obs_mean..., m.obs_varsum, m.obs
 params(m::GandK) = Float64[m.n_draws, m.c, m.ranks..., m.obs...]
 params(m::LotkaVolterra) = Float64[m.n_steps, m.dt, m.σ, m.x0, m.y0, m.obs...]
 
+# ---- any other f_dist: stays a Julia function, called back by the library for the proposals that
+#      passed the prior gate (include/sabc_hip.h: sabc_simulate_fn); everything else runs on the GPU
+struct HostDistance{F} <: DeviceDistance
+    f::F
+    n_stats::Int
+    n_para::Int
+    args::Tuple
+    kwargs::NamedTuple
+end
+model_id(::HostDistance) = Int32(0)
+n_stats(m::HostDistance) = m.n_stats
+params(::HostDistance) = Float64[]
+
+function host_callback(m::HostDistance)
+    function cb(ctx::Ptr{Cvoid}, theta::Ptr{Float64}, ids::Ptr{Int64}, n::Int64, iter::UInt64, rho::Ptr{Float64})::Cint
+        try
+            Θ = unsafe_wrap(Array, theta, (Int(n), m.n_para))        # column-major n x d
+            R = unsafe_wrap(Array, rho, (Int(n), m.n_stats))
+            Threads.@threads for i in 1:n                             # like SimulatedAnnealingABC.jl:308
+                θ = m.n_para == 1 ? Θ[i, 1] : Θ[i, :]
+                R[i, :] .= collect(Float64, m.f(θ, m.args...; m.kwargs...))
+            end
+            return Cint(0)
+        catch
+            return Cint(-1)
+        end
+    end
+    @cfunction($cb, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int64, UInt64, Ptr{Float64}))
+end
+
 # ---- priors as data: Normal, Uniform and products of those ----
 prior_descriptor(d::Normal) = (Int32(0), d.μ, d.σ)
 prior_descriptor(d::Uniform) = (Int32(1), d.a, d.b)
@@ -160,7 +190,26 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sabc_create, libsabc), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))
     finalizer(r -> (r[] != C_NULL && ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[]); r[] = C_NULL), h)
+    if f_dist isa HostDistance
+        cb = host_callback(f_dist)
+        HOST_CALLBACKS[h[]] = cb                       # keep the closure alive as long as the handle
+        check(h[], ccall((:sabc_set_host_simulator, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], cb, C_NULL))
+    end
     h
+end
+const HOST_CALLBACKS = Dict{Ptr{Cvoid},Any}()
+
+# the reference's own signature (SimulatedAnnealingABC.jl:451): any Function; the number of statistics is
+# probed with one call on a prior draw, as at :163-165
+function sabc(f_dist::Function, prior::Distribution, args...; kwargs...)
+    f_dist isa DeviceDistance && return invoke(sabc, Tuple{DeviceDistance,Distribution}, f_dist, prior; kwargs...)
+    own = (:n_particles, :n_simulation, :algorithm, :proposal, :resample, :v, :δ, :checkpoint_history,
+           :show_progressbar, :show_checkpoint, :seed, :device)
+    mine = (; (k => v for (k, v) in kwargs if k in own)...)
+    theirs = (; (k => v for (k, v) in kwargs if !(k in own))...)
+    ρ = f_dist(rand(prior), args...; theirs...)
+    hd = HostDistance(f_dist, length(ρ), length(prior), args, theirs)
+    invoke(sabc, Tuple{DeviceDistance,Distribution}, hd, prior; mine...)
 end
 
 # copies device state into the Julia arrays in place (`.=` at SimulatedAnnealingABC.jl:395-397)

@@ -89,3 +89,45 @@ class LotkaVolterra(DeviceDistance):
     @property
     def params(self):
         return [self.n_steps, self.dt, self.σ, self.x0, self.y0, *self.obs]
+
+
+class HostDistance(DeviceDistance):
+    """Any host callable as `f_dist` (SimulatedAnnealingABC.jl:164,175,315): `fn(θ, *args, **kwargs)` returning a
+    scalar, tuple or vector of non-negative distances, exactly what the reference accepts.  The proposal,
+    prior gate, ECDF transform, acceptance, reductions and resampling still run on the GPU; only the
+    simulator is called on the host, for the proposals that passed the prior gate.
+
+    batched=True: `fn(Θ, ...)` gets all m proposals at once (Θ is m×d, or length m for a univariate
+    prior) and returns m×s.  with_ids=True: `fn(θ, particle_id, iteration, ...)`, so that a simulator can
+    key its own random streams (used by the parity tests)."""
+    model_id = _lib.MODEL_HOST
+    params = ()
+
+    def __init__(self, fn, n_stats, n_para, univariate, args=(), kwargs=None, batched=False, with_ids=False):
+        self.fn, self.n_stats, self.n_para = fn, int(n_stats), (int(n_para),)
+        self.univariate, self.args, self.kwargs = bool(univariate), tuple(args), dict(kwargs or {})
+        self.batched, self.with_ids = bool(batched), bool(with_ids)
+        self.error = None            # an exception raised inside the callback, re-raised by the caller
+
+    def callback(self):
+        d, s = self.n_para[0], self.n_stats
+
+        def cb(ctx, theta, ids, m, it, rho_out):
+            try:
+                th = np.ctypeslib.as_array(theta, shape=(d, m))
+                out = np.ctypeslib.as_array(rho_out, shape=(s, m))
+                if self.batched:
+                    arg = th[0].copy() if self.univariate else np.ascontiguousarray(th.T)
+                    r = np.asarray(self.fn(arg, *self.args, **self.kwargs), dtype=np.float64).reshape(m, s)
+                    out[...] = r.T
+                else:
+                    for i in range(m):
+                        x = float(th[0, i]) if self.univariate else th[:, i].copy()
+                        extra = (int(ids[i]), int(it)) if self.with_ids else ()
+                        out[:, i] = np.atleast_1d(np.asarray(self.fn(x, *extra, *self.args, **self.kwargs), dtype=np.float64))
+                return 0
+            except Exception as e:   # never raise through the C frame; sabc() re-raises it
+                self.error = e
+                return -1
+
+        return _lib.SIMULATE_FN(cb)

@@ -1,0 +1,115 @@
+"""an arbitrary host callable as `f_dist` -- proposal, prior gate, ECDF, acceptance,
+reductions and resampling on the device, only the simulator on the host.  This is what makes the
+package a drop-in for every user model of the reference, not only the device-coded ones."""
+import numpy as np
+import pytest
+
+from tests.cases import SEED, hip_model_prior, oracle_proposal
+
+pytestmark = pytest.mark.gpu
+
+
+def gauss_iid_keyed(O, n_obs, obs_mean):
+    """f_dist(θ, particle_id, iter): the Gaussian i.i.d. simulator on the host, drawing from the same
+    Philox stream the device-coded simulator uses -- so all three implementations must agree."""
+    def f(θ, pid, it):
+        z = np.array([O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b) for b in range((n_obs + 1) // 2)]).ravel()[:n_obs]
+        x = float(np.atleast_1d(θ)[0]) + z
+        s = 0.0
+        for v in x:              # same summation order as the oracle / the kernel
+            s += v
+        return abs(obs_mean - s / n_obs)
+    return f
+
+
+@pytest.mark.parametrize("prop", ["rw", "de", "stretch"])
+def test_host_simulator_matches_oracle_and_device_coded_model(S, O, gpu, prop):
+    n, k, n_obs, ybar = 300, 6, 20, 1.4
+    prior = S.Normal(0.0, 2.0)
+    f = gauss_iid_keyed(O, n_obs, ybar)
+    from tests.cases import hip_proposal
+    hd = S.HostDistance(f, n_stats=1, n_para=1, univariate=True, with_ids=True)
+    res = S.sabc(hd, prior, n_particles=n, n_simulation=(k + 1) * n, proposal=hip_proposal(S, prop, 1), resample=n // 4, seed=SEED)
+    # the oracle with the very same Python callable as its f_dist
+    cb = O.host_simulator(f, 1, 1)
+    cfg = O.make_config(n_particles=n, n_para=1, n_stats=1, model_id=O.MODEL_HOST, model_params=[], seed=SEED,
+                        prior=[(O.PRIOR_NORMAL, 0.0, 2.0)], host_fn=cb)
+    run = O.OracleRun(cfg)
+    run.initialize((k + 1) * n)
+    run.update(O.make_update_args(n_simulation=k * n, proposal=oracle_proposal(O, prop, 1), n_para=1, n_particles=n, resample=n // 4))
+    c = run.counters
+    assert (res.state.n_accept, res.state.n_resampling, res.state.n_population_updates) == \
+        (c["n_accept"], c["n_resampling"], c["n_population_updates"])
+    tol = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}[prop]
+    np.testing.assert_allclose(res.population, run.theta[0], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(res.ρ.T, run.rho, rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+    # ... and the device-coded simulator, which draws the same normals on the GPU
+    dev = S.sabc(S.GaussianIID(n_obs=n_obs, sd=1.0, obs_mean=ybar), prior, n_particles=n, n_simulation=(k + 1) * n,
+                 proposal=hip_proposal(S, prop, 1), resample=n // 4, seed=SEED)
+    assert dev.state.n_accept == res.state.n_accept
+    np.testing.assert_allclose(dev.population, res.population, rtol=tol, atol=tol * 1e-2)
+
+
+@pytest.mark.parametrize("alg", ["multi_eps", "single_eps"])
+def test_reference_closures_run_unchanged(S, gpu, alg):
+    """test/runtests.jl:35-79 and :125-156 with the f_dist written as a plain closure, like in the reference."""
+    rng = np.random.default_rng(1)
+    f_dist = lambda θ: abs(0.0 - np.mean(rng.normal(θ, 1.0, 100)))                      # runtests.jl:35
+    prior = S.Uniform(-10, 10)
+    res = S.sabc(f_dist, prior, n_particles=100, n_simulation=1000, algorithm=alg)
+    assert res.state.n_simulation <= 1000 and res.state.n_population_updates == 9 and len(res.population) == 100
+    S.update_population_(res, f_dist, prior, n_simulation=1000)
+    assert res.state.n_simulation <= 2000 and res.state.n_population_updates == 19
+    n_sim = res.state.n_simulation
+    S.update_population_(res, f_dist, prior, n_simulation=50)
+    assert res.state.n_simulation == n_sim
+
+    def two_stats(θ):                                                                    # runtests.jl:128-131
+        y = rng.normal(θ[0], θ[1], 10)
+        return (abs(0 - np.mean(y)), abs(1 - np.mean(y ** 2)))
+    prior2 = S.product_distribution([S.Normal(0, 1), S.Uniform(0, 2)])
+    res = S.sabc(two_stats, prior2, n_particles=100, n_simulation=1000, algorithm=alg)
+    assert np.all(res.state.ϵ < 1) and res.u.shape == (100, 2) and res.population.shape == (100, 2)
+
+
+def test_any_dimension_and_statistics(S, gpu):
+    """d = 5 parameters and s = 3 statistics: no device-coded simulator has this shape."""
+    rng = np.random.default_rng(2)
+    truth = np.array([1.0, -2.0, 0.5, 3.0, 0.0])
+    def f_dist(θ, scale, offset=0.0):
+        y = θ + scale * rng.standard_normal(5) + offset
+        return np.array([np.abs(y - truth).mean(), abs(y.sum() - truth.sum()), np.abs(y - truth).max()])
+    prior = S.product_distribution([S.Normal(0, 3)] * 5)
+    res = S.sabc(f_dist, prior, 0.05, n_particles=400, n_simulation=400 * 40, proposal=S.RandomWalk(n_para=5), offset=0.0,
+                 seed=SEED)                                  # args / kwargs are forwarded to f_dist (:315)
+    assert res.population.shape == (400, 5) and res.u.shape == (400, 3) and res.state.n_population_updates == 39
+    assert np.abs(res.population.mean(0) - truth).max() < 0.5           # the prior sd is 3
+    sg = res._handle.proposal_sigma
+    np.testing.assert_allclose(sg, 0.8 * (np.cov(res.population.T) + 1e-8 * np.eye(5)), rtol=1e-6)
+
+
+def test_batched_host_simulator(S, gpu):
+    rng = np.random.default_rng(3)
+    def f_batch(Θ):                                                    # Θ: length-m vector (univariate prior)
+        return np.abs(1.5 - (Θ[:, None] + rng.standard_normal((len(Θ), 100))).mean(1))
+    hd = S.HostDistance(f_batch, n_stats=1, n_para=1, univariate=True, batched=True)
+    res = S.sabc(hd, S.Normal(0, 2), n_particles=5000, n_simulation=5000 * 30, proposal=S.RandomWalk(n_para=1), seed=SEED)
+    post_var = 1 / (1 / 4 + 100)
+    assert abs(res.population.mean() - post_var * 100 * 1.5) < 0.03 and 0.5 < res.population.var() / post_var < 2.0
+
+
+def test_exception_in_f_dist_propagates(S, gpu):
+    calls = {"n": 0}
+    def f_dist(θ):
+        calls["n"] += 1
+        if calls["n"] > 150:
+            raise ZeroDivisionError("simulator blew up")
+        return abs(θ)
+    with pytest.raises(ZeroDivisionError, match="blew up"):
+        S.sabc(f_dist, S.Normal(0, 1), n_particles=100, n_simulation=1000)
+
+
+def test_negative_distance_from_host_simulator(S, gpu):
+    with pytest.raises(S.SABCError, match="Negative distances"):       # SimulatedAnnealingABC.jl:185
+        S.sabc(lambda θ: θ, S.Normal(0, 1), n_particles=100, n_simulation=1000)
