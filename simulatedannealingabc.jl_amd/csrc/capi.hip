@@ -114,6 +114,7 @@ class RcclCollectives : public Collectives {
 };
 
 int usable_device(int device, std::string &why) {
+  (void)hipGetLastError();   // sticky: do not let an earlier failure leak into the launch checks below
   int n = 0;
   const hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) {

@@ -13,8 +13,10 @@ namespace sabc {
     if (rc_) return rc_;                           \
   } while (0)
 
+// launchers report hipGetLastError(), which is sticky: clear whatever an earlier, unrelated HIP call left
 #define HB_LAUNCH(expr, what)                      \
   do {                                             \
+    (void)hipGetLastError();                       \
     const int e_ = (expr);                         \
     if (e_) return check((hipError_t)e_, (what));  \
   } while (0)
@@ -22,6 +24,7 @@ namespace sabc {
 HipBackend::HipBackend(int device) : device_(device) {}
 
 HipBackend::~HipBackend() {
+  if (!stream_ && !pop_[0]) return;                // never allocated (e.g. create failed on a bad device ordinal)
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   for (auto &v : ev_)
