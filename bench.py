@@ -82,6 +82,8 @@ def main():
                     help="cfg2 is the headline workload (BASELINE configs[1]); the others are secondary measurements")
     ap.add_argument("--algorithm", default="single_eps", choices=["single_eps", "multi_eps"])
     ap.add_argument("--n-obs", type=int, default=100, help="cfg2 only: draws per simulation (100 is the BASELINE workload)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) is the product path; gloo lets several ranks share one GPU to rehearse the N > 1 code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
@@ -100,10 +102,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SABC engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()      # == local_rank on a node with one GPU per rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     weak = args.particles_per_gpu > 0
     n = args.particles_per_gpu * world if weak else args.n_particles
@@ -128,12 +134,12 @@ def main():
                 "stretch": S.StretchMove()}[args.proposal]
     alg = S._lib.ALG_MULTI_EPS if args.algorithm == "multi_eps" else S._lib.ALG_SINGLE_EPS
 
-    h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=local_rank, rank=rank,
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank,
                      world=world)
     transport = "none"
     if world > 1:
         from sabc_amd.dist import install_collectives
-        transport = install_collectives(h, local_rank)
+        transport = install_collectives(h, device)
     t_init0 = time.perf_counter()
     h.initialize(n)
     torch.cuda.synchronize()
@@ -155,7 +161,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -206,7 +212,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
-                "traffic": load_traffic(n, args.config),
+                "traffic": load_traffic(n, args.config) if world == 1 else None,   # measured for a 1e6-particle launch
                 "kernel": f"k_update<{type(model).__name__},{d},{s},{args.proposal}>",
                 "avg_launch_us": avg_launch_s * 1e6 if launches else None,
                 "launches": real_launches, "aborted_launches": aborted,

@@ -34,9 +34,10 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
     double cov[kMaxPara * kMaxPara];
     hostmath::cov_from_sums(S, Q, d, n, cov);
     if (d == 1) {
-      cb.sigma[0] = a.prop_p0 * cov[0];                                              // proposals.jl:59
-      if (cb.sigma[0] < 0.0) cb.error = SABC_ERR_NOT_POSDEF;
-      else cb.chol[0] = sqrt(cb.sigma[0]);                                           // proposals.jl:54
+      // a variance is >= 0; the one-pass formula can round a population of identical particles (possible
+      // after a resample of a tiny population) to -1e-17, where the reference's two-pass cov gives 0
+      cb.sigma[0] = a.prop_p0 * (cov[0] > 0.0 ? cov[0] : 0.0);                       // proposals.jl:59
+      cb.chol[0] = sqrt(cb.sigma[0]);                                                // proposals.jl:54
     } else {
       for (int k = 0; k < d; ++k)
         for (int l = 0; l < d; ++l)

@@ -1,0 +1,107 @@
+"""Edge cases of the path on the device: the smallest populations the reference's loop admits, odd sizes,
+budgets that are not multiples of n, priors that gate almost every proposal, the maximum shapes of
+the host-simulator mode, and simulators that return zeros."""
+import numpy as np
+import pytest
+
+from tests.cases import SEED, hip_model_prior, hip_proposal, oracle_proposal, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 63, 64, 65, 257])
+def test_tiny_and_ragged_populations(S, O, gpu, n):
+    """RandomWalk works from n = 2 (cov needs two particles); DE needs two particles per half batch (n >= 4)."""
+    name, d = "gauss1_cfg2", 1
+    model, prior = hip_model_prior(S, name)
+    for prop in (("rw", "stretch") if n < 4 else ("rw", "stretch", "de")):
+        res = S.sabc(model, prior, n_particles=n, n_simulation=n * 8 + (n - 1), proposal=hip_proposal(S, prop, d), seed=SEED)
+        run = oracle_run(O, name, n, n * 8 + (n - 1), prop=prop)
+        c = run.counters
+        assert (res.state.n_simulation, res.state.n_accept, res.state.n_resampling, res.state.n_population_updates) == \
+            (c["n_simulation"], c["n_accept"], c["n_resampling"], c["n_population_updates"])
+        assert res.state.n_population_updates == 7
+        np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-6, atol=1e-9)
+
+
+def test_too_few_particles_for_differential_evolution(S, gpu):
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    with pytest.raises(S.SABCError) as e:       # the reference would spin forever in proposals.jl:104-107
+        S.sabc(model, prior, n_particles=3, n_simulation=30, proposal=S.DifferentialEvolution(n_para=1), seed=SEED)
+    assert e.value.code == -8
+
+
+def test_prior_gate_rejects_most_proposals(S, O, gpu):
+    """A narrow Uniform prior: most proposals fall outside, log_accept = -Inf (:320-322), the simulator is
+    skipped for them, and n_simulation still counts them (:276,391)."""
+    n = 2000
+    model = S.GaussianIID(n_obs=100, sd=1.0, obs_mean=0.0)
+    prior = S.Uniform(-0.01, 0.01)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=n * 11, proposal=S.StretchMove(), seed=SEED)
+    assert res.state.n_simulation == n * 11 and np.all(np.abs(res.population) <= 0.01)
+    cfg = O.make_config(n_particles=n, n_para=1, n_stats=1, model_id=O.MODEL_GAUSS_IID, model_params=model.params,
+                        prior=[(O.PRIOR_UNIFORM, -0.01, 0.01)], seed=SEED)
+    run = O.OracleRun(cfg)
+    run.initialize(n * 11)
+    run.update(O.make_update_args(n_simulation=n * 10, proposal=oracle_proposal(O, "stretch", 1), n_particles=n))
+    assert res.state.n_accept == run.counters["n_accept"]
+    np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-7, atol=1e-12)
+
+
+def test_zero_distances_are_dropped_from_the_ecdf(S, gpu):
+    """cdf_estimators.jl:29: zeros are filtered before the knots are built; a statistic that is zero for some
+    particles still gives a valid table (u = 0 for them)."""
+    def f_dist(θ):
+        return (abs(θ), 0.0 if θ < 0 else abs(θ) + 0.5)
+    res = S.sabc(f_dist, S.Normal(0, 1), n_particles=400, n_simulation=400 * 6, seed=SEED)
+    k1, k2 = res.state.cdfs_dist_prior.knots(0), res.state.cdfs_dist_prior.knots(1)
+    assert len(k1) == 402 and 100 < len(k2) < 402 and k2[0] == 0.0 and k2[1] > 0.0
+    assert np.all((res.u >= 0) & (res.u <= 1))
+    with pytest.raises(S.SABCError) as e:       # every distance zero: maximum(x) of an empty collection (:33)
+        S.sabc(lambda θ: 0.0, S.Normal(0, 1), n_particles=100, n_simulation=1000)
+    assert e.value.code == -10
+
+
+def test_maximum_shapes_in_host_mode(S, O, gpu):
+    """d = 8 parameters, s = 8 statistics (SABC_MAX_PARA / SABC_MAX_STATS), both eps schedules, every proposal,
+    against the oracle driven by the same (deterministic, id-keyed) host simulator.  With 8 statistics the
+    multi-eps schedule of :100-117 can leave the (0, 1/2) branch of its beta equation (mean u > 1/2 gives a
+    negative beta): the device-side control step must follow the oracle there too."""
+    truth = np.linspace(-1, 1, 8)
+    def f_dist(θ, pid, it):
+        z = np.array([O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b) for b in range(4)]).ravel()
+        return np.abs(θ + 0.1 * z - truth)
+    pri = [("N", 0.0, 2.0)] * 4 + [("U", -3.0, 3.0)] * 4
+    prior = S.product_distribution([S.Normal(a, b) if k == "N" else S.Uniform(a, b) for k, a, b in pri])
+    opri = [(O.PRIOR_NORMAL if k == "N" else O.PRIOR_UNIFORM, a, b) for k, a, b in pri]
+    n, k = 200, 8
+    for alg in ("single_eps", "multi_eps"):
+        for prop in ("rw", "de", "stretch"):
+            hd = S.HostDistance(f_dist, n_stats=8, n_para=8, univariate=False, with_ids=True)
+            res = S.sabc(hd, prior, n_particles=n, n_simulation=n * (k + 1), algorithm=alg, proposal=hip_proposal(S, prop, 8),
+                         resample=n // 2, seed=SEED)
+            cb = O.host_simulator(f_dist, 8, 8)
+            cfg = O.make_config(n_particles=n, n_para=8, n_stats=8, model_id=O.MODEL_HOST, model_params=[], prior=opri, seed=SEED,
+                                algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS, host_fn=cb)
+            run = O.OracleRun(cfg)
+            run.initialize(n * (k + 1))
+            run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, 8), n_para=8, n_particles=n, resample=n // 2))
+            assert res.population.shape == (n, 8) and res.u.shape == (n, 8) and len(res.state.ϵ) == (8 if alg == "multi_eps" else 1)
+            assert res.state.n_accept == run.counters["n_accept"] and res.state.n_resampling == run.counters["n_resampling"]
+            tol = {"rw": 1e-8, "stretch": 1e-6, "de": 1e-5}[prop]
+            np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+            np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
+    with pytest.raises(S.SABCError):
+        S.sabc(lambda θ: np.zeros(9) + 1, prior, n_particles=100, n_simulation=1000)      # s = 9 > SABC_MAX_STATS
+
+
+def test_resample_disabled_and_every_update(S, O, gpu):
+    """`resample` is any positive real (:255): inf never resamples, a tiny value resamples after every update."""
+    n, name = 600, "gauss1_2stats"
+    model, prior = hip_model_prior(S, name)
+    for resample, expect in ((float("inf"), 1), (1e-9, 1 + 9)):
+        res = S.sabc(model, prior, n_particles=n, n_simulation=10 * n, proposal=S.RandomWalk(n_para=1), resample=resample, seed=SEED)
+        run = oracle_run(O, name, n, 10 * n, prop="rw", resample=resample)
+        assert res.state.n_resampling == run.counters["n_resampling"] == expect
+        assert res.state.n_accept == run.counters["n_accept"]
+        np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-9, atol=1e-12)
