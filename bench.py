@@ -181,6 +181,12 @@ def main():
         avg_launch_s = (kern_ms / real_launches) * 1e-3 if launches else float("nan")
         sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
+        valu = None
+        if launches and world == 1:
+            peak = S.op_rng_peak(n_lanes=int(sims_per_launch), pairs_per_lane=max(normals_per_sim // 2, 1), repeats=10, device=device)
+            in_kernel = normals_per_sim * sims_per_launch / avg_launch_s
+            valu = {"bound": "valu", "achieved": in_kernel, "peak": peak, "unit": "normals/s", "frac": in_kernel / peak,
+                    "note": "peak = rate of k_rng_peak (generator only); the rest of k_update is proposal, ECDF search, accept, sums"}
         yb = observed_mean()
         post_var = 1.0 / (1.0 / 4.0 + 100.0)
         analytic = {"analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var} \
@@ -221,6 +227,9 @@ def main():
                         f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; see normals_per_s",
             },
             "normals_per_s": float(normals_per_sim) * K * n / dt,
+            # the bound that actually binds: k_update's in-kernel normal rate against the bare Philox + Box-Muller
+            # loop measured on this GPU right now (same lane count, same pairs per lane, nothing else in the loop)
+            "valu_roofline": valu,
             "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": c["n_resampling"] - resampling0,

@@ -189,6 +189,11 @@ SABC_API int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_
 SABC_API int sabc_op_normal_pairs(int32_t device, uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter,
                                   uint32_t k, int64_t m, double *out_2m);
 
+/* Rate (normals/s) of the bare generator loop -- Philox4x32-10 block + Box-Muller pair, nothing else --
+   on n_lanes lanes: the VALU ceiling of every simulator that draws from it */
+SABC_API int sabc_op_rng_peak(int32_t device, int64_t n_lanes, int32_t pairs_per_lane, int32_t repeats,
+                              double *normals_per_s);
+
 /* ---- measurement ---- */
 enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
        SABC_KERNEL_COUNT = 4 };

@@ -152,6 +152,7 @@ def bind(L, strict=True):
                             C.POINTER(C.c_uint32), dp], C.c_int),
         "sabc_op_normal_pairs": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int64, dp],
                                  C.c_int),
+        "sabc_op_rng_peak": ([C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp], C.c_int),
         "sabc_profile_enable": ([vp, C.c_int32], C.c_int),
         "sabc_profile_get": ([vp, C.c_int32, dp, ip64], C.c_int),
         "sabc_host_syncs": ([vp], C.c_int64),

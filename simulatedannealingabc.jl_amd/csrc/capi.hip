@@ -461,6 +461,32 @@ int sabc_op_normal_pairs(int32_t device, uint64_t seed, uint64_t pid0, uint32_t 
   return 0;
 }
 
+int sabc_op_rng_peak(int32_t device, int64_t n_lanes, int32_t pairs_per_lane, int32_t repeats, double *normals_per_s) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (n_lanes < 1 || pairs_per_lane < 1 || repeats < 1) { g_err = "bad arguments"; return SABC_ERR_BAD_CONFIG; }
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  double *d = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  hipError_t e = hipMalloc((void **)&d, (size_t)n_lanes * 8);
+  if (e == hipSuccess) e = hipEventCreate(&a);
+  if (e == hipSuccess) e = hipEventCreate(&b);
+  if (e == hipSuccess) e = (hipError_t)launch_rng_peak(1, pairs_per_lane, n_lanes, d, nullptr);   // warm-up
+  if (e == hipSuccess) e = hipEventRecord(a, nullptr);
+  for (int r = 0; r < repeats && e == hipSuccess; ++r) e = (hipError_t)launch_rng_peak(2 + r, pairs_per_lane, n_lanes, d, nullptr);
+  if (e == hipSuccess) e = hipEventRecord(b, nullptr);
+  if (e == hipSuccess) e = hipEventSynchronize(b);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  if (a) (void)hipEventDestroy(a);
+  if (b) (void)hipEventDestroy(b);
+  (void)hipFree(d);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  *normals_per_s = 2.0 * (double)pairs_per_lane * (double)n_lanes * (double)repeats / ((double)ms * 1e-3);
+  return 0;
+}
+
 int64_t sabc_host_syncs(const sabc_handle *h) { return h ? h->eng->host_syncs() : 0; }
 
 int sabc_profile_enable(sabc_handle *h, int32_t on) {

@@ -906,6 +906,23 @@ __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, ui
   box_muller(w, normals[0], normals[1]);
 }
 
+// Pure generator loop: `pairs` Philox blocks + Box-Muller pairs per lane, nothing else (one store at the
+// end keeps it alive).  Its rate is the VALU ceiling for any simulator that consumes normals from this
+// generator; bench.py quotes k_update's in-kernel normal rate against it.
+__global__ void __launch_bounds__(kBlock)
+k_rng_peak(const uint64_t seed, const int pairs, const int64_t n, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int k = 0; k < pairs; ++k) {
+    double z0, z1;
+    box_muller(stream_block(seed, (uint64_t)i, PURPOSE_SIM, 0, (uint32_t)k), z0, z1);
+    acc += z0;
+    acc += z1;
+  }
+  out[i] = acc;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1134,6 +1151,12 @@ int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t
                         hipStream_t stream) {
   if (m <= 0) return 0;
   hipLaunchKernelGGL(k_normal_pairs, dim3((unsigned)n_blocks(m)), dim3(kBlock), 0, stream, seed, pid0, purpose, iter, k, m, out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_rng_peak(uint64_t seed, int pairs, int64_t n, double *out, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_rng_peak, dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, seed, pairs, n, out);
   return SABC_LAUNCH_RC();
 }
 

@@ -95,6 +95,7 @@ int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, ui
                           double *rho_out, hipStream_t stream);
 int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,
                         hipStream_t stream);
+int launch_rng_peak(uint64_t seed, int pairs, int64_t n, double *out, hipStream_t stream);
 int launch_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k, uint32_t *words,
                         double *normals, hipStream_t stream);
 

@@ -273,3 +273,12 @@ def rccl_unique_id():
     if rc:
         raise SABCError(rc, _lib.global_error())
     return buf.raw
+
+
+def op_rng_peak(n_lanes=1_000_000, pairs_per_lane=50, repeats=20, device=0):
+    """normals/s of the bare Philox + Box-Muller loop on this GPU (the VALU ceiling of the simulators)."""
+    out = C.c_double()
+    rc = _lib.lib().sabc_op_rng_peak(device, int(n_lanes), int(pairs_per_lane), int(repeats), C.byref(out))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return out.value
