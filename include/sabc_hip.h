@@ -41,8 +41,9 @@ extern "C" {
    as data; definitions in DESIGN.md "Simulators" */
 enum { SABC_MODEL_HOST = 0,   /* f_dist stays a host callable (sabc_set_host_simulator): any d, s within the maxima */
        SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4 };
-/* `prior` argument as data: product of univariate Normal / Uniform */
-enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1 };
+/* `prior` argument as data: product of univariate families (Distributions.jl parametrisation):
+   Normal(mu, sigma), Uniform(a, b), Exponential(theta = scale; second parameter unused), LogNormal(mu, sigma) */
+enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1, SABC_PRIOR_EXPONENTIAL = 2, SABC_PRIOR_LOGNORMAL = 3 };
 /* `proposal` argument (proposals.jl:24 RandomWalk, :85 DifferentialEvolution, :132 StretchMove) */
 enum { SABC_PROP_RANDOMWALK = 0, SABC_PROP_DIFFEVO = 1, SABC_PROP_STRETCH = 2 };
 /* `algorithm` argument (SimulatedAnnealingABC.jl:453,462) */
@@ -81,8 +82,8 @@ typedef struct {
   int32_t n_model_params;
   double  model_params[SABC_MAX_MODEL_PARAMS];
   int32_t prior_kind[SABC_MAX_PARA];
-  double  prior_a[SABC_MAX_PARA]; /* Normal: mu    | Uniform: lower */
-  double  prior_b[SABC_MAX_PARA]; /* Normal: sigma | Uniform: upper */
+  double  prior_a[SABC_MAX_PARA]; /* Normal, LogNormal: mu    | Uniform: lower | Exponential: scale theta */
+  double  prior_b[SABC_MAX_PARA]; /* Normal, LogNormal: sigma | Uniform: upper | Exponential: unused */
   int32_t algorithm;              /* SABC_ALG_* */
   int32_t rank;                   /* this process' shard (0 when world == 1) */
   int32_t world;                  /* number of shards (GPUs) */

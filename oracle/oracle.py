@@ -20,7 +20,7 @@ MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))
-PRIOR_NORMAL, PRIOR_UNIFORM = 0, 1
+PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL = 0, 1, 2, 3
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
 PURPOSE_PRIOR, PURPOSE_SIM, PURPOSE_PROP, PURPOSE_PROP2, PURPOSE_ACCEPT, PURPOSE_RESAMPLE = range(6)

@@ -127,10 +127,13 @@ void orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta) {
     uint32_t w[4];
     orc_stream_block(cfg->seed, pid, ORC_PURPOSE_PRIOR, 0, (uint32_t)k, w);
     double ua = orc_u52(w[0], w[1]);
-    if (cfg->prior_kind[k] == ORC_PRIOR_NORMAL) {
+    if (cfg->prior_kind[k] == ORC_PRIOR_NORMAL || cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL) {
       double ub = orc_u52(w[2], w[3]);
       double z0 = sqrt(-2.0 * log(ua)) * cos(2.0 * ORC_PI * ub);
-      theta[k] = cfg->prior_a[k] + cfg->prior_b[k] * z0;
+      double x = cfg->prior_a[k] + cfg->prior_b[k] * z0;
+      theta[k] = cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL ? exp(x) : x;
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_EXPONENTIAL) {
+      theta[k] = -cfg->prior_a[k] * log(ua);               /* inverse CDF, scale parametrisation */
     } else {
       theta[k] = cfg->prior_a[k] + (cfg->prior_b[k] - cfg->prior_a[k]) * ua;
     }
@@ -144,6 +147,14 @@ double orc_prior_logpdf(const orc_config *cfg, const double *theta) {
     if (cfg->prior_kind[k] == ORC_PRIOR_NORMAL) {
       double z = (x - cfg->prior_a[k]) / cfg->prior_b[k];
       lp += -(z * z + ORC_LOG2PI) / 2.0 - log(cfg->prior_b[k]);
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_EXPONENTIAL) {      /* Distributions.Exponential(theta): support x >= 0 */
+      if (x >= 0.0) lp += -x / cfg->prior_a[k] - log(cfg->prior_a[k]);
+      else return -INFINITY;
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL) {        /* support x > 0 */
+      if (x > 0.0) {
+        double lx = log(x), z = (lx - cfg->prior_a[k]) / cfg->prior_b[k];
+        lp += -(z * z + ORC_LOG2PI) / 2.0 - log(cfg->prior_b[k]) - lx;
+      } else return -INFINITY;
     } else {
       if (x >= cfg->prior_a[k] && x <= cfg->prior_b[k]) lp += -log(cfg->prior_b[k] - cfg->prior_a[k]);
       else return -INFINITY;

@@ -35,7 +35,7 @@ extern "C" {
 /* model ids (device-coded simulators; see DESIGN.md "Simulators") */
 enum { ORC_MODEL_HOST = 0, ORC_MODEL_GAUSS_IID = 1, ORC_MODEL_GAUSS2D = 2, ORC_MODEL_GK = 3, ORC_MODEL_LV = 4 };
 /* prior kinds (per dimension; product distribution) */
-enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1 };
+enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1, ORC_PRIOR_EXPONENTIAL = 2, ORC_PRIOR_LOGNORMAL = 3 };
 /* proposal kinds (proposals.jl:24,85,132) */
 enum { ORC_PROP_RANDOMWALK = 0, ORC_PROP_DIFFEVO = 1, ORC_PROP_STRETCH = 2 };
 /* algorithm (SimulatedAnnealingABC.jl:462) */

@@ -18,7 +18,7 @@ HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 ABI_VERSION = 1
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
-PRIOR_NORMAL, PRIOR_UNIFORM = 0, 1
+PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL = 0, 1, 2, 3
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
 KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT = 0, 1, 2, 3

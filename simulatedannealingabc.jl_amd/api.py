@@ -146,7 +146,9 @@ def as_host_distance(f_dist, prior, args=(), kwargs=None):
     if key in _HOST_WRAPPERS and _HOST_WRAPPERS[key].fn is f_dist:
         return _HOST_WRAPPERS[key]
     rng = np.random.default_rng()
-    θ = np.array([rng.normal(a, b) if k == _lib.PRIOR_NORMAL else rng.uniform(a, b) for k, a, b in prior.descriptors()])
+    draw = {_lib.PRIOR_NORMAL: lambda a, b: rng.normal(a, b), _lib.PRIOR_UNIFORM: lambda a, b: rng.uniform(a, b),
+            _lib.PRIOR_EXPONENTIAL: lambda a, b: rng.exponential(a), _lib.PRIOR_LOGNORMAL: lambda a, b: rng.lognormal(a, b)}
+    θ = np.array([draw[k](a, b) for k, a, b in prior.descriptors()])
     probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
     hd = HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
                       univariate=prior.univariate, args=args, kwargs=kwargs)
@@ -163,7 +165,7 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     if alg not in _ALGORITHMS:                                                # :462-464
         raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
     if not isinstance(prior, Distribution):
-        raise TypeError("prior must be Normal, Uniform or product_distribution([...]) of those")
+        raise TypeError("prior must be Normal, Uniform, Exponential, LogNormal or product_distribution([...]) of those")
     if not isinstance(f_dist, DeviceDistance):
         if not callable(f_dist):
             raise TypeError("f_dist must be a DeviceDistance or a callable f_dist(θ, *args, **kwargs)")

@@ -10,20 +10,42 @@ namespace sabc {
 
 #define SABC_LOG2PI 1.8378770664093454835606594728112
 
-// ---- prior: product of Normal / Uniform (Distributions.logpdf at :314,318) ----
+// ---- prior: product of univariate Normal / Uniform / Exponential / LogNormal ----
+// one dimension of Distributions.logpdf (:314,318); -inf outside the support
+__device__ __forceinline__ double prior_logpdf_1d(int kind, double a, double b, double x) {
+  if (kind == SABC_PRIOR_NORMAL) {
+    const double z = (x - a) / b;
+    return -(z * z + SABC_LOG2PI) / 2.0 - log(b);
+  }
+  if (kind == SABC_PRIOR_UNIFORM) return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
+  if (kind == SABC_PRIOR_EXPONENTIAL) return x >= 0.0 ? -x / a - log(a) : -INFINITY;
+  if (x > 0.0) {                                               // LogNormal(mu = a, sigma = b)
+    const double lx = log(x), z = (lx - a) / b;
+    return -(z * z + SABC_LOG2PI) / 2.0 - log(b) - lx;
+  }
+  return -INFINITY;
+}
+
+// one dimension of rand(prior) (:174) from one Philox block
+__device__ __forceinline__ double prior_sample_1d(int kind, double a, double b, const u32x4 w) {
+  if (kind == SABC_PRIOR_NORMAL || kind == SABC_PRIOR_LOGNORMAL) {
+    double z0, z1;
+    box_muller(w, z0, z1);
+    const double x = a + b * z0;
+    return kind == SABC_PRIOR_LOGNORMAL ? exp(x) : x;
+  }
+  const double ua = u52(w.x, w.y);
+  if (kind == SABC_PRIOR_EXPONENTIAL) return -a * log(ua);
+  return a + (b - a) * ua;
+}
+
 template <int D>
 __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double *th) {
   double lp = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const double x = th[k];
-    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
-      const double z = (x - m.prior_a[k]) / m.prior_b[k];
-      lp += -(z * z + SABC_LOG2PI) / 2.0 - log(m.prior_b[k]);
-    } else {
-      if (x >= m.prior_a[k] && x <= m.prior_b[k]) lp += -log(m.prior_b[k] - m.prior_a[k]);
-      else lp = -INFINITY;
-    }
+    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], th[k]);
+    lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
 }
@@ -32,16 +54,9 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
 template <int D>
 __device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    const u32x4 w = stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k);
-    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
-      double z0, z1;
-      box_muller(w, z0, z1);
-      th[k] = m.prior_a[k] + m.prior_b[k] * z0;
-    } else {
-      th[k] = m.prior_a[k] + (m.prior_b[k] - m.prior_a[k]) * u52(w.x, w.y);
-    }
-  }
+  for (int k = 0; k < D; ++k)
+    th[k] = prior_sample_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k],
+                            stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k));
 }
 
 // ---- empirical CDF: knots T[0..len), ordinates k/(len-1), piecewise linear, flat outside ----

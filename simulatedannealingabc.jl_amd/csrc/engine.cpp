@@ -69,6 +69,10 @@ int Engine::validate() {
       if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Normal prior needs sigma > 0");
     } else if (cfg_.prior_kind[k] == SABC_PRIOR_UNIFORM) {
       if (!(cfg_.prior_b[k] > cfg_.prior_a[k])) return fail(SABC_ERR_BAD_CONFIG, "Uniform prior needs upper > lower");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_EXPONENTIAL) {
+      if (!(cfg_.prior_a[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Exponential prior needs scale > 0");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_LOGNORMAL) {
+      if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "LogNormal prior needs sigma > 0");
     } else {
       return fail(SABC_ERR_BAD_CONFIG, "unknown prior kind");
     }

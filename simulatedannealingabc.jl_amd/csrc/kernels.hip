@@ -400,14 +400,8 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
 __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
   double lp = 0.0;
   for (int k = 0; k < m.d; ++k) {
-    const double x = th[k];
-    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
-      const double z = (x - m.prior_a[k]) / m.prior_b[k];
-      lp += -(z * z + SABC_LOG2PI) / 2.0 - log(m.prior_b[k]);
-    } else {
-      if (x >= m.prior_a[k] && x <= m.prior_b[k]) lp += -log(m.prior_b[k] - m.prior_a[k]);
-      else lp = -INFINITY;
-    }
+    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], th[k]);
+    lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
 }
@@ -417,18 +411,9 @@ __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const 
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= pp.n_local) return;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
-  for (int k = 0; k < m.d; ++k) {
-    const u32x4 w = stream_block(m.seed, gid, PURPOSE_PRIOR, 0, (uint32_t)k);
-    double v;
-    if (m.prior_kind[k] == SABC_PRIOR_NORMAL) {
-      double z0, z1;
-      box_muller(w, z0, z1);
-      v = m.prior_a[k] + m.prior_b[k] * z0;
-    } else {
-      v = m.prior_a[k] + (m.prior_b[k] - m.prior_a[k]) * u52(w.x, w.y);
-    }
-    pp.pop[(int64_t)k * pp.cap + li] = v;
-  }
+  for (int k = 0; k < m.d; ++k)
+    pp.pop[(int64_t)k * pp.cap + li] = prior_sample_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k],
+                                                         stream_block(m.seed, gid, PURPOSE_PRIOR, 0, (uint32_t)k));
 }
 
 // thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor)

@@ -53,13 +53,51 @@ class Uniform(Distribution):
         return f"Uniform(a={self.a}, b={self.b})"
 
 
+class Exponential(Distribution):
+    """Exponential(θ) with scale θ (mean θ), as in Distributions.jl."""
+
+    def __init__(self, θ=1.0):
+        if not θ > 0:
+            raise ValueError("Exponential: the scale θ must be positive")
+        self.θ = float(θ)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_EXPONENTIAL, self.θ, 0.0)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"Exponential(θ={self.θ})"
+
+
+class LogNormal(Distribution):
+    """LogNormal(μ, σ): log of the variable is Normal(μ, σ)."""
+
+    def __init__(self, μ=0.0, σ=1.0):
+        if not σ > 0:
+            raise ValueError("LogNormal: σ must be positive")
+        self.μ, self.σ = float(μ), float(σ)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_LOGNORMAL, self.μ, self.σ)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"LogNormal(μ={self.μ}, σ={self.σ})"
+
+
 class Product(Distribution):
     """`product_distribution([...])` of univariate components (test/runtests.jl:87-88)."""
 
     def __init__(self, components):
         self.components = list(components)
         if not self.components or not all(isinstance(c, Distribution) and c.univariate for c in self.components):
-            raise ValueError("product_distribution needs univariate Normal / Uniform components")
+            raise ValueError("product_distribution needs univariate Normal / Uniform / Exponential / LogNormal components")
         if len(self.components) > _lib.MAX_PARA:
             raise ValueError(f"at most {_lib.MAX_PARA} parameters are supported")
 

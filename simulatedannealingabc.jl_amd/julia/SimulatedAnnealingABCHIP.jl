@@ -9,7 +9,7 @@
 # Python mirror in ../api.py makes exactly the same calls and is what the test-suite drives.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Product, UnivariateDistribution
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Product, UnivariateDistribution
 import Base: show
 
 export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
@@ -145,6 +145,8 @@ end
 # ---- priors as data: Normal, Uniform and products of those ----
 prior_descriptor(d::Normal) = (Int32(0), d.μ, d.σ)
 prior_descriptor(d::Uniform) = (Int32(1), d.a, d.b)
+prior_descriptor(d::Exponential) = (Int32(2), d.θ, 0.0)
+prior_descriptor(d::LogNormal) = (Int32(3), d.μ, d.σ)
 prior_descriptors(d::UnivariateDistribution) = [prior_descriptor(d)]
 prior_descriptors(d::Product) = [prior_descriptor(c) for c in d.v]
 

@@ -26,6 +26,11 @@ MODELS = {
     # test/runtests.jl:163-170
     "gauss2_2stats": dict(model=("GaussianIID", dict(n_obs=10, sd=1.0, obs_mean=0.0, obs_m2=1.0)),
                           prior=[("N", 0.0, 1.0), ("U", 0.0, 2.0)], s=2),
+    # priors beyond the reference's tests: positive scale parameters
+    "gauss2_lognormal_sd": dict(model=("GaussianIID", dict(n_obs=50, sd=1.0, obs_mean=0.5)),
+                                prior=[("N", 0.0, 1.0), ("L", -0.5, 0.5)], s=1),
+    "gauss2_exponential_sd": dict(model=("GaussianIID", dict(n_obs=50, sd=1.0, obs_mean=0.5, obs_m2=1.2)),
+                                  prior=[("U", -2.0, 2.0), ("E", 0.7, 0.0)], s=2),
     # BASELINE config 3
     "gauss2d_cfg3": dict(model=("Gaussian2D", dict(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)),
                          prior=[("N", 0.0, 3.0), ("N", 0.0, 3.0)], s=3),
@@ -60,7 +65,8 @@ def oracle_model_params(O, spec):
 def oracle_config(O, name, n, algorithm="single_eps", seed=SEED, v=1.0, delta=0.1):
     spec = MODELS[name]
     mid, params = oracle_model_params(O, spec)
-    prior = [(O.PRIOR_NORMAL if k == "N" else O.PRIOR_UNIFORM, a, b) for k, a, b in spec["prior"]]
+    kinds = {"N": O.PRIOR_NORMAL, "U": O.PRIOR_UNIFORM, "E": O.PRIOR_EXPONENTIAL, "L": O.PRIOR_LOGNORMAL}
+    prior = [(kinds[k], a, b) for k, a, b in spec["prior"]]
     alg = O.ALG_MULTI_EPS if algorithm == "multi_eps" else O.ALG_SINGLE_EPS
     return O.make_config(n_particles=n, n_para=len(prior), n_stats=spec["s"], model_id=mid, model_params=params,
                          prior=prior, algorithm=alg, v=v, delta=delta, seed=seed)
@@ -87,7 +93,9 @@ def hip_model_prior(S, name):
     spec = MODELS[name]
     kind, kw = spec["model"]
     model = getattr(S, kind)(**kw)
-    comps = [S.Normal(a, b) if k == "N" else S.Uniform(a, b) for k, a, b in spec["prior"]]
+    make = {"N": lambda a, b: S.Normal(a, b), "U": lambda a, b: S.Uniform(a, b), "E": lambda a, b: S.Exponential(a),
+            "L": lambda a, b: S.LogNormal(a, b)}
+    comps = [make[k](a, b) for k, a, b in spec["prior"]]
     prior = comps[0] if len(comps) == 1 else S.product_distribution(comps)
     return model, prior
 

@@ -150,3 +150,20 @@ def test_simulators_are_what_design_md_says(O):
         xs.append(X); ys.append(Y)
     st = [np.mean(xs), np.std(xs, ddof=1), np.mean(ys), np.std(ys, ddof=1)]
     np.testing.assert_allclose(O.simulate(cfg, [a, b, c_], pid, it), np.abs(np.array(st) - kw["obs"]), rtol=1e-10)
+
+
+def test_exponential_and_lognormal_priors_against_scipy(O):
+    """Distributions.jl parametrisation: Exponential(theta = scale), LogNormal(mu, sigma)."""
+    from tests.cases import oracle_config
+    cfg = oracle_config(O, "gauss2_lognormal_sd", 10)
+    for x in (0.05, 0.6, 3.0):
+        assert O.prior_logpdf(cfg, [0.2, x]) == pytest.approx(stats.norm.logpdf(0.2) + stats.lognorm.logpdf(x, s=0.5, scale=math.exp(-0.5)), rel=1e-13)
+    assert O.prior_logpdf(cfg, [0.2, 0.0]) == -math.inf and O.prior_logpdf(cfg, [0.2, -1.0]) == -math.inf
+    th = np.array([O.prior_sample(cfg, i) for i in range(4000)])
+    assert stats.kstest(th[:, 1], "lognorm", args=(0.5, 0, math.exp(-0.5))).pvalue > 1e-3
+    cfg = oracle_config(O, "gauss2_exponential_sd", 10)
+    for x in (0.0, 0.3, 5.0):
+        assert O.prior_logpdf(cfg, [1.0, x]) == pytest.approx(math.log(0.25) + stats.expon.logpdf(x, scale=0.7), rel=1e-13)
+    assert O.prior_logpdf(cfg, [1.0, -1e-9]) == -math.inf and O.prior_logpdf(cfg, [2.5, 1.0]) == -math.inf
+    th = np.array([O.prior_sample(cfg, i) for i in range(4000)])
+    assert stats.kstest(th[:, 1], "expon", args=(0, 0.7)).pvalue > 1e-3 and th[:, 1].min() > 0
