@@ -194,7 +194,7 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     finalizer(r -> (r[] != C_NULL && ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[]); r[] = C_NULL), h)
     if f_dist isa HostDistance
         cb = host_callback(f_dist)
-        HOST_CALLBACKS[h[]] = cb                       # keep the closure alive as long as the handle
+        HOST_CALLBACKS[h[]] = (cb, f_dist)             # keep the closure (and the wrapped model) alive with the handle
         check(h[], ccall((:sabc_set_host_simulator, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], cb, C_NULL))
     end
     h
@@ -269,6 +269,18 @@ function update_population!(res::SABCresult, f_dist::DeviceDistance, prior::Dist
         d == 1 ? (proposal.Σ = Σ[1, 1]) : (proposal.Σ .= Σ)
     end
     refresh!(res, d, s)
+end
+
+# update_population!(res, f_dist, prior, args...; kwargs...) with the plain function the result was created
+# with (SimulatedAnnealingABC.jl:251): look the wrapped model up by handle; args/kwargs go to f_dist (:315)
+function update_population!(res::SABCresult, f_dist::Function, prior::Distribution, args...; kwargs...)
+    f_dist isa DeviceDistance && return invoke(update_population!, Tuple{SABCresult,DeviceDistance,Distribution}, res, f_dist, prior; kwargs...)
+    haskey(HOST_CALLBACKS, res.handle[]) || error("this SABCresult was not created with a host `f_dist`")
+    hd = HOST_CALLBACKS[res.handle[]][2]
+    hd.f === f_dist || error("`f_dist` differs from the one this SABCresult was initialised with")
+    own = (:n_simulation, :v, :δ, :proposal, :resample, :checkpoint_history, :show_progressbar, :show_checkpoint)
+    mine = (; (k => v for (k, v) in kwargs if k in own)...)
+    invoke(update_population!, Tuple{SABCresult,DeviceDistance,Distribution}, res, hd, prior; mine...)
 end
 
 """
