@@ -233,19 +233,32 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
     if resample is None:
         resample = 2 * n_global                                                        # :255
     if show_checkpoint is None:
-        show_checkpoint = math.inf
+        show_checkpoint = math.inf                                                     # quiet by default (the reference logs every 100 when not on a TTY)
     # the reference starts from the arrays held by the result (:264-267): push them to the device
     th = res.population.reshape(1, -1) if res._prior.univariate else np.ascontiguousarray(res.population.T)
     h.set_population(th, np.ascontiguousarray(res.u.T), np.ascontiguousarray(res.ρ.T))
 
     n_pop = n_simulation // n_global                                                   # :275
+    # Progress output needs the loop to come up for air: the call is split into chunks that are multiples
+    # of checkpoint_history, which leaves counters, histories and particles exactly as in one call.
+    if show_progressbar is None:
+        show_progressbar = not is_logging(sys.stderr)                                  # :257
+    cph = max(int(checkpoint_history), 1)
     chunk = n_pop
     if math.isfinite(show_checkpoint) and show_checkpoint >= 1:
         k = int(show_checkpoint)
-        if k % max(int(checkpoint_history), 1) == 0:
+        if k % cph == 0:
             chunk = k
         else:
             warnings.warn("show_checkpoint is not a multiple of checkpoint_history; progress lines are disabled")
+    pbar = None
+    if show_progressbar and n_pop > 0:
+        try:
+            from tqdm import tqdm
+            pbar = tqdm(total=n_pop, desc=f"{n_pop} population updates:", file=sys.stderr)   # :290-291
+            chunk = min(chunk, max(cph, (n_pop // 50) // cph * cph))
+        except ImportError:
+            pbar = None
     done, t0 = 0, time.time()
     while True:
         todo = min(chunk, n_pop - done) if n_pop > 0 else 0
@@ -253,10 +266,16 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         h.update(n_simulation=budget, proposal=proposal, v=v, delta=δ, resample=resample,
                  checkpoint_history=checkpoint_history)
         done += todo
+        if pbar is not None:
+            pbar.update(todo)
+            pbar.set_postfix_str(f"ϵ={np.array2string(h.eps, precision=4)}")                  # :292,374
         if done >= n_pop:
             break
-        eta = (time.time() - t0) / done * (n_pop - done)                              # :359-364
-        log.info("Update %d of %d. ϵ: %s, ETA: %.0f s", done, n_pop, np.array2string(h.eps, precision=4), eta)
+        if math.isfinite(show_checkpoint) and done % int(show_checkpoint) == 0:
+            eta = (time.time() - t0) / done * (n_pop - done)                              # :359-364
+            log.info("Update %d of %d. ϵ: %s, ETA: %.0f s", done, n_pop, np.array2string(h.eps, precision=4), eta)
+    if pbar is not None:
+        pbar.close()
     if isinstance(proposal, RandomWalk):
         sg = h.proposal_sigma
         proposal.Σ = float(sg[0, 0]) if len(prior) == 1 else sg                       # rw.Σ, proposals.jl:47,59

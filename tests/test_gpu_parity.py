@@ -223,6 +223,9 @@ def test_show_checkpoint_chunking_keeps_the_history(S, gpu, caplog):
     assert len(a.state.ϵ_history) == len(b.state.ϵ_history) == 1 + 6
     np.testing.assert_allclose(b.population, a.population, rtol=1e-12)
     assert a.state.n_accept == b.state.n_accept
+    c = S.sabc(model, prior, show_progressbar=True, **kw)            # ProgressMeter bar (:290-292,374): chunks only
+    assert len(c.state.ϵ_history) == 1 + 6 and c.state.n_accept == a.state.n_accept
+    np.testing.assert_allclose(c.population, a.population, rtol=1e-12)
 
 
 def test_effective_sample_size(S, O, gpu):
