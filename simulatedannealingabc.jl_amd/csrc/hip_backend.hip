@@ -307,9 +307,15 @@ int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t l
     err_ = "update_range: range outside the shard";
     return -1;
   }
-  prof_begin(SABC_KERNEL_UPDATE);
-  HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_), "k_update");
-  prof_end(SABC_KERNEL_UPDATE);
+  // the timing events ride on the kernel's own dispatch packet (no marker packets around it)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof_) {
+    EvPair e{nullptr, nullptr};
+    if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); }
+    else if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) e = EvPair{nullptr, nullptr};
+    if (e.a && e.b) { ev_[SABC_KERNEL_UPDATE].push_back(e); ev0 = e.a; ev1 = e.b; }
+  }
+  HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_, ev0, ev1), "k_update");
   *rows_out = rows;
   return 0;
 }

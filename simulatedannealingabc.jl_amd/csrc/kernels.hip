@@ -11,6 +11,7 @@
 //    wave shuffles -> LDS across the 4 waves of a block -> one partial row per block, summed
 //    later in a fixed order (bitwise reproducible for a given grid).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include "control.hpp"
 #include "device_models.hpp"
 #include "kernels.hpp"
@@ -967,23 +968,31 @@ int64_t update_rows(const ModelDesc &m, int64_t act_n) {
                                      : n_blocks(act_n);            // 256 particles per workgroup
 }
 
+// ev0 / ev1 (optional): timing events attached to the dispatch packet itself (hipExtLaunchKernel), so that
+// measuring the kernel does not put separate marker packets into the queue
+#define SABC_LAUNCH_UPDATE(KERNEL, GRID)                                                                         \
+  do {                                                                                                           \
+    if (ev0) hipExtLaunchKernelGGL((KERNEL), (GRID), block, 0, stream, ev0, ev1, 0, m, c, cb, pp, cdf, pv, act_lo, act_n, out); \
+    else hipLaunchKernelGGL((KERNEL), (GRID), block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out);      \
+  } while (0)
+
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
-                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream) {
+                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream, hipEvent_t ev0,
+                  hipEvent_t ev1) {
   if (act_n <= 0) return 0;
   const dim3 grid((unsigned)update_rows(m, act_n)), block(kBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
   if (m.model_id == SABC_MODEL_GK) {
     const dim3 g((unsigned)update_rows(m, act_n));
     switch (c.prop_kind) {
-      case SABC_PROP_RANDOMWALK: hipLaunchKernelGGL((k_update_gk<SABC_PROP_RANDOMWALK>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
-      case SABC_PROP_DIFFEVO: hipLaunchKernelGGL((k_update_gk<SABC_PROP_DIFFEVO>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
-      case SABC_PROP_STRETCH: hipLaunchKernelGGL((k_update_gk<SABC_PROP_STRETCH>), g, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out); break;
+      case SABC_PROP_RANDOMWALK: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_RANDOMWALK>), g); break;
+      case SABC_PROP_DIFFEVO: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_DIFFEVO>), g); break;
+      case SABC_PROP_STRETCH: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_STRETCH>), g); break;
       default: return (int)hipErrorInvalidValue;
     }
     return SABC_LAUNCH_RC();
   }
-#define CALLP(M, D, S, P) \
-  hipLaunchKernelGGL((k_update<M, D, S, P>), grid, block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out)
+#define CALLP(M, D, S, P) SABC_LAUNCH_UPDATE((k_update<M, D, S, P>), grid)
 #define CALL(M, D, S)                                                           \
   switch (c.prop_kind) {                                                        \
     case SABC_PROP_RANDOMWALK: CALLP(M, D, S, SABC_PROP_RANDOMWALK); break;     \

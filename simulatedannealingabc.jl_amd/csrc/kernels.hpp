@@ -42,8 +42,10 @@ int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
 int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
 // K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
 // writes one partial row per block at partials[(row0 + blockIdx) * np]
+// ev0 / ev1: optional timing events carried by the kernel's own dispatch packet
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
-                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream);
+                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
+                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // number of partial rows launch_update() writes for act_n particles (depends on the kernel's granularity)
 int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0

@@ -80,3 +80,27 @@ def test_cfg3_multistat_fullsize(S, O, gpu):
         np.testing.assert_allclose(m, run.theta.mean(1), rtol=1e-9)
         np.testing.assert_allclose(res.population.var(0), run.theta.var(1), rtol=1e-9)
         np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=1e-9)
+
+
+@pytest.mark.parametrize("prop,updates", [("rw", 300), ("de", 40)])
+def test_long_run_soak(S, O, gpu, prop, updates):
+    """Hundreds of population updates with many in-loop resamples through the queued-ahead loop (device-side
+    resample test, halt flag, aborted launches, mailbox ring): accept and resample counts stay identical to
+    the oracle's and the particles stay on the same trajectory."""
+    from tests.cases import hip_proposal
+    n, name = 100_000, "gauss1_2stats"
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=(updates + 1) * n, algorithm="multi_eps",
+                 proposal=hip_proposal(S, prop, 1), resample=n // 3, seed=SEED, checkpoint_history=7)
+    O.set_threads(16)
+    run = oracle_run(O, name, n, (updates + 1) * n, algorithm="multi_eps", prop=prop, resample=n // 3, checkpoint_history=7)
+    O.set_threads(1)
+    c = run.counters
+    assert (res.state.n_accept, res.state.n_resampling, res.state.n_population_updates) == \
+        (c["n_accept"], c["n_resampling"], updates)
+    assert res.state.n_resampling > (12 if prop == "rw" else 5)
+    assert len(res.state.ϵ_history) == run.history[0].shape[0] == 1 + updates // 7 + (1 if updates % 7 else 0)
+    tol = 1e-7 if prop == "rw" else 1e-4        # DE compounds differences by ~(1 + 2 gamma) per update
+    np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+    np.testing.assert_allclose(np.array(res.state.ϵ_history), run.history[0], rtol=tol)
+    np.testing.assert_allclose(res.population, run.theta[0], rtol=tol, atol=tol)
