@@ -70,7 +70,7 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
 //     + fused block partials.   SimulatedAnnealingABC.jl:308-331
 // ------------------------------------------------------------------------------------------
 template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 4)
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
