@@ -203,20 +203,17 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   __shared__ GkStage stage[kBlock / 64];
   __shared__ double red[kBlock / 64][NP];
-  __shared__ double term_lds[kBlock / 64][NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GkStage &st = stage[wave];
-  double acc = 0.0;                                     // lane q < NP accumulates component q
   const int64_t t0 = (int64_t)blockIdx.x * kGkPerBlock + wave * PW;
+  // the wave owns particles t0 .. t0+PW-1; in the scalar phases (1a, 3) lane i < PW handles particle t0+i
+  const int64_t t_mine = t0 + lane;
+  const bool mine = lane < PW && t_mine < act_n;
+  const int64_t li = act_lo + t_mine;
+  const uint64_t gid = (uint64_t)(pp.gid0 + li);
 
-  // ---- phase 1: proposal (:311), prior gate (:314), simulate (:315); scalar work is done by all
-  //      lanes redundantly (same counters, same values), the 128 draws and their sort are spread
-  //      over the lanes
-  for (int it = 0; it < PW; ++it) {
-    const int64_t t = t0 + it;
-    if (t >= act_n) break;                              // uniform over the wave
-    const int64_t li = act_lo + t;
-    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  // ---- phase 1a, lane-parallel over the wave's particles: proposal (:311) and prior gate (:314)
+  if (mine) {
     double th[D], thp[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
@@ -262,25 +259,31 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
       }
       logf = log(z) * (double)(D - 1);
     }
-    const double lpp = prior_logpdf<D>(m, thp);
-    double rp[S];
 #pragma unroll
-    for (int j = 0; j < S; ++j) rp[j] = 0.0;
-    if (lpp > -INFINITY) gk_simulate_wave<S>(m, thp, gid, c.iter, rp);
+    for (int k = 0; k < D; ++k) st.thp[lane][k] = thp[k];
+    st.lpp[lane] = prior_logpdf<D>(m, thp);
+    st.logf[lane] = logf;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- phase 1b, one particle at a time with the whole wave: simulate (:315); lane l draws 2 of the 128
+  for (int it = 0; it < PW; ++it) {
+    if (t0 + it >= act_n) break;                       // uniform over the wave
+    if (!(st.lpp[it] > -INFINITY)) continue;           // outside the prior's support: not simulated (:314)
+    double thp[D], rp[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
+    gk_simulate_wave<S>(m, thp, (uint64_t)(pp.gid0 + act_lo + t0 + it), c.iter, rp);
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) st.thp[it][k] = thp[k];
-#pragma unroll
       for (int j = 0; j < S; ++j) st.rp[it][j] = rp[j];
-      st.lpp[it] = lpp;
-      st.logf[it] = logf;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase 2: all 16 x 4 ECDF lookups of the wave at once, one per lane (:316); the 20-step
-  //      dependent search is paid once per 16 particles instead of once per particle
+  // ---- phase 2: all 16 x 4 ECDF lookups of the wave at once, one per lane (:316)
   {
     const int it = lane >> 2, j = lane & 3;
     double upv = 0.0;
@@ -296,23 +299,22 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase 3: acceptance (:318-329) and the fused sums; lane q < NP accumulates component q
-  for (int it = 0; it < PW; ++it) {
-    const int64_t t = t0 + it;
-    if (t >= act_n) break;
-    const int64_t li = act_lo + t;
-    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  // ---- phase 3, lane-parallel again: acceptance (:318-329), store, and the particle's moment terms
+  double term[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) term[q] = 0.0;
+  if (mine) {
     double th[D], u[S], rho[S], thp[D], up[S], rp[S];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = pp.pop[(int64_t)k * pp.cap + li]; thp[k] = st.thp[it][k]; }
+    for (int k = 0; k < D; ++k) { th[k] = pp.pop[(int64_t)k * pp.cap + li]; thp[k] = st.thp[lane][k]; }
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
       rho[j] = pp.rho[(int64_t)j * pp.cap + li];
-      up[j] = st.up[it][j];
-      rp[j] = st.rp[it][j];
+      up[j] = st.up[lane][j];
+      rp[j] = st.rp[lane][j];
     }
-    const double lpp = st.lpp[it];
+    const double lpp = st.lpp[lane];
     double log_accept = -INFINITY;
     if (lpp > -INFINITY) {
       double a = 0.0;
@@ -321,39 +323,30 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (u[j] - up[j]) / e;
       }
-      log_accept = lpp - prior_logpdf<D>(m, th) + a + st.logf[it];
+      log_accept = lpp - prior_logpdf<D>(m, th) + a + st.logf[lane];
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
     const bool accepted = log(u52(wa.x, wa.y)) < log_accept;
     if (accepted) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) th[k] = thp[k];
+      for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
 #pragma unroll
-      for (int j = 0; j < S; ++j) { u[j] = up[j]; rho[j] = rp[j]; }
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) pp.pop[(int64_t)k * pp.cap + li] = thp[k];
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-          pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
-          pp.rho[(int64_t)j * pp.cap + li] = rp[j];
-        }
+      for (int j = 0; j < S; ++j) {
+        u[j] = up[j]; rho[j] = rp[j];
+        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
       }
     }
-    {
-      double term[NP];
-      moment_terms<D, S>(cb->pivot, accepted, th, u, rho, term);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) term_lds[wave][q] = term[q];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (lane < NP) acc += term_lds[wave][lane];
-    }
+    moment_terms<D, S>(cb->pivot, accepted, th, u, rho, term);
   }
-  if (lane < NP) red[wave][lane] = acc;
+  // sum the moment terms over the wave's 16 particle lanes (lanes >= 16 hold zeros), then over the 4 waves
+#pragma unroll
+  for (int q = 0; q < NP; ++q) {
+    double v = term[q];
+#pragma unroll
+    for (int off = PW / 2; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][q] = v;
+  }
   __syncthreads();
   if (threadIdx.x < NP) {
     const int q = threadIdx.x;
