@@ -12,16 +12,18 @@ namespace sabc {
 
 // ---- prior: product of univariate Normal / Uniform / Exponential / LogNormal ----
 // one dimension of Distributions.logpdf (:314,318); -inf outside the support
-__device__ __forceinline__ double prior_logpdf_1d(int kind, double a, double b, double x) {
+// lc = the log of the family's scale constant, computed once on the host (ModelDesc::prior_logc):
+// log(sigma), log(b - a), log(theta)
+__device__ __forceinline__ double prior_logpdf_1d(int kind, double a, double b, double lc, double x) {
   if (kind == SABC_PRIOR_NORMAL) {
     const double z = (x - a) / b;
-    return -(z * z + SABC_LOG2PI) / 2.0 - log(b);
+    return -(z * z + SABC_LOG2PI) / 2.0 - lc;
   }
-  if (kind == SABC_PRIOR_UNIFORM) return (x >= a && x <= b) ? -log(b - a) : -INFINITY;
-  if (kind == SABC_PRIOR_EXPONENTIAL) return x >= 0.0 ? -x / a - log(a) : -INFINITY;
+  if (kind == SABC_PRIOR_UNIFORM) return (x >= a && x <= b) ? -lc : -INFINITY;
+  if (kind == SABC_PRIOR_EXPONENTIAL) return x >= 0.0 ? -x / a - lc : -INFINITY;
   if (x > 0.0) {                                               // LogNormal(mu = a, sigma = b)
     const double lx = log(x), z = (lx - a) / b;
-    return -(z * z + SABC_LOG2PI) / 2.0 - log(b) - lx;
+    return -(z * z + SABC_LOG2PI) / 2.0 - lc - lx;
   }
   return -INFINITY;
 }
@@ -44,7 +46,7 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
   double lp = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], th[k]);
+    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], m.prior_logc[k], th[k]);
     lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
@@ -178,8 +180,8 @@ constexpr int kGkParticlesPerWave = 16;
 // (1 + z^2)^k as exp(k log(1 + z^2)): the argument of the log is >= 1 and normal, so the
 // range-specialised log of device_rng.hpp applies (relative error ~ k log(1+z^2) * 2e-16)
 __device__ __forceinline__ double gk_quantile(const double *th, double c, double z) {
-  const double w = exp(th[3] * log_fast(fma(z, z, 1.0)));
-  return th[0] + th[1] * (1.0 + c * tanh(th[2] * z / 2.0)) * w * z;
+  const double w = exp_fast(th[3] * log_fast(fma(z, z, 1.0)));
+  return th[0] + th[1] * (1.0 + c * tanh_abs(th[2] * z / 2.0)) * w * z;
 }
 
 template <int S>

@@ -99,6 +99,38 @@ __device__ __forceinline__ double log_fast(double x) {
   return fma(dk, 6.93147180369123816490e-01, (fma(s, hfsq + R, dk * 1.90821492927058770002e-10) - hfsq) + f);
 }
 
+// exp(x) for |x| <= 700: n = rint(x / ln 2), r = x - n ln 2 in two pieces, Taylor polynomial of degree 13
+// on |r| <= ln(2)/2 (remainder 4e-18), scaled by 2^n with v_ldexp_f64.  ~1 ulp.
+__device__ __forceinline__ double exp_fast(double x) {
+  x = fmin(fmax(x, -700.0), 700.0);
+  const double n = rint(x * 1.44269504088896338700e+00);
+  double r = fma(-n, 6.93147180369123816490e-01, x);
+  r = fma(-n, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// tanh(y) = sign(y) (1 - 2 / (exp(2|y|) + 1)): absolute error ~1e-16 (the relative error near 0 is not
+// controlled, which is fine where it is used: inside 1 + c tanh(.))
+__device__ __forceinline__ double tanh_abs(double y) {
+  const double a = fmin(fabs(y), 20.0);
+  const double t = 1.0 - div_fast(2.0, exp_fast(2.0 * a) + 1.0);
+  return copysign(t, y);
+}
+
 // sin and cos of 2 pi u for u in (0,1): quadrant k = rint(4u) and r = 4u - k are exact; the two
 // Taylor polynomials run on a = (pi/2) r, |a| <= pi/4
 __device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {

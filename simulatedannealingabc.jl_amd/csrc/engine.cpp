@@ -21,6 +21,9 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
     m_.prior_kind[k] = cfg.prior_kind[k];
     m_.prior_a[k] = cfg.prior_a[k];
     m_.prior_b[k] = cfg.prior_b[k];
+    const double scale = cfg.prior_kind[k] == SABC_PRIOR_UNIFORM ? cfg.prior_b[k] - cfg.prior_a[k]
+                         : cfg.prior_kind[k] == SABC_PRIOR_EXPONENTIAL ? cfg.prior_a[k] : cfg.prior_b[k];
+    m_.prior_logc[k] = scale > 0 ? std::log(scale) : 0.0;
   }
   m_.seed = cfg.seed;
   const int world = cfg.world < 1 ? 1 : cfg.world;

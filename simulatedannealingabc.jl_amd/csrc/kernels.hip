@@ -160,7 +160,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
 
     // ---- accept / store (:324-329) ----
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = log(u52(wa.x, wa.y)) < log_accept;
+    const bool accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
     if (accepted) {
 #pragma unroll
       for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
@@ -326,7 +326,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
       log_accept = lpp - prior_logpdf<D>(m, th) + a + st.logf[lane];
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = log(u52(wa.x, wa.y)) < log_accept;
+    const bool accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
     if (accepted) {
 #pragma unroll
       for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
@@ -394,7 +394,7 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
 __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
   double lp = 0.0;
   for (int k = 0; k < m.d; ++k) {
-    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], th[k]);
+    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], m.prior_logc[k], th[k]);
     lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
@@ -490,7 +490,7 @@ k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restric
       log_accept = lpp - prior_logpdf_rt(m, th) + a + logf;
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    accepted = log(u52(wa.x, wa.y)) < log_accept;
+    accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
     if (accepted) {
       for (int k = 0; k < d; ++k) pp.pop[(int64_t)k * pp.cap + li] = thp_in[(int64_t)k * act_n + t];
       for (int j = 0; j < s; ++j) {

@@ -15,6 +15,7 @@ struct ModelDesc {
   double p[SABC_MAX_MODEL_PARAMS];
   int32_t prior_kind[kMaxPara];
   double prior_a[kMaxPara], prior_b[kMaxPara];
+  double prior_logc[kMaxPara];   // log sigma | log(b - a) | log theta: the scale constant of logpdf, once on the host
   uint64_t seed;
 };
 
