@@ -184,6 +184,55 @@ __device__ __forceinline__ double gk_quantile(const double *th, double c, double
   return th[0] + th[1] * (1.0 + c * tanh_abs(th[2] * z / 2.0)) * w * z;
 }
 
+// v from lane ^ DIST, DIST a compile-time power of two: DPP quad_perm for 1 and 2 (register crossbar, no
+// LDS hardware, no address VGPR), ds_swizzle bit-mask mode for 4, 8, 16 (no address VGPR), ds_bpermute for 32
+template <int DIST>
+__device__ __forceinline__ double xor_lane(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (DIST == 1) {
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+  } else if constexpr (DIST == 2) {
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+  } else if constexpr (DIST <= 16) {
+    constexpr int pattern = 0x1F | (DIST << 10);                        // and_mask 0x1f, or 0, xor DIST
+    lo = __builtin_amdgcn_ds_swizzle(lo, pattern);
+    hi = __builtin_amdgcn_ds_swizzle(hi, pattern);
+  } else {
+    return __shfl_xor(v, DIST, 64);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step(int lane, double &v0, double &v1) {
+  const bool up = ((2 * lane) & K) == 0;               // K = 128: always ascending
+  if constexpr (J == 1) {
+    const double lo = fmin(v0, v1), hi = fmax(v0, v1);
+    v0 = up ? lo : hi;
+    v1 = up ? hi : lo;
+  } else {
+    constexpr int dist = J >> 1;
+    const double p0 = xor_lane<dist>(v0), p1 = xor_lane<dist>(v1);
+    const bool keep_min = ((lane & dist) == 0) == up;
+    v0 = keep_min ? fmin(v0, p0) : fmax(v0, p0);
+    v1 = keep_min ? fmin(v1, p1) : fmax(v1, p1);
+  }
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge(int lane, double &v0, double &v1) {
+  bitonic_step<K, J>(lane, v0, v1);
+  if constexpr (J > 1) bitonic_merge<K, J / 2>(lane, v0, v1);
+}
+
+template <int K>
+__device__ __forceinline__ void bitonic_sort128(int lane, double &v0, double &v1) {
+  if constexpr (K > 2) bitonic_sort128<K / 2>(lane, v0, v1);
+  bitonic_merge<K, K / 2>(lane, v0, v1);
+}
+
 template <int S>
 __device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
                                                  double *rho) {
@@ -198,24 +247,7 @@ __device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const doubl
   // bitonic sorting network over the 128 values, two per lane (element index = 2*lane + slot):
   // 28 compare-exchange steps, 7 of them inside the lane, 21 with the lane at distance j/2
   double v0 = a, v1 = b;
-#pragma unroll
-  for (int k = 2; k <= kGkMaxDraws; k <<= 1) {
-    const bool up = ((2 * lane) & k) == 0;              // k = 128: always ascending
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j == 1) {
-        const double lo = fmin(v0, v1), hi = fmax(v0, v1);
-        v0 = up ? lo : hi;
-        v1 = up ? hi : lo;
-      } else {
-        const int dist = j >> 1;
-        const double p0 = __shfl_xor(v0, dist, 64), p1 = __shfl_xor(v1, dist, 64);
-        const bool keep_min = ((lane & dist) == 0) == up;
-        v0 = keep_min ? fmin(v0, p0) : fmax(v0, p0);
-        v1 = keep_min ? fmin(v1, p1) : fmax(v1, p1);
-      }
-    }
-  }
+  bitonic_sort128<kGkMaxDraws>(lane, v0, v1);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
