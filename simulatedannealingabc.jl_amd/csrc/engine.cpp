@@ -372,9 +372,18 @@ int Engine::update(const sabc_update_args &a) {
   const int kDepth = host_mode_ ? 1 : kMaxDepth;     // a host simulator leaves nothing to queue ahead
   int64_t seqs[kMaxDepth + 1] = {0};
   int64_t next_enqueue = 1, next_confirm = 1;
+  int64_t known_accept = cb_.n_accept, last_delta = 0;   // as of the last confirmed update
   auto hist_flag = [&](int64_t ix) { return (cph > 0 && ix % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };
+  // Queueing ahead of an update that then triggers the resample costs three no-op launches; the accept
+  // count moves slowly from one update to the next, so the host only queues ahead when the update in
+  // flight is not expected to reach the threshold (a wrong guess costs one ~10 us gap, never correctness).
+  auto resample_expected = [&]() {
+    const double threshold = (double)(n_resampling_ + 1) * a.resample;
+    return (double)known_accept + 1.25 * (double)last_delta >= threshold;
+  };
   while (next_confirm <= n_pop) {                                           // :294
-    while (next_enqueue <= n_pop && next_enqueue - next_confirm < kDepth) {
+    while (next_enqueue <= n_pop && next_enqueue - next_confirm < kDepth &&
+           (next_enqueue == next_confirm || !resample_expected())) {
       const int64_t ix = next_enqueue;
       if ((rc = enqueue_update(a, (uint64_t)(n_population_updates_ + ix), /*guarded=*/true))) return rc;
       const double threshold = (double)(n_resampling_ + 1) * a.resample;    // :340
@@ -387,6 +396,8 @@ int Engine::update(const sabc_update_args &a) {
     int64_t n_accept_now = 0;
     int halted = 0;
     if ((rc = wait_step(seqs[ix % (kMaxDepth + 1)], &n_accept_now, &halted))) return rc;
+    last_delta = n_accept_now - known_accept;
+    known_accept = n_accept_now;
     if (halted) {
       // n_accept >= (n_resampling + 1) * resample after update ix (:340): resample, then the part of
       // the control step that was skipped; updates queued behind ix were no-ops and are enqueued again
