@@ -85,9 +85,10 @@ void orc_stream_block(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t it
   orc_philox4x32_10(key, ctr, out);
 }
 
-/* 52-bit uniform in (0,1): (x + 1/2) * 2^-52 is exact in binary64 */
+/* 52-bit uniform in (0,1): x = (low 20 bits of `hi`) : (all 32 bits of `lo`); (x + 1/2) * 2^-52 is exact
+   in binary64.  (These are the 52 bits that drop into a double's mantissa without a shift.) */
 double orc_u52(uint32_t hi, uint32_t lo) {
-  uint64_t x = (((uint64_t)hi << 32) | lo) >> 12;
+  uint64_t x = ((uint64_t)(hi & 0xFFFFFu) << 32) | lo;
   return ((double)x + 0.5) * 0x1.0p-52;
 }
 

@@ -41,12 +41,12 @@ __device__ __forceinline__ u32x4 stream_block(uint64_t seed, uint64_t pid, uint3
   return philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)pid, k, (uint32_t)iter, c3);
 }
 
-// (x + 1/2) * 2^-52 with x the top 52 bits of the 64-bit word: exact in binary64, in (0,1).
-// Built without an int->fp conversion: the 52 bits become the mantissa of a double in [1,2) and
-// (1 - 2^-53) is subtracted, which is exact ((x + 1/2) 2^-52 is representable).
+// (x + 1/2) * 2^-52 with x = (low 20 bits of hi):(all of lo): exact in binary64, in (0,1).
+// Built without a shift or an int->fp conversion: those 52 bits ARE the mantissa of a double in [1,2)
+// (one v_and_or on the high word), and (1 - 2^-53) is subtracted, which is exact.
 __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
-  const uint64_t x = (((uint64_t)hi << 32) | lo) >> 12;
-  return __longlong_as_double((long long)(0x3FF0000000000000ull | x)) - 0x1.fffffffffffffp-1;
+  const double d = __hiloint2double((int)(0x3FF00000u | (hi & 0xFFFFFu)), (int)lo);
+  return d - 0x1.fffffffffffffp-1;
 }
 
 __device__ __forceinline__ uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }

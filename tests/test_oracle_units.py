@@ -21,7 +21,8 @@ def test_philox_known_answers(O):
 def test_uniform_open_interval_and_exact(O):
     assert O.lib().orc_u52(0, 0) == 2.0 ** -53
     assert O.lib().orc_u52(0xFFFFFFFF, 0xFFFFFFFF) == 1.0 - 2.0 ** -53
-    assert O.lib().orc_u52(0x80000000, 0) == 0.5 + 2.0 ** -53
+    assert O.lib().orc_u52(0x00080000, 0) == 0.5 + 2.0 ** -53        # mantissa = low 20 bits of hi : lo
+    assert O.lib().orc_u52(0xFFF00000, 0) == 2.0 ** -53              # the top 12 bits of hi are not used
 
 
 def test_normal_stream_moments(O):
