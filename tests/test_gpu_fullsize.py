@@ -104,3 +104,35 @@ def test_long_run_soak(S, O, gpu, prop, updates):
     np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
     np.testing.assert_allclose(np.array(res.state.ϵ_history), run.history[0], rtol=tol)
     np.testing.assert_allclose(res.population, run.theta[0], rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("name,n,alg,prop,updates", [
+    ("gk_cfg4", 4_000_000, "multi_eps", "de", 4),       # BASELINE config 4 at its full size, the reference's default proposal
+    ("lv_cfg5", 1_000_000, "single_eps", "rw", 4),      # BASELINE config 5
+])
+def test_cfg4_cfg5_fullsize_against_cpu_run(S, O, gpu, name, n, alg, prop, updates):
+    """g-and-k (wave-per-particle kernel, 128-value bitonic sort) and Lotka-Volterra (256 Euler-Maruyama steps)
+    at BASELINE.json's particle counts: counters identical to the CPU run, state within the proposal's tolerance,
+    and the size-independent invariants."""
+    from tests.cases import hip_proposal, MODELS
+    d = len(MODELS[name]["prior"])
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=(updates + 1) * n, algorithm=alg,
+                 proposal=hip_proposal(S, prop, d), seed=SEED)
+    st = res.state
+    assert st.n_population_updates == updates and st.n_simulation == (updates + 1) * n
+    assert res.population.shape == (n, d) and np.all(np.isfinite(res.population))
+    assert np.all((res.u >= 0) & (res.u <= 1)) and np.all(res.ρ >= 0) and np.all(np.isfinite(res.ρ))
+    for j in range(res.u.shape[1]):
+        kn = st.cdfs_dist_prior.knots(j)
+        assert kn[0] == 0.0 and np.all(np.diff(kn) >= 0) and kn[-1] == 1.5 * kn[-2]
+    O.set_threads(16)
+    run = oracle_run(O, name, n, (updates + 1) * n, algorithm=alg, prop=prop)
+    O.set_threads(1)
+    assert (st.n_accept, st.n_resampling) == (run.counters["n_accept"], run.counters["n_resampling"])
+    tol = 1e-9 if prop == "rw" else 1e-6
+    np.testing.assert_allclose(st.ϵ, run.eps, rtol=tol)
+    # rho = |summary - observed|: the subtraction cancels, so the bound is absolute (summaries are O(10))
+    np.testing.assert_allclose(res.ρ, run.rho.T, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(res.population.mean(0), run.theta.mean(1), rtol=tol)
+    np.testing.assert_allclose(res.population.var(0), run.theta.var(1), rtol=tol)
