@@ -185,16 +185,18 @@ __device__ __forceinline__ double gk_quantile(const double *th, double c, double
 }
 
 // v from lane ^ DIST, DIST a compile-time power of two: DPP quad_perm for 1 and 2 (register crossbar, no
-// LDS hardware, no address VGPR), ds_swizzle bit-mask mode for 4, 8, 16 (no address VGPR), ds_bpermute for 32
+// LDS hardware, no address VGPR), ds_swizzle bit-mask mode for 4, 8, 16 (no address VGPR), ds_bpermute for 32.
+// Measured on cfg4 (k_update_gk, n = 1e6): everything through ds_swizzle 910 us; DPP for 1, 2 (this) 863 us;
+// DPP also for 4 (half_mirror + quad_perm) and 8 (row_ror:8) 871 us.
 template <int DIST>
 __device__ __forceinline__ double xor_lane(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   if constexpr (DIST == 1) {
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);           // quad_perm [1,0,3,2]; every lane is written
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
   } else if constexpr (DIST == 2) {
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true);           // quad_perm [2,3,0,1]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true);
   } else if constexpr (DIST <= 16) {
     constexpr int pattern = 0x1F | (DIST << 10);                        // and_mask 0x1f, or 0, xor DIST
     lo = __builtin_amdgcn_ds_swizzle(lo, pattern);
@@ -205,19 +207,23 @@ __device__ __forceinline__ double xor_lane(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// One compare-exchange step of the bitonic network.  Written with a compare and selects instead of
+// fmin / fmax: the values are never NaN, and min/max would each be preceded by a canonicalising
+// v_max_f64 x, x (a third of the sort's instructions).  Equal values may be taken from either side.
 template <int K, int J>
 __device__ __forceinline__ void bitonic_step(int lane, double &v0, double &v1) {
   const bool up = ((2 * lane) & K) == 0;               // K = 128: always ascending
   if constexpr (J == 1) {
-    const double lo = fmin(v0, v1), hi = fmax(v0, v1);
-    v0 = up ? lo : hi;
-    v1 = up ? hi : lo;
+    const bool swap = (v0 > v1) == up;                 // the lane's own pair is out of order for this direction
+    const double a = swap ? v1 : v0, b = swap ? v0 : v1;
+    v0 = a; v1 = b;
   } else {
     constexpr int dist = J >> 1;
     const double p0 = xor_lane<dist>(v0), p1 = xor_lane<dist>(v1);
     const bool keep_min = ((lane & dist) == 0) == up;
-    v0 = keep_min ? fmin(v0, p0) : fmax(v0, p0);
-    v1 = keep_min ? fmin(v1, p1) : fmax(v1, p1);
+    // the partner lane evaluates the mirrored test, so the pair {v, p} is preserved (g-and-k)
+    v0 = ((p0 < v0) == keep_min) ? p0 : v0;
+    v1 = ((p1 < v1) == keep_min) ? p1 : v1;
   }
 }
 
