@@ -77,11 +77,34 @@ __device__ __forceinline__ double cdf_apply(const double *__restrict__ T, int64_
   return y0 + slope * (x - T[i0]);
 }
 
-// Same function, two-level search: C is the LDS copy of the coarse index (C[k] = T[k << shift], +inf
-// padded to kCdfCoarse, a power of two), so the first log2(kCdfCoarse) steps are LDS reads and only
-// `shift` steps touch the knot table in global memory.
-__device__ __forceinline__ double cdf_apply_2level(const double *__restrict__ T, int64_t len, int shift,
-                                                   const double *C, double x) {
+// ---- the same function with an index over the knot table -------------------------------------
+// A plain binary search into an 8 MB table (n = 1e6) touches ~7 distinct 128-byte lines per lookup, most of
+// them outside the 4 MB L2 of the XCD.  Index levels (built once per table, k_cdf_index):
+//   C  coarse, LDS:    C[k] = T[k << shift], kCdfCoarse entries (+inf padded)          -> 10 LDS steps
+//   M  mid, L2-hot:    M[m] = T[m << 4] (every 16th knot = first knot of each line)    -> shift - 4 steps in <= 0.5 MB
+//   T  the table:      the 15 knots behind T[m << 4], all in ONE line (+inf padded)     -> 4 steps in one line
+// so a lookup costs one line of the big table.  Every step tests the same monotone predicate T[i] < x as the
+// plain search, so the rank -- and therefore u -- is bit-identical (duplicated knots included).
+constexpr int kCdfLineShift = 4;           // 16 doubles = one 128-byte line
+
+__device__ __forceinline__ double cdf_interp(const double *__restrict__ T, int64_t len, int64_t lo, double x) {
+  const int64_t i0 = lo > 0 ? lo - 1 : 0;
+  const double L1 = (double)(len - 1);
+  const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
+  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
+  return y0 + slope * (x - T[i0]);
+}
+
+// p = last index in [a, a + 2^steps) with T[p] < x, given T[a] < x (branchless count form)
+__device__ __forceinline__ int64_t cdf_advance(const double *__restrict__ T, int64_t a, int steps, double x) {
+  for (int step = 1 << steps >> 1; step >= 1; step >>= 1)
+    if (T[a + step] < x) a += step;
+  return a;
+}
+
+// coarse (LDS) -> mid -> line
+__device__ __forceinline__ double cdf_apply_3level(const double *__restrict__ T, int64_t len, int shift, const double *C,
+                                                   const double *__restrict__ M, double x) {
   if (!(x >= T[0])) return (x != x) ? x : 0.0;
   if (x > T[len - 1]) return 1.0;
   int c = 0;                               // c = #coarse entries < x
@@ -91,19 +114,33 @@ __device__ __forceinline__ double cdf_apply_2level(const double *__restrict__ T,
   if (C[c] < x) c += 1;                    // the last entry (index kCdfCoarse-1) is only reachable here
   int64_t lo = 0;                          // lo = #knots < x
   if (c > 0) {
-    lo = ((int64_t)(c - 1) << shift) + 1;
-    int64_t hi = (int64_t)c << shift;
-    if (hi > len) hi = len;
-    while (lo < hi) {
-      const int64_t mid = lo + ((hi - lo) >> 1);
-      if (T[mid] < x) lo = mid + 1; else hi = mid;
+    int64_t a = (int64_t)(c - 1) << shift; // T[a] < x, and T[a + 2^shift] >= x or beyond the table (+inf padding)
+    if (shift > kCdfLineShift) {
+      const int64_t m = cdf_advance(M, a >> kCdfLineShift, shift - kCdfLineShift, x);
+      a = cdf_advance(T, m << kCdfLineShift, kCdfLineShift, x);
+    } else {
+      a = cdf_advance(T, a, shift, x);
     }
+    lo = a + 1;
   }
-  const int64_t i0 = lo > 0 ? lo - 1 : 0;
-  const double L1 = (double)(len - 1);
-  const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
-  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
-  return y0 + slope * (x - T[i0]);
+  return cdf_interp(T, len, lo, x);
+}
+
+// mid -> line, for callers without the LDS copy of the coarse level (one lookup per lane, g-and-k / host mode)
+__device__ __forceinline__ double cdf_apply_mid(const double *__restrict__ T, int64_t len, const double *__restrict__ M,
+                                                double x) {
+  if (!(x >= T[0])) return (x != x) ? x : 0.0;
+  if (x > T[len - 1]) return 1.0;
+  int64_t lo = 0;
+  if (T[0] < x) {
+    int64_t mlo = 0, mhi = (len + 15) >> kCdfLineShift;   // last m in [0, mhi) with M[m] < x; M[0] = T[0] < x
+    while (mhi - mlo > 1) {
+      const int64_t mid = mlo + ((mhi - mlo) >> 1);
+      if (M[mid] < x) mlo = mid; else mhi = mid;
+    }
+    lo = cdf_advance(T, mlo << kCdfLineShift, kCdfLineShift, x) + 1;
+  }
+  return cdf_interp(T, len, lo, x);
 }
 
 __device__ __forceinline__ double finite_or_big(double v) { return isfinite(v) ? v : 1e30; }

@@ -30,7 +30,7 @@ HipBackend::~HipBackend() {
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   if (host_thp_dev_) (void)hipFree(host_thp_dev_);
@@ -78,6 +78,8 @@ CdfPtrs HipBackend::cdf_ptrs() const {
   c.knots = knots_;
   c.stride = knot_stride_;
   c.coarse = coarse_;
+  c.mid = mid_;
+  c.mid_stride = mid_stride_;
   for (int j = 0; j < kMaxStats; ++j) { c.len[j] = cdf_len_[j]; c.shift[j] = cdf_shift_[j]; }
   return c;
 }
@@ -100,8 +102,10 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
   HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
   HB_CHECK(hipMalloc((void **)&coarse_, (size_t)m.s * kCdfCoarse * sizeof(double)), "hipMalloc(coarse)");
-  knot_stride_ = (int64_t)N + 2;
-  HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (N + 2) * sizeof(double)), "hipMalloc(knots)");
+  knot_stride_ = (((int64_t)N + 2 + 15) / 16) * 16;       // every table starts on a 128-byte line
+  HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (size_t)knot_stride_ * sizeof(double)), "hipMalloc(knots)");
+  mid_stride_ = cdf_mid_stride(knot_stride_);
+  HB_CHECK(hipMalloc((void **)&mid_, (size_t)m.s * (size_t)mid_stride_ * sizeof(double)), "hipMalloc(mid)");
   {   // k_update writes one row per workgroup; its granularity depends on the model's kernel
     const int64_t per_half = update_rows(m, (sh.cap + 1) / 2) + 1, whole = update_rows(m, sh.cap);
     partial_rows_ = 2 * per_half > whole ? 2 * per_half : whole;
@@ -484,13 +488,14 @@ int HipBackend::set_knots(int stat, const double *knots, int64_t len) {
   return build_coarse(stat);
 }
 
-// coarse level of the two-level ECDF search: the smallest shift with ceil(len / 2^shift) <= kCdfCoarse
+// index levels of the ECDF search (device_models.hpp): coarse = the smallest shift with ceil(len / 2^shift) <= kCdfCoarse
 int HipBackend::build_coarse(int stat) {
   int shift = 0;
   while ((((int64_t)cdf_len_[stat] + ((int64_t)1 << shift) - 1) >> shift) > kCdfCoarse) ++shift;
   cdf_shift_[stat] = shift;
-  HB_LAUNCH(launch_cdf_coarse(knots_ + (int64_t)stat * knot_stride_, cdf_len_[stat], shift, coarse_ + (int64_t)stat * kCdfCoarse, stream_),
-            "k_cdf_coarse");
+  HB_LAUNCH(launch_cdf_index(knots_ + (int64_t)stat * knot_stride_, cdf_len_[stat], knot_stride_, shift,
+                             coarse_ + (int64_t)stat * kCdfCoarse, mid_ + (int64_t)stat * mid_stride_, mid_stride_, stream_),
+            "k_cdf_index");
   return 0;
 }
 

@@ -73,7 +73,8 @@ class HipBackend : public Backend {
   int np_ = 0;
   double *pop_[2] = {nullptr, nullptr};
   int cur_ = 0;
-  double *rho_ = nullptr, *knots_ = nullptr, *coarse_ = nullptr;
+  double *rho_ = nullptr, *knots_ = nullptr, *coarse_ = nullptr, *mid_ = nullptr;
+  int64_t mid_stride_ = 0;
   int32_t cdf_shift_[kMaxStats] = {0};
   int build_coarse(int stat);
   int64_t knot_stride_ = 0;

@@ -151,7 +151,8 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
       double a = 0.0;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        up[j] = cdf_apply_2level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j], rp[j]);   // :316
+        up[j] = cdf_apply_3level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
+                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (u[j] - up[j]) / e;                                             // :319
       }
@@ -292,7 +293,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
 #pragma unroll
       for (int q = 1; q < S; ++q)
         if (j == q) len = cdf.len[q];
-      upv = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, len, st.rp[it][j]);
+      upv = cdf_apply_mid(cdf.knots + (int64_t)j * cdf.stride, len, cdf.mid + (int64_t)j * cdf.mid_stride, st.rp[it][j]);
     }
     st.up[it][j] = upv;
   }
@@ -483,7 +484,8 @@ k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restric
       for (int k = 0; k < d; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
       double a = 0.0;
       for (int j = 0; j < s; ++j) {
-        up[j] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rho_prop[(int64_t)j * act_n + t]);
+        up[j] = cdf_apply_mid(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.mid + (int64_t)j * cdf.mid_stride,
+                              rho_prop[(int64_t)j * act_n + t]);
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (pp.pop[(int64_t)(d + j) * pp.cap + li] - up[j]) / e;
       }
@@ -828,11 +830,18 @@ k_cdf_fill(const double *__restrict__ sorted, const int64_t n, const int64_t *__
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_cdf_coarse(const double *__restrict__ knots, const int64_t len, const int shift, double *__restrict__ coarse) {
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  if (k >= kCdfCoarse) return;
-  const int64_t p = (int64_t)k << shift;
-  coarse[k] = p < len ? knots[p] : INFINITY;
+k_cdf_index(double *__restrict__ knots, const int64_t len, const int64_t stride, const int shift, double *__restrict__ coarse,
+            double *__restrict__ mid, const int64_t mid_len) {
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k < kCdfCoarse) {
+    const int64_t p = k << shift;
+    coarse[k] = p < len ? knots[p] : INFINITY;
+  }
+  if (k < mid_len) {
+    const int64_t p = k << kCdfLineShift;
+    mid[k] = p < len ? knots[p] : INFINITY;
+  }
+  if (len + k < stride) knots[len + k] = INFINITY;       // the searches read up to 15 knots past the last one
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -1095,8 +1104,13 @@ int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *me
   return SABC_LAUNCH_RC();
 }
 
-int launch_cdf_coarse(const double *knots, int64_t len, int shift, double *coarse, hipStream_t stream) {
-  hipLaunchKernelGGL(k_cdf_coarse, dim3((kCdfCoarse + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, knots, len, shift, coarse);
+int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, double *mid, int64_t mid_len,
+                     hipStream_t stream) {
+  int64_t work = kCdfCoarse;
+  if (mid_len > work) work = mid_len;
+  if (stride - len > work) work = stride - len;
+  hipLaunchKernelGGL(k_cdf_index, dim3((unsigned)n_blocks(work)), dim3(kBlock), 0, stream, knots, len, stride, shift, coarse, mid,
+                     mid_len);
   return SABC_LAUNCH_RC();
 }
 

@@ -19,12 +19,17 @@ struct PopPtrs {
 constexpr int kCdfCoarse = 1024;
 
 struct CdfPtrs {
-  const double *knots;   // [s][stride]
+  const double *knots;   // [s][stride]; stride is a multiple of 16 (each table starts on a 128-byte line), +inf behind len
   int64_t stride;
   int64_t len[kMaxStats];
   const double *coarse;  // [s][kCdfCoarse]
+  const double *mid;     // [s][mid_stride]: every 16th knot (the first knot of each line), +inf padded
+  int64_t mid_stride;
   int32_t shift[kMaxStats];
 };
+// entries of the mid level that a search can touch for a table of `stride` knots: (kCdfCoarse << shift) >> 4 + 1 with
+// (kCdfCoarse << shift) < 2 * stride + 2 * kCdfCoarse
+inline int64_t cdf_mid_stride(int64_t stride) { return ((2 * stride + 2 * kCdfCoarse) >> 4) + 2; }
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
@@ -74,8 +79,10 @@ int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows,
 // K2: knots = [0; sorted positives; 1.5 max] from an ascending-sorted column         cdf_estimators.jl:29-33
 // meta[0] = number of non-positive entries, meta[1] = 1 if any entry is negative
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream);
-// coarse[k] = knots[k << shift] for k << shift < len, +inf beyond
-int launch_cdf_coarse(const double *knots, int64_t len, int shift, double *coarse, hipStream_t stream);
+// the index levels of one table: coarse[k] = knots[k << shift], mid[m] = knots[m << 4] (+inf beyond len), and
+// +inf written into knots[len, stride)
+int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, double *mid, int64_t mid_len,
+                     hipStream_t stream);
 // compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
 int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
                           hipStream_t stream);

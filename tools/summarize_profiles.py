@@ -16,7 +16,7 @@ out, prof = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)      # gpurun_out/ accumulates: newest wins
     if not hits:
         raise SystemExit(f"nothing matches {pattern}")
     return hits[-1]
