@@ -121,9 +121,8 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipHostMalloc((void **)&mbox_host_, kMailboxRing * sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
   for (int i = 0; i < kMailboxRing; ++i) { mbox_host_[i].seq = 0; mbox_host_[i].n_accept = 0; mbox_host_[i].error = 0; mbox_host_[i].halted = 0; }
   HB_CHECK(hipHostGetDevicePointer((void **)&mbox_dev_, mbox_host_, 0), "hipHostGetDevicePointer(mailbox)");
-  const size_t nb = (N + kScanChunk - 1) / kScanChunk;
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
-  HB_CHECK(hipMalloc((void **)&block_sums_, 2 * nb * sizeof(double)), "hipMalloc(block_sums)");
+  HB_CHECK(hipMalloc((void **)&block_sums_, (size_t)weight_scan_doubles((int64_t)N) * sizeof(double)), "hipMalloc(block_sums)");
   HB_CHECK(hipMalloc((void **)&totals_dev_, 2 * sizeof(double)), "hipMalloc(totals)");
   HB_CHECK(hipHostMalloc((void **)&totals_host_, 2 * sizeof(double)), "hipHostMalloc(totals)");
   totals_host_[0] = totals_host_[1] = 0.0;

@@ -68,6 +68,12 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
 int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
                             hipStream_t stream);
+// block_sums: weight_scan_doubles(n_global) doubles of scratch shared by K5b and K5c (chunk sums, chunk sums of squares,
+// group-end values)
+inline int64_t weight_scan_doubles(int64_t n_global) {
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  return 2 * nb + nb * (kScanChunk / 16);
+}
 // K5b: inclusive scan of the global weight vector (gathered layout [world][rows][cap]) -> cum[n_global];
 // totals[0] = sum w, totals[1] = sum w^2                               :129,134
 int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
