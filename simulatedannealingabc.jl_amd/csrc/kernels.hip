@@ -611,8 +611,17 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
   const int g = threadIdx.x / np, c = threadIdx.x - g * np;
   if (!skip_reduce) {
     double v = 0.0;
-    if (g < G)
-      for (int64_t r = g; r < rows; r += G) v += partials[r * np + c];
+    if (g < G) {
+      int64_t r = g;
+      for (; r + 7 * (int64_t)G < rows; r += 8 * (int64_t)G) {   // 8 loads in flight per lane; the additions stay in row order
+        double x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = partials[(r + (int64_t)e * G) * np + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v += x[e];
+      }
+      for (; r < rows; r += G) v += partials[r * np + c];
+    }
     sm[threadIdx.x] = v;
     __syncthreads();
     if (threadIdx.x < np) {
