@@ -925,6 +925,7 @@ k_rng_peak(const uint64_t seed, const int pairs, const int64_t n, double *__rest
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double acc = 0.0;
+#pragma unroll SABC_SIM_UNROLL
   for (int k = 0; k < pairs; ++k) {
     double z0, z1;
     box_muller(stream_block(seed, (uint64_t)i, PURPOSE_SIM, 0, (uint32_t)k), z0, z1);
