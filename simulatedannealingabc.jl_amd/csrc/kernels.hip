@@ -586,64 +586,87 @@ k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const
   if (threadIdx.x == 0) sums[c] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-// the state hand-over between two population updates, one lane (control.hpp)
-__global__ void k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, const double *sums_in) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (!control_step(*cb, a, hist, sums_in)) return;
-  if (a.notify_seq != 0) {
+// The state hand-over between two population updates (control.hpp), one lane -- on an LDS copy of the control
+// block: the step is a chain of dependent reads and writes of the block, each of which would be a round trip to
+// L2 (~1 us); the workgroup loads the 1.7 KB block once, lane 0 works on the copy, the workgroup writes it back.
+static_assert(sizeof(ControlBlock) % 8 == 0, "copied as 8-byte words");
+constexpr int kControlWords = (int)(sizeof(ControlBlock) / 8);
+
+// the workgroup's loads of the block; the caller puts a barrier between this and control_on_copy()
+__device__ __forceinline__ void control_load(ControlBlock &lcb, const ControlBlock *cb) {
+  for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
+    reinterpret_cast<uint64_t *>(&lcb)[i] = reinterpret_cast<const uint64_t *>(cb)[i];
+}
+
+__device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, ControlBlock *cb, const ControlArgs &a,
+                                                double *hist, Mailbox *ring, const double *sums, double *stage) {
+  if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums) ? 1 : 0;
+  __syncthreads();
+  if (!ran) return;                         // guarded and halted: nothing changed, nothing is posted
+  for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
+    reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
+  if (stage && threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
+  if (threadIdx.x == 0 && a.notify_seq != 0) {
     Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
-    mbox->n_accept = cb->n_accept;
-    mbox->error = cb->error;
-    mbox->halted = cb->halt;
+    mbox->n_accept = lcb.n_accept;
+    mbox->error = lcb.error;
+    mbox->halted = lcb.halt;
     __threadfence_system();                 // payload before the sequence word, visible to the host
     mbox->seq = a.notify_seq;
   }
 }
 
+__global__ void __launch_bounds__(64)
+k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, const double *sums_in) {
+  __shared__ ControlBlock lcb;
+  __shared__ int ran;
+  __shared__ double sums[kMaxPartials];
+  const int np = n_partials(a.d, a.s);
+  control_load(lcb, cb);
+  for (int i = threadIdx.x; i < np; i += blockDim.x) sums[i] = sums_in[i];
+  __syncthreads();
+  control_on_copy(lcb, ran, cb, a, hist, ring, sums, nullptr);
+}
+
 // k_reduce_partials + k_control in one launch, for the case that no allreduce sits between them
 // (one shard).  1024 threads: thread (g, c) sums rows g, g+G, ... of column c (consecutive threads
 // read consecutive addresses), LDS combines the G row groups in a fixed order, lane 0 runs the
-// control step on the staged sums.
+// control step on the sums.  The loads of the control block and of the partial rows are issued together
+// (one round trip); the staging buffer is written only by a step that runs.
 __global__ void __launch_bounds__(1024)
 k_reduce_control(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ stage,
-                 const int reduce_guarded, ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring) {
+                 ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring) {
+  __shared__ ControlBlock lcb;
+  __shared__ int ran;
   __shared__ double sm[1024];
-  const bool skip_reduce = reduce_guarded && cb->halt;
+  __shared__ double sums[kMaxPartials];
+  control_load(lcb, cb);
   const int G = 1024 / np;
   const int g = threadIdx.x / np, c = threadIdx.x - g * np;
-  if (!skip_reduce) {
-    double v = 0.0;
-    if (g < G) {
-      int64_t r = g;
-      for (; r + 7 * (int64_t)G < rows; r += 8 * (int64_t)G) {   // 8 loads in flight per lane; the additions stay in row order
-        double x[8];
+  double v = 0.0;
+  if (g < G) {
+    int64_t r = g;
+    for (; r + 7 * (int64_t)G < rows; r += 8 * (int64_t)G) {   // 8 loads in flight per lane; the additions stay in row order
+      double x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = partials[(r + (int64_t)e * G) * np + c];
+      for (int e = 0; e < 8; ++e) x[e] = partials[(r + (int64_t)e * G) * np + c];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v += x[e];
-      }
-      for (; r < rows; r += G) v += partials[r * np + c];
+      for (int e = 0; e < 8; ++e) v += x[e];
     }
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    if (threadIdx.x < np) {
-      double t = 0.0;
-      for (int q = 0; q < G; ++q) t += sm[q * np + threadIdx.x];
-      stage[threadIdx.x] = t;
-    }
+    for (; r < rows; r += G) v += partials[r * np + c];
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  // fixed-shape tree over the G row groups (a serial sum by np lanes would be G dependent LDS reads: 6 us at G = 204)
+  int top = 1;
+  while (top * 2 < G) top *= 2;
+  for (int stride = top; stride >= 1; stride >>= 1) {
+    if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
-  __threadfence();                          // the staged sums written by other lanes of this block
-  if (!control_step(*cb, a, hist, stage)) return;
-  if (a.notify_seq != 0) {
-    Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
-    mbox->n_accept = cb->n_accept;
-    mbox->error = cb->error;
-    mbox->halted = cb->halt;
-    __threadfence_system();
-    mbox->seq = a.notify_seq;
-  }
+  if (threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
+  __syncthreads();
+  control_on_copy(lcb, ran, cb, a, hist, ring, sums, stage);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1084,7 +1107,8 @@ int launch_reduce_partials(const double *partials, int64_t rows, int np, double 
 
 int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
                           ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream) {
-  hipLaunchKernelGGL(k_reduce_control, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, reduce_guarded ? 1 : 0, cb,
+  (void)reduce_guarded;   // a guarded reduction is always paired with a guarded control step, which is what decides
+  hipLaunchKernelGGL(k_reduce_control, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb,
                      a, hist, mbox);
   return SABC_LAUNCH_RC();
 }
