@@ -605,7 +605,7 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
   if (!ran) return;                         // guarded and halted: nothing changed, nothing is posted
   for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
     reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
-  if (stage && threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
+  if (stage && (int)threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
   if (threadIdx.x == 0 && a.notify_seq != 0) {
     Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
     mbox->n_accept = lcb.n_accept;
@@ -664,7 +664,7 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
     if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
     __syncthreads();
   }
-  if (threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
+  if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
   __syncthreads();
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, stage);
 }
