@@ -162,12 +162,83 @@ __device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
   cs = ((k + 1) & 2) ? -c1 : c1;               // k = 1,2: cos flips
 }
 
+// ---- table-driven log and sin/cos for the Box-Muller pair ------------------------------------
+// The pair costs one log and one sin/cos; with two small tables in LDS (2.5 KB, rng_tables.inc, generated by
+// tools/gen_rng_tables.py) both shrink to short polynomials on a tiny argument: log 33 -> 19 VALU instructions
+// (no division), sin/cos 34 -> 23 (no quadrant selects).  Every kernel that draws normals calls
+// rng_tables_init() first (all threads of the workgroup, before any divergent return).
+#include "rng_tables.inc"
+
+struct RngTables {
+  double2 logt[128];     // { 1/c_i rounded, -log of that }: c_i = 1 + i/128 (i < 53) or (1 + i/128)/2 (i >= 53); c_0 = 1
+  double2 sct[32];       // { sin, cos } of 2 pi k / 32
+};
+
+__device__ __forceinline__ RngTables &rng_tables() {
+  __shared__ RngTables t;
+  return t;
+}
+
+__device__ __forceinline__ void rng_tables_init() {
+  RngTables &t = rng_tables();
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) t.logt[i] = make_double2(kLogTab[i][0], kLogTab[i][1]);
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i][0], kSinCosTab[i][1]);
+  __syncthreads();
+}
+
+// log(x), normal x > 0.  x = 2^E m; the 7 leading mantissa bits (rounded to nearest, so that 1 is a bin CENTRE)
+// pick c_i with |m / c_i - 1| <= 2^-8; bins above sqrt(2) are taken as c_i / 2 with E + 1, so m / c stays in
+// [0.707, 1.414) and there is no cancellation against E ln 2 for x near 1 (x -> 1 from below lands in bin 0 of
+// E = 0: c = 1, log = log1p(x - 1) to full relative accuracy).  log(m) = logc_i + log1p(r), r = m inv_i - 1 by one
+// fma; log1p on |r| <= 2^-8 is r + r^2 P(r) with the Taylor terms to r^7 (remainder 2^-59 relative).
+__device__ __forceinline__ double log_tab(double x) {
+  const uint32_t hi = (uint32_t)__double2hiint(x);
+  const uint32_t t = hi + 0x800u;                       // round the mantissa to 7 bits (may carry into the exponent)
+  const uint32_t tp = t + (75u << 13);                  // ... and carry when that rounded mantissa is >= 53/128
+  const int nE = 1023 - (int)(tp >> 20);                // -E
+  const double m = __hiloint2double((int)(hi + ((uint32_t)nE << 20)), __double2loint(x));   // x 2^-E, exact
+  const double2 e = rng_tables().logt[(t >> 13) & 127u];
+  const double r = fma(m, e.x, -1.0);
+  double p = 1.0 / 7.0;
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 0.2);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  const double l1p = fma(r * r, p, r);
+  const double nEd = (double)nE;
+  const double hi_part = fma(nEd, -6.93147180369123816490e-01, e.y);     // ln2_hi has 32 trailing zero bits: the product is exact
+  return hi_part + fma(nEd, -1.90821492927058770002e-10, l1p);
+}
+
+// sin and cos of 2 pi u, u in (0,1): k = rint(32 u), f = 32 u - k exact, r = (pi/16) f, |r| <= pi/32;
+// sin(a_k + r) = S + (S q + C sin r), cos(a_k + r) = C + (C q - S sin r) with q = cos r - 1 and (S, C) from the table.
+__device__ __forceinline__ void sincos_2pi_tab(double u, double &sn, double &cs) {
+  const double t = 32.0 * u;
+  const double kf = rint(t);
+  const double r = 1.96349540849362077404e-01 * (t - kf);               // pi / 16
+  const double2 sc = rng_tables().sct[(int)kf & 31];
+  const double r2 = r * r;
+  double p = 1.0 / 362880.0;
+  p = fma(p, r2, -1.0 / 5040.0);
+  p = fma(p, r2, 1.0 / 120.0);
+  p = fma(p, r2, -1.0 / 6.0);
+  const double sr = fma(r * r2, p, r);                                    // sin r
+  double q = 1.0 / 40320.0;
+  q = fma(q, r2, -1.0 / 720.0);
+  q = fma(q, r2, 1.0 / 24.0);
+  q = fma(q, r2, -0.5);
+  q *= r2;                                                                // cos r - 1
+  sn = sc.x + fma(sc.x, q, sc.y * sr);
+  cs = sc.y + fma(sc.y, q, -(sc.x * sr));
+}
+
 __device__ __forceinline__ void box_muller(const u32x4 w, double &z0, double &z1) {
   const double ua = u52(w.x, w.y);
   const double ub = u52(w.z, w.w);
-  const double r = sqrt_fast(-2.0 * log_fast(ua));
+  const double r = sqrt_fast(-2.0 * log_tab(ua));
   double sn, cs;
-  sincos_2pi(ub, sn, cs);
+  sincos_2pi_tab(ub, sn, cs);
   z0 = r * cs;
   z1 = r * sn;
 }

@@ -75,6 +75,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
+  rng_tables_init();
   __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
   for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
   __syncthreads();
@@ -204,6 +205,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   constexpr int D = kGkD, S = kGkS, NP = n_partials(D, S), PW = kGkParticlesPerWave;
   static_assert(PW * S == 64, "phase 2 maps one (particle, statistic) pair to each lane");
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
+  rng_tables_init();
   __shared__ GkStage stage[kBlock / 64];
   __shared__ double red[kBlock / 64][NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,6 +365,7 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
               const uint64_t pid0, const uint64_t iter, const int sample_prior, double *__restrict__ theta_out,
               double *__restrict__ rho_out, const int64_t out_stride) {
   constexpr int D = kGkD, S = kGkS;
+  rng_tables_init();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int it = 0; it < kGkParticlesPerWave; ++it) {
     const int64_t i = (int64_t)blockIdx.x * kGkPerBlock + wave * kGkParticlesPerWave + it;
@@ -405,6 +408,7 @@ __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const doub
 
 // rand(prior) for the shard (:174); theta goes to the population rows
 __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const PopPtrs pp) {
+  rng_tables_init();
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= pp.n_local) return;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
@@ -418,6 +422,7 @@ __global__ void __launch_bounds__(kBlock)
 k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp,
                const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ thp_out,
                double *__restrict__ aux) {
+  rng_tables_init();
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= act_n) return;
   const int d = m.d;
@@ -674,6 +679,7 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
 // ------------------------------------------------------------------------------------------
 template <int MODEL, int D, int S>
 __global__ void __launch_bounds__(kBlock) k_prior_simulate(const ModelDesc m, const PopPtrs pp) {
+  rng_tables_init();
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= pp.n_local) return;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
@@ -924,6 +930,7 @@ template <int MODEL, int D, int S>
 __global__ void __launch_bounds__(kBlock)
 k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,
                  const uint64_t iter, double *__restrict__ rho_out) {
+  rng_tables_init();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double th[D], rho[S];
@@ -936,6 +943,7 @@ k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int6
 
 __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                                uint32_t *words, double *normals) {
+  rng_tables_init();
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const u32x4 w = stream_block(seed, pid, purpose, iter, k);
   words[0] = w.x; words[1] = w.y; words[2] = w.z; words[3] = w.w;
@@ -947,6 +955,7 @@ __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, ui
 // generator; bench.py quotes k_update's in-kernel normal rate against it.
 __global__ void __launch_bounds__(kBlock)
 k_rng_peak(const uint64_t seed, const int pairs, const int64_t n, double *__restrict__ out) {
+  rng_tables_init();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double acc = 0.0;
@@ -962,6 +971,7 @@ k_rng_peak(const uint64_t seed, const int pairs, const int64_t n, double *__rest
 
 __global__ void __launch_bounds__(kBlock)
 k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out) {
+  rng_tables_init();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= m) return;
   double z0, z1;
