@@ -67,13 +67,12 @@ __device__ __forceinline__ double div_fast(double a, double b) {
   return fma(fma(-b, q, a), r, q);
 }
 
-// sqrt(x) for x in [1e-300, 1e300]: v_rsq_f64 + two coupled Newton steps + one correction
+// sqrt(x) for x in [1e-300, 1e300]: v_rsq_f64 (~2^-27), one coupled Newton step, one residual correction
+// (what the compiler emits for sqrt(), minus its second correction and the scaling for tiny / huge x)
 __device__ __forceinline__ double sqrt_fast(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g); h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
+  const double r = fma(-h, g, 0.5);
   g = fma(g, r, g); h = fma(h, r, h);
   return fma(fma(-g, g, x), h, g);
 }
@@ -170,7 +169,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
 #include "rng_tables.inc"
 
 struct RngTables {
-  double2 logt[128];     // { 1/c_i rounded, -log of that }: c_i = 1 + i/128 (i < 53) or (1 + i/128)/2 (i >= 53); c_0 = 1
+  double2 logt[128];     // -2 x { 1/c_i rounded, -log of that }: c_i = 1 + i/128 (i < 53) or (1 + i/128)/2 (i >= 53); c_0 = 1
   double2 sct[32];       // { sin, cos } of 2 pi k / 32
 };
 
@@ -186,29 +185,30 @@ __device__ __forceinline__ void rng_tables_init() {
   __syncthreads();
 }
 
-// log(x), normal x > 0.  x = 2^E m; the 7 leading mantissa bits (rounded to nearest, so that 1 is a bin CENTRE)
-// pick c_i with |m / c_i - 1| <= 2^-8; bins above sqrt(2) are taken as c_i / 2 with E + 1, so m / c stays in
-// [0.707, 1.414) and there is no cancellation against E ln 2 for x near 1 (x -> 1 from below lands in bin 0 of
-// E = 0: c = 1, log = log1p(x - 1) to full relative accuracy).  log(m) = logc_i + log1p(r), r = m inv_i - 1 by one
-// fma; log1p on |r| <= 2^-8 is r + r^2 P(r) with the Taylor terms to r^7 (remainder 2^-59 relative).
-__device__ __forceinline__ double log_tab(double x) {
+// -2 log(x), normal x > 0 (the squared Box-Muller radius).  x = 2^E m; the 7 leading mantissa bits (rounded to
+// nearest, so that 1 is a bin CENTRE) pick c_i with |m / c_i - 1| <= 2^-8; bins above sqrt(2) are taken as c_i / 2
+// with E + 1, so m / c stays in [0.707, 1.414) and there is no cancellation against E ln 2 for x near 1 (x -> 1
+// from below lands in bin 0 of E = 0: c = 1, full relative accuracy).  log(m) = logc_i + log1p(r), r = m inv_i - 1.
+// With s = -2 r (one fma against the table's -2 inv_i): -2 log1p(r) = s + s^2/4 + s^3/12 + ... + s^7/448
+// (remainder 2^-59 relative on |s| <= 2^-7).
+__device__ __forceinline__ double neg2_log_tab(double x) {
   const uint32_t hi = (uint32_t)__double2hiint(x);
   const uint32_t t = hi + 0x800u;                       // round the mantissa to 7 bits (may carry into the exponent)
   const uint32_t tp = t + (75u << 13);                  // ... and carry when that rounded mantissa is >= 53/128
   const int nE = 1023 - (int)(tp >> 20);                // -E
   const double m = __hiloint2double((int)(hi + ((uint32_t)nE << 20)), __double2loint(x));   // x 2^-E, exact
   const double2 e = rng_tables().logt[(t >> 13) & 127u];
-  const double r = fma(m, e.x, -1.0);
-  double p = 1.0 / 7.0;
-  p = fma(p, r, -1.0 / 6.0);
-  p = fma(p, r, 0.2);
-  p = fma(p, r, -0.25);
-  p = fma(p, r, 1.0 / 3.0);
-  p = fma(p, r, -0.5);
-  const double l1p = fma(r * r, p, r);
+  const double s = fma(m, e.x, 2.0);                    // -2 (m inv - 1)
+  double p = 1.0 / 448.0;
+  p = fma(p, s, 1.0 / 192.0);
+  p = fma(p, s, 1.0 / 80.0);
+  p = fma(p, s, 1.0 / 32.0);
+  p = fma(p, s, 1.0 / 12.0);
+  p = fma(p, s, 0.25);
+  const double l = fma(s * s, p, s);
   const double nEd = (double)nE;
-  const double hi_part = fma(nEd, -6.93147180369123816490e-01, e.y);     // ln2_hi has 32 trailing zero bits: the product is exact
-  return hi_part + fma(nEd, -1.90821492927058770002e-10, l1p);
+  const double hi_part = fma(nEd, 2.0 * 6.93147180369123816490e-01, e.y);   // ln2_hi has 32 trailing zero bits: exact product
+  return hi_part + fma(nEd, 2.0 * 1.90821492927058770002e-10, l);
 }
 
 // sin and cos of 2 pi u, u in (0,1): k = rint(32 u), f = 32 u - k exact, r = (pi/16) f, |r| <= pi/32;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void sincos_2pi_tab(double u, double &sn, double &cs)
 __device__ __forceinline__ void box_muller(const u32x4 w, double &z0, double &z1) {
   const double ua = u52(w.x, w.y);
   const double ub = u52(w.z, w.w);
-  const double r = sqrt_fast(-2.0 * log_tab(ua));
+  const double r = sqrt_fast(neg2_log_tab(ua));
   double sn, cs;
   sincos_2pi_tab(ub, sn, cs);
   z0 = r * cs;
