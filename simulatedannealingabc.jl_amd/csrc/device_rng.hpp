@@ -170,7 +170,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
 
 struct RngTables {
   double2 logt[128];     // -2 x { 1/c_i rounded, -log of that }: c_i = 1 + i/128 (i < 53) or (1 + i/128)/2 (i >= 53); c_0 = 1
-  double2 sct[32];       // { sin, cos } of 2 pi k / 32
+  double2 sct[33];       // { sin, cos } of 2 pi k / 32, k = 0..32 (row 32 = row 0)
 };
 
 __device__ __forceinline__ RngTables &rng_tables() {
@@ -181,7 +181,7 @@ __device__ __forceinline__ RngTables &rng_tables() {
 __device__ __forceinline__ void rng_tables_init() {
   RngTables &t = rng_tables();
   for (int i = threadIdx.x; i < 128; i += blockDim.x) t.logt[i] = make_double2(kLogTab[i][0], kLogTab[i][1]);
-  for (int i = threadIdx.x; i < 32; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i][0], kSinCosTab[i][1]);
+  for (int i = threadIdx.x; i < 33; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i & 31][0], kSinCosTab[i & 31][1]);
   __syncthreads();
 }
 
@@ -214,10 +214,12 @@ __device__ __forceinline__ double neg2_log_tab(double x) {
 // sin and cos of 2 pi u, u in (0,1): k = rint(32 u), f = 32 u - k exact, r = (pi/16) f, |r| <= pi/32;
 // sin(a_k + r) = S + (S q + C sin r), cos(a_k + r) = C + (C q - S sin r) with q = cos r - 1 and (S, C) from the table.
 __device__ __forceinline__ void sincos_2pi_tab(double u, double &sn, double &cs) {
-  const double t = 32.0 * u;
-  const double kf = rint(t);
-  const double r = 1.96349540849362077404e-01 * (t - kf);               // pi / 16
-  const double2 sc = rng_tables().sct[(int)kf & 31];
+  // k = rint(32 u) by the add-a-big-number trick: the sum's low mantissa word IS k (0..32; the table has 33 rows),
+  // which saves the conversion and the wrap-around mask
+  const double tm = fma(u, 32.0, 0x1.8p52);
+  const double kf = tm - 0x1.8p52;
+  const double r = 1.96349540849362077404e-01 * fma(u, 32.0, -kf);       // (pi / 16) (32 u - k), the difference is exact
+  const double2 sc = rng_tables().sct[__double2loint(tm)];
   const double r2 = r * r;
   double p = 1.0 / 362880.0;
   p = fma(p, r2, -1.0 / 5040.0);
