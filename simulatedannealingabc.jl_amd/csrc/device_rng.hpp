@@ -179,10 +179,15 @@ __device__ __forceinline__ RngTables &rng_tables() {
   return t;
 }
 
-__device__ __forceinline__ void rng_tables_init() {
+// the copies only; the caller's next __syncthreads() publishes them (k_update shares that barrier with its ECDF index)
+__device__ __forceinline__ void rng_tables_load() {
   RngTables &t = rng_tables();
   for (int i = threadIdx.x; i < 128; i += blockDim.x) t.logt[i] = make_double2(kLogTab[i][0], kLogTab[i][1]);
   for (int i = threadIdx.x; i < 33; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i & 31][0], kSinCosTab[i & 31][1]);
+}
+
+__device__ __forceinline__ void rng_tables_init() {
+  rng_tables_load();
   __syncthreads();
 }
 

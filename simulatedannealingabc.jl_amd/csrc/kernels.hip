@@ -75,10 +75,10 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
-  rng_tables_init();
+  rng_tables_load();
   __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
   for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
-  __syncthreads();
+  __syncthreads();                         // publishes both the generator tables and the index
   double acc[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) acc[q] = 0.0;
