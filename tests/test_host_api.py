@@ -82,3 +82,32 @@ def test_no_cpu_fallback(S):
     assert e.value.code == -20 and "no CPU path" in str(e.value)
     with pytest.raises(S.SABCError):
         S.op_build_cdf([1.0, 2.0, 3.0])
+
+
+def test_rng_tables_are_what_the_generator_script_writes(tmp_path, monkeypatch):
+    """csrc/rng_tables.inc (the log / sin-cos tables behind the device Box-Muller) is generated, not edited:
+    re-running tools/gen_rng_tables.py reproduces the committed file bit for bit, and the table entries satisfy
+    their defining identities in binary64."""
+    import importlib.util
+    import math
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "simulatedannealingabc.jl_amd", "csrc", "rng_tables.inc")
+    committed = open(inc).read()
+    spec = importlib.util.spec_from_file_location("gen_rng_tables", os.path.join(root, "tools", "gen_rng_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fake_tools = tmp_path / "tools"
+    (tmp_path / "simulatedannealingabc.jl_amd" / "csrc").mkdir(parents=True)
+    fake_tools.mkdir()
+    monkeypatch.setattr(gen, "__file__", str(fake_tools / "gen_rng_tables.py"))
+    gen.main()
+    assert open(tmp_path / "simulatedannealingabc.jl_amd" / "csrc" / "rng_tables.inc").read() == committed
+    rows = [[float.fromhex(x) for x in re.findall(r"-?0x[0-9a-f.]+p[-+]\d+", ln)] for ln in committed.splitlines() if ln.strip().startswith("{")]
+    logt, sct = rows[:128], rows[128:]
+    assert len(sct) == 32 and logt[0] == [-2.0, 0.0]
+    for i, (m2inv, m2logc) in enumerate(logt):
+        c = (1 + i / 128) if i < 53 else (1 + i / 128) / 2
+        assert abs(-0.5 * m2inv * c - 1) < 2e-16 and abs(-0.5 * m2logc - math.log(c)) < 3e-16
+    for k, (s, c) in enumerate(sct):
+        assert abs(s * s + c * c - 1) < 3e-16 and abs(s - math.sin(math.pi * k / 16)) < 1e-15
