@@ -64,7 +64,8 @@ def single(S, Handle, case, alg, prop, n, updates, resample=None):
 
 
 @pytest.mark.parametrize("world,case,alg,n", [(2, "gauss1_cfg2", "single_eps", 1001), (3, "gauss2_2stats", "multi_eps", 1000),
-                                               (2, "gauss2d_cfg3", "single_eps", 777)])
+                                               (2, "gauss2d_cfg3", "single_eps", 777),
+                                               (8, "gauss1_cfg2", "single_eps", 1003)])     # the N = 8 geometry, ragged last shard
 def test_cpu_engine_sharded_randomwalk_equals_single_shard(S, tmp_path, world, case, alg, n):
     from tests import cpu_engine
     ref = single(S, cpu_engine.handle_class(), case, alg, "rw", n, 10, resample=n // 4)
