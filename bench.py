@@ -70,6 +70,21 @@ def _load_traffic(workload_n):
     return None
 
 
+def load_sq_summary(workload_n, config="cfg2"):
+    """VALU busy fraction / effective clock of the update kernel from the committed SQ counter pass (tools/pmc_sq.sh)."""
+    if config != "cfg2" or int(workload_n) != 1_000_000:
+        return {}
+    try:
+        import csv
+        rows = {r["name"]: float(r["value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_cfg2.csv")))}
+        return {"pmc_valu_busy_fraction": rows["valu_busy_fraction"], "pmc_effective_clock_ghz": rows["effective_clock_ghz"],
+                "pmc_cycles_per_valu_instruction": rows["cycles_per_valu_instruction"],
+                "pmc_note": "rocprofv3 --pmc SQ_* pass of the same command (profiles/r01_pmc_sq_cfg2.csv): share of the SQ busy "
+                            "cycles in which a SIMD's VALU executes"}
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +201,8 @@ def main():
             peak = S.op_rng_peak(n_lanes=int(sims_per_launch), pairs_per_lane=max(normals_per_sim // 2, 1), repeats=10, device=device)
             in_kernel = normals_per_sim * sims_per_launch / avg_launch_s
             valu = {"bound": "valu", "achieved": in_kernel, "peak": peak, "unit": "normals/s", "frac": in_kernel / peak,
-                    "note": "peak = rate of k_rng_peak (generator only); the rest of k_update is proposal, ECDF search, accept, sums"}
+                    "note": "peak = rate of k_rng_peak (generator only); the rest of k_update is proposal, ECDF search, accept, sums",
+                    **load_sq_summary(n, args.config)}
         yb = observed_mean()
         post_var = 1.0 / (1.0 / 4.0 + 100.0)
         analytic = {"analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var} \
