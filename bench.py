@@ -240,7 +240,8 @@ def main():
                 "launches": real_launches, "aborted_launches": aborted,
                 "algorithmic_bytes_per_sim": bytes_per_sim,
                 "note": f"not HBM-bound by construction: {normals_per_sim} f64 normals ({normals_per_sim // 2} Philox4x32-10 "
-                        f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; see normals_per_s",
+                        f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; the binding resource is VALU issue "
+                        f"(valu_roofline: SQ counters show the VALU executing in ~95 % of the busy cycles); see normals_per_s",
             },
             "normals_per_s": float(normals_per_sim) * K * n / dt,
             # the bound that actually binds: k_update's in-kernel normal rate against the bare Philox + Box-Muller
