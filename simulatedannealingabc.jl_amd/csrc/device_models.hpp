@@ -165,25 +165,24 @@ struct Sim<SABC_MODEL_GAUSS_IID, D, S> {
     const double mu = th[0];
     const double sd = (D >= 2) ? th[1] : m.p[1];
     NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
-    double sum = 0.0, sum2 = 0.0;
+    // x_i = mu + sd z_i: the loop sums z and z^2 only; sum x = n mu + sd sum z, sum x^2 = n mu^2 + 2 mu sd sum z + sd^2 sum z^2
+    double sz = 0.0, szz = 0.0;
     const int n_pairs = n_obs >> 1;
 #pragma unroll SABC_SIM_UNROLL
     for (int k = 0; k < n_pairs; ++k) {
       double z0, z1;
       ns.pair(z0, z1);
-      const double x0 = mu + sd * z0;
-      const double x1 = mu + sd * z1;
-      sum += x0; if (S >= 2) sum2 += x0 * x0;
-      sum += x1; if (S >= 2) sum2 += x1 * x1;
+      sz += z0; if (S >= 2) szz = fma(z0, z0, szz);
+      sz += z1; if (S >= 2) szz = fma(z1, z1, szz);
     }
     if (n_obs & 1) {
       double z0, z1;
       ns.pair(z0, z1);
-      const double x0 = mu + sd * z0;
-      sum += x0; if (S >= 2) sum2 += x0 * x0;
+      sz += z0; if (S >= 2) szz = fma(z0, z0, szz);
     }
-    rho[0] = fabs(m.p[2] - sum / n_obs);
-    if (S >= 2) rho[1] = fabs(m.p[3] - sum2 / n_obs);
+    const double n = (double)n_obs;
+    rho[0] = fabs(m.p[2] - (mu + sd * sz / n));
+    if (S >= 2) rho[1] = fabs(m.p[3] - (mu * mu + (2.0 * mu * sd * sz + sd * sd * szz) / n));
   }
 };
 
@@ -195,14 +194,16 @@ struct Sim<SABC_MODEL_GAUSS2D, D, S> {
     const int n_obs = (int)m.p[0];
     const double r = m.p[1], c = sqrt(1.0 - r * r);
     NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
-    double S1 = 0, S2 = 0, Q11 = 0, Q22 = 0, Q12 = 0;
+    // e1 = za, e2 = r za + c zb: the loop sums the raw moments of (za, zb); the correlated ones follow by linearity
+    double A = 0, B = 0, AA = 0, BB = 0, AB = 0;
 #pragma unroll SABC_SIM_UNROLL
     for (int k = 0; k < n_obs; ++k) {
       double za, zb;
       ns.pair(za, zb);
-      const double e1 = za, e2 = r * za + c * zb;
-      S1 += e1; S2 += e2; Q11 += e1 * e1; Q22 += e2 * e2; Q12 += e1 * e2;
+      A += za; B += zb; AA = fma(za, za, AA); BB = fma(zb, zb, BB); AB = fma(za, zb, AB);
     }
+    const double S1 = A, S2 = r * A + c * B;
+    const double Q11 = AA, Q22 = r * r * AA + 2.0 * r * c * AB + c * c * BB, Q12 = r * AA + c * AB;
     const double m1 = S1 / n_obs, m2 = S2 / n_obs;
     const double var1 = (Q11 - S1 * m1) / (n_obs - 1), var2 = (Q22 - S2 * m2) / (n_obs - 1);
     const double cov = (Q12 - S1 * m2) / (n_obs - 1);

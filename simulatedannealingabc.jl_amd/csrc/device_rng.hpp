@@ -213,8 +213,9 @@ __device__ __forceinline__ double neg2_log_tab(double x) {
   p = fma(p, s, 0.25);
   const double l = fma(s * s, p, s);
   const double nEd = (double)nE;
-  const double hi_part = fma(nEd, 2.0 * 6.93147180369123816490e-01, e.y);   // ln2_hi has 32 trailing zero bits: exact product
-  return hi_part + fma(nEd, 2.0 * 1.90821492927058770002e-10, l);
+  // the product and the polynomial have the same sign (both >= 0 for x < 1, both <= 0 for x > 1) and the table entry is
+  // small, so one rounded product is accurate to about half an ulp of the sum: no hi/lo split of ln 2 needed
+  return fma(nEd, 2.0 * 6.93147180559945309417e-01, e.y) + l;
 }
 
 // sin and cos of 2 pi u, u in (0,1): k = rint(32 u), f = 32 u - k exact, r = (pi/16) f, |r| <= pi/32;
