@@ -461,35 +461,129 @@ static void push_history(orc_state *st, int push_rho_only) {
 /* categorical draws; realised by inverse-CDF on the running sum.      */
 /* rho is NOT permuted (:131-132 permute population and u only).       */
 /* ------------------------------------------------------------------ */
+/* ------------------------------------------------------------------ */
+/* Running sum of the resample weights.  sample(1:n, weights(w), n) (:129) is restated as n inverse-CDF draws  */
+/* on the running weight sum; WHICH floating-point running sum is part of the shared stream specification      */
+/* (DESIGN.md "RNG streams"), like the Philox counters: a sequential sum and a blocked one differ in the last    */
+/* bits, and at n ~ 5e6 that moves a few draws per resample to the neighbouring particle.  The order below is    */
+/* the one a 3-pass blocked scan produces (chunks of 1024 weights, 256 "threads" x 4 weights, 64-wide trees):    */
+/*   pass 1  chunk sums:   per thread ((w0+w1)+w2)+w3; per 64 threads the tree r[l] += r[l+off], off = 32..1;    */
+/*                         per chunk ((t0+t1)+t2)+t3                                                             */
+/*   pass 2  chunk offsets: 1024 owners of ceil(nb/1024) consecutive chunks each, sequential inside an owner,    */
+/*                         Hillis-Steele inclusive scan (offsets 1,2,..,512) across the owners; total = last     */
+/*   pass 3  inside a chunk: exclusive sequential scan of the 256 thread sums, then offset + running sum of 4    */
+/* ------------------------------------------------------------------ */
+#define ORC_SCAN_CHUNK 1024
+int64_t orc_scan_chunks(int64_t n) { return (n + ORC_SCAN_CHUNK - 1) / ORC_SCAN_CHUNK; }
+
+void orc_weight_scan(const double *w, int64_t n, double *cum, double *bs, double totals[2]) {
+  const int64_t nb = orc_scan_chunks(n);
+  double *raw = (double *)malloc(sizeof(double) * (size_t)(nb > 0 ? nb : 1));
+  double W2 = 0.0;
+  for (int64_t b = 0; b < nb; ++b) {                                   /* pass 1 */
+    double th[256];
+    for (int t = 0; t < 256; ++t) {
+      double sacc = 0.0;
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = b * ORC_SCAN_CHUNK + 4 * t + e;
+        const double wi = i < n ? w[i] : 0.0;
+        sacc += wi; W2 += wi * wi;
+      }
+      th[t] = sacc;
+    }
+    double wave[4];
+    for (int v = 0; v < 4; ++v) {
+      double r[64];
+      for (int l = 0; l < 64; ++l) r[l] = th[64 * v + l];
+      for (int off = 32; off >= 1; off >>= 1)
+        for (int l = 0; l < off; ++l) r[l] += r[l + off];
+      wave[v] = r[0];
+    }
+    raw[b] = ((wave[0] + wave[1]) + wave[2]) + wave[3];
+  }
+  {                                                                    /* pass 2 */
+    const int64_t per = (nb + 1023) / 1024;
+    double a[2][1024];
+    for (int t = 0; t < 1024; ++t) {
+      const int64_t lo = (int64_t)t * per, hi = lo + per < nb ? lo + per : nb;
+      double sacc = 0.0;
+      for (int64_t b = lo; b < hi; ++b) sacc += raw[b];
+      a[0][t] = sacc;
+    }
+    int cur = 0;
+    for (int off = 1; off < 1024; off <<= 1) {
+      for (int t = 0; t < 1024; ++t) a[1 - cur][t] = t >= off ? a[cur][t] + a[cur][t - off] : a[cur][t];
+      cur = 1 - cur;
+    }
+    totals[0] = a[cur][1023];
+    totals[1] = W2;
+    for (int t = 0; t < 1024; ++t) {
+      const int64_t lo = (int64_t)t * per, hi = lo + per < nb ? lo + per : nb;
+      double run = t > 0 ? a[cur][t - 1] : 0.0;
+      for (int64_t b = lo; b < hi; ++b) { const double v = raw[b]; bs[b] = run; run += v; }
+    }
+  }
+  for (int64_t b = 0; b < nb; ++b) {                                   /* pass 3 */
+    double th[256], ex[256];
+    for (int t = 0; t < 256; ++t) {
+      double sacc = 0.0;
+      for (int e = 0; e < 4; ++e) { const int64_t i = b * ORC_SCAN_CHUNK + 4 * t + e; sacc += i < n ? w[i] : 0.0; }
+      th[t] = sacc;
+    }
+    double run = 0.0;
+    for (int t = 0; t < 256; ++t) { ex[t] = run; run += th[t]; }
+    for (int t = 0; t < 256; ++t) {
+      double r = bs[b] + ex[t];
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = b * ORC_SCAN_CHUNK + 4 * t + e;
+        r += i < n ? w[i] : 0.0;
+        if (i < n) cum[i] = r;
+      }
+    }
+  }
+  free(raw);
+}
+
+/* first k with cum[k] > t, searched as the scan is laid out: the chunk by its offset, then inside the chunk */
+int64_t orc_resample_index(const double *cum, const double *bs, int64_t n, double t) {
+  const int64_t nb = orc_scan_chunks(n);
+  int64_t blo = 0, bhi = nb;
+  while (blo < bhi) { const int64_t mid = blo + ((bhi - blo) >> 1); if (bs[mid] > t) bhi = mid; else blo = mid + 1; }
+  const int64_t chunk = blo - 1;
+  int64_t lo = chunk * ORC_SCAN_CHUNK, hi = lo + ORC_SCAN_CHUNK;
+  if (hi > n) hi = n;
+  while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (cum[mid] > t) hi = mid; else lo = mid + 1; }
+  return lo < n ? lo : n - 1;
+}
+
 static int resample_population(orc_state *st, double delta, uint64_t iter) {
   const int64_t n = st->n; const int s = st->s, d = st->d;
   double ubar[ORC_MAX_STATS];
   col_means(st->u, n, s, ubar);                                      /* :126 */
+  double *w = (double *)malloc(sizeof(double) * (size_t)n);
   double *cum = (double *)malloc(sizeof(double) * (size_t)n);
-  double W = 0.0, W2 = 0.0;
+  double *bs = (double *)malloc(sizeof(double) * (size_t)orc_scan_chunks(n));
   for (int64_t i = 0; i < n; ++i) {                                  /* :127 */
     double acc = 0.0;
     for (int j = 0; j < s; ++j) acc += st->u[(size_t)j * n + i] * delta / ubar[j];
-    double w = exp(-acc);
-    W += w; W2 += w * w;
-    cum[i] = W;
+    w[i] = exp(-acc);
   }
+  double totals[2];
+  orc_weight_scan(w, n, cum, bs, totals);
   double *th2 = (double *)malloc(sizeof(double) * (size_t)(n * d));
   double *u2 = (double *)malloc(sizeof(double) * (size_t)(n * s));
   for (int64_t i = 0; i < n; ++i) {                                  /* :129 */
     uint32_t w4[4];
     orc_stream_block(st->cfg.seed, (uint64_t)i, ORC_PURPOSE_RESAMPLE, iter, 0, w4);
-    double t = orc_u52(w4[0], w4[1]) * W;
-    int64_t lo = 0, hi = n;                                          /* first k with cum[k] > t */
-    while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if (cum[mid] > t) hi = mid; else lo = mid + 1; }
-    int64_t idx = lo < n ? lo : n - 1;
+    const double t = orc_u52(w4[0], w4[1]) * totals[0];
+    const int64_t idx = orc_resample_index(cum, bs, n, t);
     for (int k = 0; k < d; ++k) th2[(size_t)k * n + i] = st->theta[(size_t)k * n + idx];   /* :131 */
     for (int j = 0; j < s; ++j) u2[(size_t)j * n + i] = st->u[(size_t)j * n + idx];       /* :132 */
   }
   memcpy(st->theta, th2, sizeof(double) * (size_t)(n * d));
   memcpy(st->u, u2, sizeof(double) * (size_t)(n * s));
-  st->last_ess = W * W / W2;                                         /* :134 */
-  free(cum); free(th2); free(u2);
+  st->last_ess = totals[0] * totals[0] / totals[1];                  /* :134 */
+  free(w); free(cum); free(bs); free(th2); free(u2);
   return 0;
 }
 

@@ -136,6 +136,11 @@ double orc_prior_logpdf(const orc_config *cfg, const double *theta);
 void   orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta);
 /* simulators: rho_out[s] */
 int    orc_simulate(const orc_config *cfg, const double *theta, uint64_t pid, uint64_t iter, double *rho_out);
+/* running sum of the resample weights in the specified blocked order (sabc_oracle.c) and the draw on it (:129);
+   bs needs orc_scan_chunks(n) doubles */
+int64_t orc_scan_chunks(int64_t n);
+void   orc_weight_scan(const double *w, int64_t n, double *cum, double *bs, double totals[2]);
+int64_t orc_resample_index(const double *cum, const double *bs, int64_t n, double t);
 /* lower Cholesky of d x d row-major; returns 0 or ORC_ERR_NOT_POSDEF */
 int    orc_cholesky(const double *a, int d, double *l);
 

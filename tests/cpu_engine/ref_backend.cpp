@@ -248,23 +248,20 @@ class RefBackend : public Backend {
 
   int resample_draw(const double *g, uint64_t iter) override {
     const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
-    std::vector<double> cum((size_t)N);
-    double W = 0.0, W2 = 0.0;
+    std::vector<double> w((size_t)N), cum((size_t)N), bs((size_t)orc_scan_chunks(N));
     for (int64_t gid = 0; gid < N; ++gid) {
       const int64_t r = gid / cap, o = gid - r * cap;
-      const double w = g[(r * rows_ + (rows_ - 1)) * cap + o];
-      W += w; W2 += w * w;
-      cum[(size_t)gid] = W;
+      w[(size_t)gid] = g[(r * rows_ + (rows_ - 1)) * cap + o];
     }
-    ess_ = W2 > 0 ? W * W / W2 : 0.0;
+    double totals[2];
+    orc_weight_scan(w.data(), N, cum.data(), bs.data(), totals);
+    ess_ = totals[1] > 0 ? totals[0] * totals[0] / totals[1] : 0.0;
     std::vector<double> &dst = pop_[1 - cur_];
     for (int64_t li = 0; li < sh_.n_local; ++li) {
       uint32_t w4[4];
       orc_stream_block(m_.seed, (uint64_t)(sh_.gid0 + li), ORC_PURPOSE_RESAMPLE, iter, 0, w4);
-      const double t = orc_u52(w4[0], w4[1]) * W;
-      int64_t lo = 0, hi = N;
-      while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (cum[(size_t)mid] > t) hi = mid; else lo = mid + 1; }
-      const int64_t idx = lo < N ? lo : N - 1;
+      const double t = orc_u52(w4[0], w4[1]) * totals[0];
+      const int64_t idx = orc_resample_index(cum.data(), bs.data(), N, t);
       const int64_t r = idx / cap, o = idx - r * cap;
       for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = g[(r * rows_ + row) * cap + o];
     }

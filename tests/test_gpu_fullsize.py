@@ -136,3 +136,19 @@ def test_cfg4_cfg5_fullsize_against_cpu_run(S, O, gpu, name, n, alg, prop, updat
     np.testing.assert_allclose(res.ρ, run.rho.T, rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(res.population.mean(0), run.theta.mean(1), rtol=tol)
     np.testing.assert_allclose(res.population.var(0), run.theta.var(1), rtol=tol)
+
+
+def test_resample_beyond_the_lds_index(S, O, gpu):
+    """n > 4096 * 1024 particles: the chunk offsets of the weight scan no longer fit the gather kernel's LDS copy and are
+    searched in global memory instead; same draws as the oracle (the initial resample and one in-loop resample)."""
+    from tests.cases import hip_proposal
+    n, updates = 5_000_000, 3
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    res = S.sabc(model, prior, n_particles=n, n_simulation=(updates + 1) * n, proposal=hip_proposal(S, "rw", 1), resample=n // 4, seed=SEED)
+    O.set_threads(16)
+    run = oracle_run(O, "gauss1_cfg2", n, (updates + 1) * n, prop="rw", resample=n // 4)
+    O.set_threads(1)
+    c = run.counters
+    assert (res.state.n_accept, res.state.n_resampling) == (c["n_accept"], c["n_resampling"]) and c["n_resampling"] >= 2
+    np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res.u[:, 0], run.u[0], rtol=1e-7, atol=1e-12)
