@@ -133,6 +133,12 @@ def lib():
         L.orc_prior_sample.argtypes = [C.POINTER(Config), C.c_uint64, dp]
         L.orc_simulate.argtypes = [C.POINTER(Config), dp, C.c_uint64, C.c_uint64, dp]
         L.orc_cholesky.argtypes = [dp, C.c_int, dp]
+        L.orc_scan_chunks.argtypes = [C.c_int64]
+        L.orc_scan_chunks.restype = C.c_int64
+        L.orc_weight_scan.argtypes = [dp, C.c_int64, dp, dp, dp]
+        L.orc_weight_scan.restype = None
+        L.orc_resample_index.argtypes = [dp, dp, C.c_int64, C.c_double]
+        L.orc_resample_index.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -317,6 +323,19 @@ def eps_multi(ubar, v):
     if rc:
         raise OracleError(rc, "eps_multi")
     return out
+
+
+def weight_scan(w):
+    """(cum, chunk offsets, (sum w, sum w^2)) in the specified blocked order (sabc_oracle.c: orc_weight_scan)."""
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    n = len(w)
+    cum, bs, tot = np.zeros(n), np.zeros(lib().orc_scan_chunks(n)), np.zeros(2)
+    lib().orc_weight_scan(_dp(w), n, _dp(cum), _dp(bs), _dp(tot))
+    return cum, bs, tot
+
+
+def resample_index(cum, bs, t):
+    return int(lib().orc_resample_index(_dp(cum), _dp(bs), len(cum), float(t)))
 
 
 def simulate(cfg: Config, theta, pid, it):

@@ -168,3 +168,24 @@ def test_exponential_and_lognormal_priors_against_scipy(O):
     assert O.prior_logpdf(cfg, [1.0, -1e-9]) == -math.inf and O.prior_logpdf(cfg, [2.5, 1.0]) == -math.inf
     th = np.array([O.prior_sample(cfg, i) for i in range(4000)])
     assert stats.kstest(th[:, 1], "expon", args=(0, 0.7)).pvalue > 1e-3 and th[:, 1].min() > 0
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 4099, 300_000])
+def test_weight_scan_and_resample_index(O, n):
+    """The running weight sum of the resample (:129) in its specified blocked order: equal to the exact prefix sums
+    up to rounding, total = last chunk offset + last chunk, and the draw on it is the inverse CDF (first k with
+    cum[k] > t), also across chunk boundaries and for zero weights."""
+    rng = np.random.default_rng(n)
+    w = np.exp(-rng.random(n) * 3.0)
+    if n > 4:
+        w[rng.integers(0, n, size=max(n // 50, 1))] = 0.0          # exp(-a) underflows to 0 for hopeless particles
+    cum, bs, tot = O.weight_scan(w)
+    exact = np.cumsum(w.astype(np.longdouble))
+    assert np.max(np.abs(cum - exact) / exact.clip(1e-300)) < 1e-13
+    assert tot[0] == pytest.approx(float(exact[-1]), rel=1e-14) and tot[1] == pytest.approx(float(np.sum(w * w)), rel=1e-13)
+    assert bs[0] == 0.0 and np.all(np.diff(bs) >= 0) and len(bs) == (n + 1023) // 1024
+    ts = np.concatenate([rng.random(200) * tot[0], cum[:: max(n // 37, 1)], bs, [0.0, np.nextafter(tot[0], 0)]])
+    for t in ts[ts < tot[0]]:
+        k = O.resample_index(cum, bs, t)
+        assert 0 <= k < n and cum[k] > t and (k == 0 or cum[k - 1] <= t or (k % 1024 == 0))    # chunk starts may sit one ulp off
+        assert w[k] > 0.0 or k == n - 1
