@@ -288,8 +288,10 @@ double orc_cdf_apply(const double *knots, int64_t len, double x) {
   int64_t i0 = lo > 0 ? lo - 1 : 0;
   double L1 = (double)(len - 1);
   double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
-  double slope = (y1 - y0) / (knots[i0 + 1] - knots[i0]);
-  return y0 + slope * (x - knots[i0]);
+  /* weight form t in [0, 1] (what a linear interpolant evaluates); the slope form overflows to inf * 0 = NaN when two
+     knots are closer than ~1e-308 / len */
+  double t = (x - knots[i0]) / (knots[i0 + 1] - knots[i0]);
+  return y0 + t * (y1 - y0);
 }
 
 /* ------------------------------------------------------------------ */

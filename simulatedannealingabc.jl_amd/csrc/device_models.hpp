@@ -79,8 +79,8 @@ __device__ __forceinline__ double cdf_apply(const double *__restrict__ T, int64_
   const int64_t i0 = lo > 0 ? lo - 1 : 0;
   const double L1 = (double)(len - 1);
   const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
-  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
-  return y0 + slope * (x - T[i0]);
+  const double t = (x - T[i0]) / (T[i0 + 1] - T[i0]);     // weight form, t in [0, 1]: no overflow for close knots
+  return y0 + t * (y1 - y0);
 }
 
 // ---- the same function with an index over the knot table -------------------------------------
@@ -97,8 +97,8 @@ __device__ __forceinline__ double cdf_interp(const double *__restrict__ T, int64
   const int64_t i0 = lo > 0 ? lo - 1 : 0;
   const double L1 = (double)(len - 1);
   const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
-  const double slope = (y1 - y0) / (T[i0 + 1] - T[i0]);
-  return y0 + slope * (x - T[i0]);
+  const double t = (x - T[i0]) / (T[i0 + 1] - T[i0]);     // weight form, t in [0, 1]: no overflow for close knots
+  return y0 + t * (y1 - y0);
 }
 
 // p = last index in [a, a + 2^steps) with T[p] < x, given T[a] < x (branchless count form)

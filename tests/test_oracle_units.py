@@ -189,3 +189,39 @@ def test_weight_scan_and_resample_index(O, n):
         k = O.resample_index(cum, bs, t)
         assert 0 <= k < n and cum[k] > t and (k == 0 or cum[k - 1] <= t or (k % 1024 == 0))    # chunk starts may sit one ulp off
         assert w[k] > 0.0 or k == n - 1
+
+
+def test_cdf_equals_piecewise_linear_interpolation_property(O):
+    """Property test (hypothesis): for arbitrary non-negative samples -- ties, zeros, wide dynamic range -- the oracle's
+    estimator is the piecewise-linear interpolant through (knot_k, k / (len - 1)) with flat extrapolation
+    (cdf_estimators.jl:29-42), it is monotone, and at a run of equal knots it takes the FIRST duplicate's ordinate."""
+    from hypothesis import given, settings, strategies as st
+
+    vals = st.one_of(st.floats(min_value=1e-290, max_value=1e6, allow_nan=False), st.sampled_from([0.0, 1.0, 2.5, 1e-12]))   # no denormals
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(vals, min_size=1, max_size=60), st.lists(st.floats(min_value=-1.0, max_value=2e6, allow_nan=False), min_size=1, max_size=25))
+    def check(xs, qs):
+        xs = np.array(xs)
+        if not np.any(xs > 0):
+            with pytest.raises(O.OracleError):
+                O.build_cdf(xs)
+            return
+        kn = O.build_cdf(xs)
+        pos = np.sort(xs[xs > 0])
+        np.testing.assert_array_equal(kn, np.concatenate([[0.0], pos, [1.5 * pos[-1]]]))
+        y = np.arange(len(kn)) / (len(kn) - 1)
+        q = np.sort(np.array(qs))
+        got = np.atleast_1d(O.cdf_apply(kn, q))
+        assert np.all(np.diff(got) >= -1e-15) and got[0] >= 0.0 and got[-1] <= 1.0
+        for x, g in zip(q, got):
+            if x <= 0:
+                assert g == 0.0
+            elif x >= kn[-1]:
+                assert g == 1.0
+            else:
+                i0 = int(np.searchsorted(kn, x, side="left")) - 1           # last knot < x
+                want = y[i0] + (y[i0 + 1] - y[i0]) * ((x - kn[i0]) / (kn[i0 + 1] - kn[i0]))
+                assert g == pytest.approx(want, rel=1e-12, abs=1e-15)
+
+    check()
