@@ -225,3 +225,33 @@ def test_cdf_equals_piecewise_linear_interpolation_property(O):
                 assert g == pytest.approx(want, rel=1e-12, abs=1e-15)
 
     check()
+
+
+def test_epsilon_schedules_property(O):
+    """Property test (hypothesis) of both schedules over their whole input range: the single-eps root lies in (0, ubar) and
+    satisfies eps^2 + v eps^1.5 = ubar^2 (:93); the multi-eps beta satisfies its equation (:113) for every mean in (0, 1);
+    both are monotone in ubar (a population closer to the data gets a smaller tolerance)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.floats(min_value=1e-12, max_value=1.0), st.floats(min_value=1e-3, max_value=1e3))
+    def single(ubar, v):
+        e = O.eps_single(ubar, v)
+        assert 0.0 < e < ubar
+        assert abs(e * e + v * e ** 1.5 - ubar * ubar) <= 1e-11 * ubar * ubar
+        assert O.eps_single(ubar * 1.01, v) > e
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.floats(min_value=1e-6, max_value=1.0 - 1e-6))
+    def beta(ub):
+        b = O.lib().orc_multi_eps_beta(ub)
+        if abs(b) < 1e-8:
+            assert abs(ub - 0.5) < 1e-8
+            return
+        tail = 0.0 if b > 700 else (-1.0 if b < -700 else 1.0 / math.expm1(b))       # 1 / (e^b - 1) without overflow
+        mean = 1.0 / b - tail if abs(b) > 1e-2 else 0.5 - b / 12 + b ** 3 / 720
+        assert abs(mean - ub) < 1e-10
+        assert (b > 0) == (ub < 0.5)
+
+    single()
+    beta()
