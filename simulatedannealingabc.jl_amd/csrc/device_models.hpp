@@ -256,6 +256,32 @@ __device__ __forceinline__ double xor_lane(double v) {
 // One compare-exchange step of the bitonic network.  Written with a compare and selects instead of
 // fmin / fmax: the values are never NaN, and min/max would each be preceded by a canonicalising
 // v_max_f64 x, x (a third of the sort's instructions).  Equal values may be taken from either side.
+// Lane distances 16 and 32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap (new on gfx950) exchange
+// the upper half of one register with the lower half of another.  Swapping v0's upper half (odd rows) with v1's
+// lower half (even rows) leaves every lane with BOTH elements of one pair -- the lower lanes hold the v0 pair, the
+// upper lanes the v1 pair, a = the lower lane's element, b = the upper lane's --, the pair is ordered locally, and
+// the same swap puts the elements back.  One compare per lane instead of two, no ds_bpermute / ds_swizzle round trip.
+template <int DIST>
+__device__ __forceinline__ void half_swap(double &a, double &b) {
+  static_assert(DIST == 16 || DIST == 32, "row-pair or half-wave swap");
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  if constexpr (DIST == 32) {
+    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+  } else {
+    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+  }
+  a = __hiloint2double((int)ahi, (int)alo);
+  b = __hiloint2double((int)bhi, (int)blo);
+}
+
+// One compare-exchange step of the bitonic network.  Written with a compare and selects instead of
+// fmin / fmax: the values are never NaN, and min/max would each be preceded by a canonicalising
+// v_max_f64 x, x (a third of the sort's instructions).  Equal values may be taken from either side.
 template <int K, int J>
 __device__ __forceinline__ void bitonic_step(int lane, double &v0, double &v1) {
   const bool up = ((2 * lane) & K) == 0;               // K = 128: always ascending
@@ -263,6 +289,13 @@ __device__ __forceinline__ void bitonic_step(int lane, double &v0, double &v1) {
     const bool swap = (v0 > v1) == up;                 // the lane's own pair is out of order for this direction
     const double a = swap ? v1 : v0, b = swap ? v0 : v1;
     v0 = a; v1 = b;
+  } else if constexpr ((J >> 1) >= 16) {
+    constexpr int dist = J >> 1;
+    half_swap<dist>(v0, v1);
+    const bool swap = (v0 > v1) == up;                 // (both lanes of a pair see the same direction: K > J)
+    const double a = swap ? v1 : v0, b = swap ? v0 : v1;
+    v0 = a; v1 = b;
+    half_swap<dist>(v0, v1);
   } else {
     constexpr int dist = J >> 1;
     const double p0 = xor_lane<dist>(v0), p1 = xor_lane<dist>(v1);
