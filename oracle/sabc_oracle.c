@@ -240,10 +240,11 @@ int orc_simulate(const orc_config *cfg, const double *th, uint64_t pid, uint64_t
     double SX = 0, QX = 0, SY = 0, QY = 0;
     for (int t = 0; t < n_steps; ++t) {
       double z1 = ns_next(&ns), z2 = ns_next(&ns);
-      double xy = X * Y;
-      double dX = (th[0] * X - th[1] * xy) * dt + sg * X * sq * z1;
-      double dY = (th[1] * xy - th[2] * Y) * dt + sg * Y * sq * z2;
-      X = fmax(X + dX, 0.0); Y = fmax(Y + dY, 0.0);
+      /* dX = (aX - bXY) dt + sigma X sqrt(dt) z1 = X ((a - bY) dt + sigma sqrt(dt) z1): the factored form, both
+         species from the OLD state */
+      double fx = (th[0] - th[1] * Y) * dt + sg * sq * z1;
+      double fy = (th[1] * X - th[2]) * dt + sg * sq * z2;
+      X = fmax(X + X * fx, 0.0); Y = fmax(Y + Y * fy, 0.0);
       SX += X; QX += X * X; SY += Y; QY += Y * Y;
     }
     double mX = SX / n_steps, mY = SY / n_steps;

@@ -350,18 +350,19 @@ struct Sim<SABC_MODEL_LV, D, S> {
     const int n_steps = (int)m.p[0];
     const double dt = m.p[1], sg = m.p[2];
     double X = m.p[3], Y = m.p[4];
-    const double sq = sqrt(dt);
+    const double sdt = sg * sqrt(dt);
     NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
     double SX = 0, QX = 0, SY = 0, QY = 0;
 #pragma unroll SABC_SIM_UNROLL
     for (int t = 0; t < n_steps; ++t) {
       double z1, z2;
       ns.pair(z1, z2);
-      const double xy = X * Y;
-      const double dX = (th[0] * X - th[1] * xy) * dt + sg * X * sq * z1;
-      const double dY = (th[1] * xy - th[2] * Y) * dt + sg * Y * sq * z2;
-      X = fmax(X + dX, 0.0);
-      Y = fmax(Y + dY, 0.0);
+      // dX = (aX - bXY) dt + sigma X sqrt(dt) z1 = X ((a - bY) dt + sigma sqrt(dt) z1): the factored form (14 instead
+      // of 21 operations per step), both species from the OLD state
+      const double fx = fma(sdt, z1, fma(-th[1], Y, th[0]) * dt);
+      const double fy = fma(sdt, z2, fma(th[1], X, -th[2]) * dt);
+      X = fmax(fma(X, fx, X), 0.0);
+      Y = fmax(fma(Y, fy, Y), 0.0);
       SX += X; QX += X * X; SY += Y; QY += Y * Y;
     }
     const double mX = SX / n_steps, mY = SY / n_steps;
