@@ -226,8 +226,8 @@ constexpr int kGkParticlesPerWave = 16;
 // (1 + z^2)^k as exp(k log(1 + z^2)): the argument of the log is >= 1 and normal, so the
 // table-driven log of device_rng.hpp applies (relative error ~ k log(1+z^2) * 2e-16)
 __device__ __forceinline__ double gk_quantile(const double *th, double c, double z) {
-  const double w = exp_fast(-0.5 * th[3] * neg2_log_tab(fma(z, z, 1.0)));
-  return th[0] + th[1] * (1.0 + c * tanh_abs(th[2] * z / 2.0)) * w * z;
+  const double w = exp_tab(-0.5 * th[3] * neg2_log_tab(fma(z, z, 1.0)));
+  return th[0] + th[1] * (1.0 + c * tanh_abs_tab(th[2] * z / 2.0)) * w * z;
 }
 
 // v from lane ^ DIST, DIST a compile-time power of two: DPP quad_perm for 1 and 2 (register crossbar, no

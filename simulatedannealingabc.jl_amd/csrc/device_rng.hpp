@@ -172,6 +172,7 @@ __device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
 struct RngTables {
   double2 logt[128];     // -2 x { 1/c_i rounded, -log of that }: c_i = 1 + i/128 (i < 53) or (1 + i/128)/2 (i >= 53); c_0 = 1
   double2 sct[33];       // { sin, cos } of 2 pi k / 32, k = 0..32 (row 32 = row 0)
+  double exp2t[32];      // 2^(j/32)
 };
 
 __device__ __forceinline__ RngTables &rng_tables() {
@@ -184,6 +185,7 @@ __device__ __forceinline__ void rng_tables_load() {
   RngTables &t = rng_tables();
   for (int i = threadIdx.x; i < 128; i += blockDim.x) t.logt[i] = make_double2(kLogTab[i][0], kLogTab[i][1]);
   for (int i = threadIdx.x; i < 33; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i & 31][0], kSinCosTab[i & 31][1]);
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) t.exp2t[i] = kExp2Tab[i];
 }
 
 __device__ __forceinline__ void rng_tables_init() {
@@ -240,6 +242,35 @@ __device__ __forceinline__ void sincos_2pi_tab(double u, double &sn, double &cs)
   q *= r2;                                                                // cos r - 1
   sn = sc.x + fma(sc.x, q, sc.y * sr);
   cs = sc.y + fma(sc.y, q, -(sc.x * sr));
+}
+
+// exp(x), |x| <= 700 (clamped): x = (32 e + j) ln2/32 + r with |r| <= ln2/64, exp(x) = 2^e 2^(j/32) exp(r); the integer
+// 32 e + j by the add-a-big-number trick (two's complement in the sum's low word), 2^(j/32) from the table, exp(r) by
+// its Taylor polynomial of degree 6 (remainder 4e-18).  15 VALU instructions against 21 for exp_fast, and 7 polynomial
+// constants instead of 13 (the g-and-k kernel, which calls it four times per draw pair, is short of scalar registers).
+__device__ __forceinline__ double exp_tab(double x) {
+  x = fmin(fmax(x, -700.0), 700.0);
+  const double tm = fma(x, 0x1.71547652b82fep+5, 0x1.8p52);             // 32 / ln 2
+  const double nf = tm - 0x1.8p52;
+  const int n = __double2loint(tm);
+  double r = fma(-nf, 0x1.62e42feep-6, x);                                // ln2/32, 32 significant bits: exact product
+  r = fma(-nf, 0x1.a39ef35793c76p-38, r);
+  const double t = rng_tables().exp2t[n & 31];
+  double p = 1.0 / 720.0;
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(t * p, n >> 5);
+}
+
+// tanh(y) = sign(y) (1 - 2 / (exp(2|y|) + 1)) on the table-driven exp (same error bounds as tanh_abs)
+__device__ __forceinline__ double tanh_abs_tab(double y) {
+  const double a = fmin(fabs(y), 20.0);
+  const double t = 1.0 - div_fast(2.0, exp_tab(2.0 * a) + 1.0);
+  return copysign(t, y);
 }
 
 __device__ __forceinline__ void box_muller(const u32x4 w, double &z0, double &z1) {
