@@ -99,69 +99,6 @@ __device__ __forceinline__ double log_fast(double x) {
   return fma(dk, 6.93147180369123816490e-01, (fma(s, hfsq + R, dk * 1.90821492927058770002e-10) - hfsq) + f);
 }
 
-// exp(x) for |x| <= 700: n = rint(x / ln 2), r = x - n ln 2 in two pieces, Taylor polynomial of degree 13
-// on |r| <= ln(2)/2 (remainder 4e-18), scaled by 2^n with v_ldexp_f64.  ~1 ulp.
-__device__ __forceinline__ double exp_fast(double x) {
-  x = fmin(fmax(x, -700.0), 700.0);
-  const double n = rint(x * 1.44269504088896338700e+00);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
-  r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;
-  p = fma(p, r, 1.0 / 479001600.0);
-  p = fma(p, r, 1.0 / 39916800.0);
-  p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0);
-  p = fma(p, r, 1.0 / 40320.0);
-  p = fma(p, r, 1.0 / 5040.0);
-  p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0);
-  p = fma(p, r, 1.0 / 24.0);
-  p = fma(p, r, 1.0 / 6.0);
-  p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0);
-  p = fma(p, r, 1.0);
-  return ldexp(p, (int)n);
-}
-
-// tanh(y) = sign(y) (1 - 2 / (exp(2|y|) + 1)): absolute error ~1e-16 (the relative error near 0 is not
-// controlled, which is fine where it is used: inside 1 + c tanh(.))
-__device__ __forceinline__ double tanh_abs(double y) {
-  const double a = fmin(fabs(y), 20.0);
-  const double t = 1.0 - div_fast(2.0, exp_fast(2.0 * a) + 1.0);
-  return copysign(t, y);
-}
-
-// sin and cos of 2 pi u for u in (0,1): quadrant k = rint(4u) and r = 4u - k are exact; the two
-// Taylor polynomials run on a = (pi/2) r, |a| <= pi/4
-__device__ __forceinline__ void sincos_2pi(double u, double &sn, double &cs) {
-  const double t = 4.0 * u;
-  const double kf = rint(t);
-  const double a = 1.57079632679489661923 * (t - kf);
-  const double a2 = a * a;
-  double p = -1.0 / 1307674368000.0;
-  p = fma(p, a2, 1.0 / 6227020800.0);
-  p = fma(p, a2, -1.0 / 39916800.0);
-  p = fma(p, a2, 1.0 / 362880.0);
-  p = fma(p, a2, -1.0 / 5040.0);
-  p = fma(p, a2, 1.0 / 120.0);
-  p = fma(p, a2, -1.0 / 6.0);
-  const double s = fma(a, a2 * p, a);
-  double q = 1.0 / 20922789888000.0;
-  q = fma(q, a2, -1.0 / 87178291200.0);
-  q = fma(q, a2, 1.0 / 479001600.0);
-  q = fma(q, a2, -1.0 / 3628800.0);
-  q = fma(q, a2, 1.0 / 40320.0);
-  q = fma(q, a2, -1.0 / 720.0);
-  q = fma(q, a2, 1.0 / 24.0);
-  q = fma(q, a2, -0.5);
-  const double c = fma(a2, q, 1.0);
-  const int k = (int)kf;                       // 0..4
-  const double s1 = (k & 1) ? c : s;           // odd quadrant: swap
-  const double c1 = (k & 1) ? s : c;
-  sn = (k & 2) ? -s1 : s1;                     // k = 2,3: sin flips
-  cs = ((k + 1) & 2) ? -c1 : c1;               // k = 1,2: cos flips
-}
-
 // ---- table-driven log and sin/cos for the Box-Muller pair ------------------------------------
 // The pair costs one log and one sin/cos; with two small tables in LDS (2.5 KB, rng_tables.inc, generated by
 // tools/gen_rng_tables.py) both shrink to short polynomials on a tiny argument: log 33 -> 19 VALU instructions
@@ -246,7 +183,7 @@ __device__ __forceinline__ void sincos_2pi_tab(double u, double &sn, double &cs)
 
 // exp(x), |x| <= 700 (clamped): x = (32 e + j) ln2/32 + r with |r| <= ln2/64, exp(x) = 2^e 2^(j/32) exp(r); the integer
 // 32 e + j by the add-a-big-number trick (two's complement in the sum's low word), 2^(j/32) from the table, exp(r) by
-// its Taylor polynomial of degree 6 (remainder 4e-18).  15 VALU instructions against 21 for exp_fast, and 7 polynomial
+// its Taylor polynomial of degree 6 (remainder 4e-18).  15 VALU instructions against 21 for a table-free version with a degree-13 polynomial, and 7 polynomial
 // constants instead of 13 (the g-and-k kernel, which calls it four times per draw pair, is short of scalar registers).
 __device__ __forceinline__ double exp_tab(double x) {
   x = fmin(fmax(x, -700.0), 700.0);
@@ -266,7 +203,8 @@ __device__ __forceinline__ double exp_tab(double x) {
   return ldexp(t * p, n >> 5);
 }
 
-// tanh(y) = sign(y) (1 - 2 / (exp(2|y|) + 1)) on the table-driven exp (same error bounds as tanh_abs)
+// tanh(y) = sign(y) (1 - 2 / (exp(2|y|) + 1)): absolute error ~1e-16 (the relative error near 0 is not controlled,
+// which is fine where it is used: inside 1 + c tanh(.))
 __device__ __forceinline__ double tanh_abs_tab(double y) {
   const double a = fmin(fabs(y), 20.0);
   const double t = 1.0 - div_fast(2.0, exp_tab(2.0 * a) + 1.0);

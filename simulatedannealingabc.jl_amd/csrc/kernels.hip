@@ -162,7 +162,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
 
     // ---- accept / store (:324-329) ----
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
+    const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
     if (accepted) {
 #pragma unroll
       for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
@@ -331,7 +331,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
       log_accept = lpp - prior_logpdf<D>(m, th) + a + st.logf[lane];
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
+    const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
     if (accepted) {
 #pragma unroll
       for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
