@@ -111,3 +111,15 @@ def test_rng_tables_are_what_the_generator_script_writes(tmp_path, monkeypatch):
         assert abs(-0.5 * m2inv * c - 1) < 2e-16 and abs(-0.5 * m2logc - math.log(c)) < 3e-16
     for k, (s, c) in enumerate(sct):
         assert abs(s * s + c * c - 1) < 3e-16 and abs(s - math.sin(math.pi * k / 16)) < 1e-15
+
+
+def test_bench_refuses_to_run_without_a_device():
+    """bench.py parses, imports the package and stops with a clear message when there is no GPU (no CPU path to time)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
