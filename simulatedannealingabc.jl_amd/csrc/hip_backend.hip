@@ -411,11 +411,14 @@ int HipBackend::write_control(const ControlBlock &in) {
 int HipBackend::history_reserve(int64_t rows) {
   const int row_len = kMaxStats * 3;
   if (rows > hist_cap_) {
+    // grow geometrically from 4096 rows (0.8 MB): a typical call never pays hipFree + hipMalloc inside update_population!
+    int64_t cap = hist_cap_ > 0 ? 2 * hist_cap_ : 4096;
+    if (cap < rows) cap = rows;
     HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
     if (hist_dev_) (void)hipFree(hist_dev_);
     hist_dev_ = nullptr;
-    HB_CHECK(hipMalloc((void **)&hist_dev_, (size_t)rows * row_len * sizeof(double)), "hipMalloc(history)");
-    hist_cap_ = rows;
+    HB_CHECK(hipMalloc((void **)&hist_dev_, (size_t)cap * row_len * sizeof(double)), "hipMalloc(history)");
+    hist_cap_ = cap;
   }
   return 0;
 }
