@@ -34,21 +34,35 @@ def observed_mean():
     return float(np.random.default_rng(SEED).normal(1.5, 1.0, 100).mean())
 
 
-def cpu_baseline(n, updates, threads):
+def cpu_baseline(n, updates, threads, warmup=0, steps=0):
     """The oracle (CPU restatement, NOT the Julia reference: Julia is not installed) on the host
-    cores of this box, same workload, bounded sample; update loop only, like `value`."""
+    cores of this box, same workload, bounded sample; update loop only, like `value`.
+    The first `warmup` + `steps` updates are issued exactly like the GPU's (same seed, same two calls), so that the
+    posterior moments of the two runs can be compared (BASELINE metric: "posterior-mean L2 vs ref")."""
     from oracle import oracle as O
     O.set_threads(threads)
     cfg = O.make_config(n_particles=n, n_para=1, n_stats=1, model_id=O.MODEL_GAUSS_IID,
                         model_params=[100, 1.0, observed_mean(), 0.0], prior=[(O.PRIOR_NORMAL, 0.0, 2.0)], seed=SEED)
     run = O.OracleRun(cfg)
     run.initialize(n)
+    args = lambda k: O.make_update_args(n_simulation=k * n, proposal=(O.PROP_RANDOMWALK, 0.8, 0.0), n_particles=n)
     t0 = time.perf_counter()
-    run.update(O.make_update_args(n_simulation=updates * n, proposal=(O.PROP_RANDOMWALK, 0.8, 0.0), n_particles=n))
+    same = None
+    done = 0
+    for k in (warmup, steps):
+        if k > 0 and done + k <= updates:
+            run.update(args(k))
+            done += k
+    if done == warmup + steps and done > 0:
+        th = run.theta[0]
+        same = {"mean": float(th.mean()), "var": float(th.var()), "n_accept": int(run.counters["n_accept"]), "updates": done}
+    if updates > done:
+        run.update(args(updates - done))
     dt = time.perf_counter() - t0
-    return {"value": updates * n / dt, "unit": "particle-simulations/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/sabc_oracle.c (OpenMP), cfg2 n_particles={n}, {updates} population updates, "
-                      f"{dt:.1f} s; CPU restatement, not the Julia reference"}
+    out = {"value": updates * n / dt, "unit": "particle-simulations/s", "cores": threads, "kind": "port",
+           "sample": f"oracle/sabc_oracle.c (OpenMP), cfg2 n_particles={n}, {updates} population updates, "
+                     f"{dt:.1f} s; CPU restatement, not the Julia reference"}
+    return out, same
 
 
 def load_traffic(workload_n, config="cfg2"):
@@ -259,7 +273,14 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
             # the GPU box shows 256 logical CPUs but a one-GPU job's CPU share is 16: use that many threads
             threads = min(os.cpu_count() or 1, int(os.environ.get("SABC_CPU_THREADS", "16")))
-            out["cpu_baseline"] = cpu_baseline(n, args.cpu_updates, threads)
+            out["cpu_baseline"], same = cpu_baseline(n, max(args.cpu_updates, W + K), threads, W, K)
+            if same and args.proposal == "randomwalk" and args.algorithm == "single_eps" and args.n_obs == 100:
+                gm, gv = float(th.mean()), float(th.var())
+                out["posterior_vs_cpu"] = {
+                    "gpu_mean": gm, "gpu_var": gv, "cpu_mean": same["mean"], "cpu_var": same["var"],
+                    "rel_err_mean": abs(gm / same["mean"] - 1.0), "rel_err_var": abs(gv / same["var"] - 1.0),
+                    "n_accept_equal": same["n_accept"] == c["n_accept"], "updates": same["updates"],
+                    "note": "same seed, same calls on the CPU restatement (oracle); the north star asks for moments within 1 %"}
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:
