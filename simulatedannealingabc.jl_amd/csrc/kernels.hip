@@ -68,7 +68,11 @@ __device__ __forceinline__ void moment_terms(const double *__restrict__ pivot, b
 __device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 
 __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint64_t j) {
-  int64_t r = (int64_t)(j / (uint64_t)pv.m_full);
+  if (pv.world == 1) return pv.base + pv.off_last + (int64_t)j;        // one shard: no 64-bit division (uniform branch)
+  // shard index j / m_full without a 64-bit integer division: j < 2^53, so the f64 quotient is off by at most one
+  int64_t r = (int64_t)((double)j / (double)pv.m_full);
+  if (r * pv.m_full > (int64_t)j) r -= 1;
+  else if ((r + 1) * pv.m_full <= (int64_t)j) r += 1;
   if (r > pv.world - 1) r = pv.world - 1;
   const int64_t o = (int64_t)j - r * pv.m_full;
   const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
