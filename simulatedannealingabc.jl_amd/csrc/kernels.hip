@@ -67,6 +67,16 @@ __device__ __forceinline__ void moment_terms(const double *__restrict__ pivot, b
 
 __device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 
+// (gid / cap, gid % cap) for 0 <= gid < 2^53 without a 64-bit integer division (~100 instructions on this ISA): one
+// shard needs none (gid < cap), several take the f64 quotient, which is off by at most one, and correct it
+__device__ __forceinline__ void split_index(int64_t gid, int64_t cap, int64_t &r, int64_t &o) {
+  if (gid < cap) { r = 0; o = gid; return; }
+  r = (int64_t)((double)gid / (double)cap);
+  if (r * cap > gid) r -= 1;
+  else if ((r + 1) * cap <= gid) r += 1;
+  o = gid - r * cap;
+}
+
 __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint64_t j) {
   if (pv.world == 1) return pv.base + pv.off_last + (int64_t)j;        // one shard: no 64-bit division (uniform branch)
   // shard index j / m_full without a 64-bit integer division: j < 2^53, so the f64 quotient is off by at most one
@@ -732,7 +742,8 @@ k_resample_weights(const int d, const int s, const PopPtrs pp, const ControlBloc
 }
 
 __device__ __forceinline__ double gathered_weight(const double *g, int rows, int64_t cap, int64_t gid) {
-  const int64_t r = gid / cap, o = gid - r * cap;
+  int64_t r, o;
+  split_index(gid, cap, r, o);
   return g[(r * rows + (rows - 1)) * cap + o];
 }
 
@@ -866,7 +877,8 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
     if (cum[mid] > t) hi = mid; else lo = mid + 1;
   }
   const int64_t idx = lo < n ? lo : n - 1;
-  const int64_t r = idx / cap, o = idx - r * cap;
+  int64_t r, o;
+  split_index(idx, cap, r, o);
   for (int row = 0; row < d + s; ++row)
     dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
 }
@@ -917,7 +929,8 @@ k_compact_column(const double *__restrict__ g, const int s, const int stat, cons
                  double *__restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= n) return;
-  const int64_t r = gid / cap, o = gid - r * cap;
+  int64_t r, o;
+  split_index(gid, cap, r, o);
   out[gid] = g[(r * s + stat) * cap + o];
 }
 
