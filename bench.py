@@ -99,6 +99,63 @@ def load_sq_summary(workload_n, config="cfg2"):
         return {}
 
 
+def launch_ranks(n, argv, timeout_s):
+    """Start `n` fresh rank processes of this script (one per GPU, LOCAL_RANK = RANK = 0..n-1, rendezvous on 127.0.0.1),
+    relay rank 0's JSON line, and return the exit code.  A rank that fails takes the others down; ranks still running at
+    the deadline are killed (exact PIDs) and the code is 124.  The parent never imports torch or touches HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", "2")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    deadline = time.monotonic() + timeout_s
+    code = 0
+    try:
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [c for c in states if c not in (None, 0)]
+            if bad:
+                code = bad[0] if bad[0] > 0 else 1
+                print(f"[bench] a rank exited with code {bad[0]}; stopping the others", file=sys.stderr, flush=True)
+                break
+            if all(c == 0 for c in states):
+                break
+            if time.monotonic() > deadline:
+                code = 124
+                print(f"[bench] ranks still running after {timeout_s:.0f} s; killing them", file=sys.stderr, flush=True)
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        out0 = ""
+        for r, p in enumerate(procs):
+            try:
+                o, _ = p.communicate(timeout=30)
+            except Exception:
+                o = ""
+            if r == 0:
+                out0 = o or ""
+    if code == 0:
+        lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+        if not lines:
+            print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+            return 1
+        print(lines[-1], flush=True)
+    elif out0.strip():
+        print(out0, file=sys.stderr, flush=True)
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,7 +174,16 @@ def main():
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=100, help="population updates of the CPU baseline sample (~15 s on 16 cores)")
+    ap.add_argument("--allow-hooks", action="store_true",
+                    help="with --dist-backend nccl: keep going when RCCL could not be bound inside the library and the "
+                         "collectives fell back to the torch.distributed hooks (default: exit non-zero)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 without a launcher: deadline for the ranks (s)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without torch.distributed.run: start the N ranks ourselves -- BEFORE anything in this
+    # process imports torch or touches HIP (a process that has initialised the GPU must not fork/exec workers)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
     import torch
     import torch.distributed as dist
@@ -127,8 +193,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let bench.py start them: "
+                         f"run it without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the SABC engine has no CPU path")
     device = local_rank % torch.cuda.device_count()      # == local_rank on a node with one GPU per rank
@@ -169,6 +235,14 @@ def main():
     if world > 1:
         from sabc_amd.dist import install_collectives
         transport = install_collectives(h, device)
+        if args.dist_backend == "nccl" and transport != "rccl" and not args.allow_hooks:
+            # every rank takes the same branch (install_collectives agrees on the transport across ranks)
+            print(f"[bench] rank {rank}: RCCL could not be bound inside the library, the collectives fell back to "
+                  f"'{transport}' (Python in the per-update path): not measuring that silently; --allow-hooks overrides",
+                  file=sys.stderr, flush=True)
+            h.close()
+            dist.destroy_process_group()
+            raise SystemExit(3)
     t_init0 = time.perf_counter()
     h.initialize(n)
     torch.cuda.synchronize()
@@ -184,6 +258,7 @@ def main():
     h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else 1))
     barrier()
     syncs0 = h.host_syncs
+    comm0 = h.comm_bytes
     resampling0 = h.counters["n_resampling"]
     t0 = time.perf_counter()
     h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
@@ -195,6 +270,7 @@ def main():
         dt = float(t.item())
 
     syncs = h.host_syncs - syncs0
+    comm_bytes = h.comm_bytes - comm0
     kern_ms, launches = h.profile_get(S._lib.KERNEL_UPDATE)
     red_ms, red_n = h.profile_get(S._lib.KERNEL_REDUCE)
     res_ms, res_n = h.profile_get(S._lib.KERNEL_RESAMPLE)
@@ -261,6 +337,9 @@ def main():
             # the bound that actually binds: k_update's in-kernel normal rate against the bare Philox + Box-Muller
             # loop measured on this GPU right now (same lane count, same pairs per lane, nothing else in the loop)
             "valu_roofline": valu,
+            # bytes landing in one shard's receive buffers per population update (allreduce of the fused sums; DE / Stretch:
+            # two allgathers of the inactive halves; on resamples the weight row and the rows the shard drew)
+            "comm_bytes_per_step": comm_bytes / K,
             "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": c["n_resampling"] - resampling0,

@@ -111,6 +111,11 @@ typedef struct {
    `stream` is the hipStream_t the library enqueues its kernels on. */
 typedef int (*sabc_allreduce_fn)(void *ctx, void *buf, int64_t count_f64, void *stream);
 typedef int (*sabc_allgather_fn)(void *ctx, const void *send, void *recv, int64_t count_f64_per_rank, void *stream);
+/* personalised exchange (optional; the sharded resample uses it to fetch only the rows it drew, :129-132):
+   send_counts[p] doubles go to rank p, taken from consecutive segments of `send`; recv_counts[p] arrive from rank p into
+   consecutive segments of `recv`.  The count arrays (length `world`) are host memory. */
+typedef int (*sabc_alltoallv_fn)(void *ctx, const void *send, const int64_t *send_counts, void *recv,
+                                 const int64_t *recv_counts, int32_t world, void *stream);
 
 /* The user's f_dist (SimulatedAnnealingABC.jl:164,175,315) as a host callback, for models that are not
    device-coded: called with the m proposals that passed the prior gate (theta column-major m x d,
@@ -130,6 +135,10 @@ SABC_API const char *sabc_last_error(const sabc_handle *h);
 SABC_API int         sabc_set_stream(sabc_handle *h, void *hip_stream);
 SABC_API int         sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx,
                                           int device_buffers);
+/* after sabc_set_collectives: same ctx and buffer kind.  Without it a resample allgathers the whole population. */
+SABC_API int         sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn);
+/* bytes that landed in this shard's receive buffers through the collectives since sabc_create */
+SABC_API int64_t     sabc_comm_bytes(const sabc_handle *h);
 SABC_API int         sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx);   /* SABC_MODEL_HOST */
 SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
 SABC_API int         sabc_comm_unique_id(void *out_128b);
@@ -142,6 +151,12 @@ SABC_API int sabc_initialize(sabc_handle *h, int64_t n_simulation);
 /* update_population!(), SimulatedAnnealingABC.jl:251-402: proposals.jl call + update_proposal!,
    per-particle body :308-331, resample :124-137, eps schedules :92-117, histories :367-382. */
 SABC_API int sabc_update(sabc_handle *h, const sabc_update_args *args);
+/* Error contract of sabc_update: argument errors (SABC_ERR_BAD_V / _BAD_DELTA / _BAD_BETA / _BAD_CONFIG) leave the
+   handle untouched.  A failure inside the loop (device-side SABC_ERR_ZERO_MEAN_U / _NOT_POSDEF, a failing callback or
+   collective) drains the queue, puts counters, epsilon and histories back to their values at entry -- the reference
+   works on copies and leaves its state untouched when it throws (:264-267, :387-397) -- and, because the particles were
+   updated in place on the device, the handle then refuses sabc_update (SABC_ERR_STATE) until sabc_set_population has
+   restored them. */
 
 /* ---- result / state (SABCresult :55-60, SABCstate :28-42) ---- */
 SABC_API int64_t sabc_n_local(const sabc_handle *h);          /* particles held by this shard */

@@ -59,6 +59,8 @@ class UpdateArgs(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                           C.c_int32, C.c_void_p)
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))
 
@@ -120,6 +122,8 @@ def bind(L, strict=True):
         "sabc_last_error": ([vp], C.c_char_p),
         "sabc_set_stream": ([vp, vp], C.c_int),
         "sabc_set_collectives": ([vp, ALLREDUCE_FN, ALLGATHER_FN, vp, C.c_int], C.c_int),
+        "sabc_set_alltoallv": ([vp, ALLTOALLV_FN], C.c_int),
+        "sabc_comm_bytes": ([vp], C.c_int64),
         "sabc_set_host_simulator": ([vp, SIMULATE_FN, vp], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),
         "sabc_comm_unique_id": ([vp], C.c_int),

@@ -33,6 +33,20 @@ class CallbackCollectives : public Collectives {
  public:
   CallbackCollectives(HipBackend *be, int world, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, bool dev)
       : be_(be), world_(world), ar_(ar), ag_(ag), ctx_(ctx), dev_(dev) {}
+  void set_alltoallv(sabc_alltoallv_fn fn) { a2a_ = fn; }
+  bool has_alltoallv() const override { return a2a_ != nullptr; }
+  int alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) override {
+    if (!a2a_) return -1;
+    if (dev_) return a2a_(ctx_, send, sc, recv, rc, world_, (void *)be_->stream());
+    int64_t ns = 0, nr = 0;
+    for (int p = 0; p < world_; ++p) { ns += sc[p]; nr += rc[p]; }
+    double *h = be_->host_stage(ns + nr + 2);
+    if (ns > 0 && hipMemcpyAsync(h, send, (size_t)ns * sizeof(double), hipMemcpyDeviceToHost, be_->stream()) != hipSuccess) return -1;
+    if (hipStreamSynchronize(be_->stream()) != hipSuccess) return -1;
+    if (a2a_(ctx_, h, sc, h + ns, rc, world_, nullptr)) return -1;
+    if (nr > 0 && hipMemcpyAsync(recv, h + ns, (size_t)nr * sizeof(double), hipMemcpyHostToDevice, be_->stream()) != hipSuccess) return -1;
+    return hipStreamSynchronize(be_->stream()) == hipSuccess ? 0 : -1;
+  }
   int allreduce_sum(double *buf, int64_t count) override {
     if (dev_) return ar_(ctx_, buf, count, (void *)be_->stream());
     double *h = be_->host_stage(count);
@@ -57,6 +71,7 @@ class CallbackCollectives : public Collectives {
   int world_;
   sabc_allreduce_fn ar_;
   sabc_allgather_fn ag_;
+  sabc_alltoallv_fn a2a_ = nullptr;
   void *ctx_;
   bool dev_;
 };
@@ -71,6 +86,10 @@ struct RcclApi {
   int (*CommDestroy)(void *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
 };
 
 RcclApi *rccl_api() {
@@ -89,6 +108,10 @@ RcclApi *rccl_api() {
       api.CommDestroy = (int (*)(void *))dlsym(api.lib, "ncclCommDestroy");
       api.AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclAllReduce");
       api.AllGather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t))dlsym(api.lib, "ncclAllGather");
+      api.Send = (int (*)(const void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclSend");
+      api.Recv = (int (*)(void *, size_t, int, int, void *, hipStream_t))dlsym(api.lib, "ncclRecv");
+      api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+      api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
     }
   }
   return (api.lib && api.GetUniqueId && api.CommInitRank && api.AllReduce && api.AllGather) ? &api : nullptr;
@@ -96,7 +119,25 @@ RcclApi *rccl_api() {
 
 class RcclCollectives : public Collectives {
  public:
-  RcclCollectives(HipBackend *be, void *comm) : be_(be), comm_(comm) {}
+  RcclCollectives(HipBackend *be, void *comm, int world) : be_(be), comm_(comm), world_(world) {}
+  bool has_alltoallv() const override {
+    RcclApi *a = rccl_api();
+    return a && a->Send && a->Recv && a->GroupStart && a->GroupEnd;
+  }
+  // grouped ncclSend / ncclRecv, one pair per peer with a non-empty segment (ncclFloat64 = 8)
+  int alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) override {
+    RcclApi *a = rccl_api();
+    if (a->GroupStart()) return -1;
+    int bad = 0;
+    int64_t so = 0, ro = 0;
+    for (int p = 0; p < world_; ++p) {
+      if (sc[p] > 0) bad |= a->Send(send + so, (size_t)sc[p], 8, p, comm_, be_->stream());
+      if (rc[p] > 0) bad |= a->Recv(recv + ro, (size_t)rc[p], 8, p, comm_, be_->stream());
+      so += sc[p]; ro += rc[p];
+    }
+    const int end = a->GroupEnd();
+    return (bad || end) ? -1 : 0;
+  }
   ~RcclCollectives() override {
     RcclApi *a = rccl_api();
     if (a && a->CommDestroy && comm_) a->CommDestroy(comm_);
@@ -111,6 +152,7 @@ class RcclCollectives : public Collectives {
  private:
   HipBackend *be_;
   void *comm_;
+  int world_;
 };
 
 int usable_device(int device, std::string &why) {
@@ -209,6 +251,16 @@ int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn
   return 0;
 }
 
+int sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn) {
+  if (!h || !fn) return hset(h, SABC_ERR_COMM, "null collective hook");
+  CallbackCollectives *c = dynamic_cast<CallbackCollectives *>(h->coll);
+  if (!c) return hset(h, SABC_ERR_COMM, "sabc_set_alltoallv needs the hooks of sabc_set_collectives to be installed first");
+  c->set_alltoallv(fn);
+  return 0;
+}
+
+int64_t sabc_comm_bytes(const sabc_handle *h) { return h ? h->eng->comm_bytes() : 0; }
+
 int sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx) {
   if (!h || !fn) return hset(h, SABC_ERR_BAD_CONFIG, "null host simulator");
   if (h->eng->model().model_id != SABC_MODEL_HOST) return hset(h, SABC_ERR_BAD_CONFIG, "the handle was not created with SABC_MODEL_HOST");
@@ -233,35 +285,52 @@ int sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b) {
   const Shard &sh = h->eng->shard();
   if (a->CommInitRank(&comm, sh.world, id, sh.rank) != 0) return hset(h, SABC_ERR_COMM, "ncclCommInitRank failed");
   delete h->coll;
-  h->coll = new RcclCollectives(h->be, comm);
+  h->coll = new RcclCollectives(h->be, comm, sh.world);
   h->eng->set_collectives(h->coll);
   return 0;
 }
 
-// Exercise the installed collectives once (allreduce of rank+1, allgather of rank-tagged words) and
-// check the result on the host: validates the transport before the first population update.
+// Exercise the installed collectives once and check the result on the host: an allgather of an odd-sized block (5
+// doubles: not a multiple of any vector width), an allreduce, and -- when the transport has one -- a personalised
+// exchange with a different segment length for every (sender, receiver) pair, as the resample issues it.
+// Validates the transport before the first population update.
 int sabc_comm_selftest(sabc_handle *h) {
   if (!h) return SABC_ERR_STATE;
   const Shard &sh = h->eng->shard();
   if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
-  const int world = sh.world;
-  double *g = h->be->gather_buffer((int64_t)(world + 1) * 4);
+  const int world = sh.world, B = 5;
+  if (world == 1) return 0;
+  double *g = h->be->gather_buffer((int64_t)(world + 1) * B);
   if (!g) return hset(h, SABC_ERR_HIP, "out of memory for the self-test buffer");
-  double send[4] = {(double)(sh.rank + 1), 2.0, 3.0, (double)(100 + sh.rank)};
-  std::vector<double> back((size_t)(world + 1) * 4, 0.0);
-  hipStream_t s = h->be->stream();
-  if (hipMemcpyAsync(g, send, sizeof(send), hipMemcpyHostToDevice, s) != hipSuccess) return hset(h, SABC_ERR_HIP, "memcpy failed");
-  if (world > 1) {
-    if (h->coll->allgather(g, g + 4, 4)) return hset(h, SABC_ERR_COMM, "self-test allgather failed");
-    if (h->coll->allreduce_sum(g, 4)) return hset(h, SABC_ERR_COMM, "self-test allreduce failed");
-  }
-  if (hipMemcpyAsync(back.data(), g, back.size() * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess) return hset(h, SABC_ERR_HIP, "memcpy failed");
-  if (hipStreamSynchronize(s) != hipSuccess) return hset(h, SABC_ERR_HIP, "stream sync failed");
-  if (world > 1) {
-    if (back[0] != 0.5 * world * (world + 1) || back[1] != 2.0 * world) return hset(h, SABC_ERR_COMM, "self-test allreduce gave a wrong sum");
-    for (int r = 0; r < world; ++r)
-      if (back[4 + 4 * r] != (double)(r + 1) || back[4 + 4 * r + 3] != (double)(100 + r))
-        return hset(h, SABC_ERR_COMM, "self-test allgather gave wrong words");
+  double send[B] = {(double)(sh.rank + 1), 2.0, 3.0, (double)(100 + sh.rank), -1.5};
+  std::vector<double> back((size_t)(world + 1) * B, 0.0);
+  if (h->be->to_backend(g, send, B)) return hfail(h, SABC_ERR_HIP);
+  if (h->coll->allgather(g, g + B, B)) return hset(h, SABC_ERR_COMM, "self-test allgather failed");
+  if (h->coll->allreduce_sum(g, B)) return hset(h, SABC_ERR_COMM, "self-test allreduce failed");
+  if (h->be->to_host(back.data(), g, (int64_t)back.size())) return hfail(h, SABC_ERR_HIP);
+  if (back[0] != 0.5 * world * (world + 1) || back[1] != 2.0 * world || back[4] != -1.5 * world)
+    return hset(h, SABC_ERR_COMM, "self-test allreduce gave a wrong sum");
+  for (int r = 0; r < world; ++r)
+    if (back[B + B * r] != (double)(r + 1) || back[B + B * r + 3] != (double)(100 + r) || back[B + B * r + 4] != -1.5)
+      return hset(h, SABC_ERR_COMM, "self-test allgather gave wrong words");
+  if (h->coll->has_alltoallv()) {
+    // rank r sends (r + p + 1) doubles of value 1000 r + p to rank p
+    std::vector<int64_t> sc((size_t)world), rc((size_t)world);
+    int64_t ns = 0, nr = 0;
+    for (int p = 0; p < world; ++p) { sc[(size_t)p] = rc[(size_t)p] = sh.rank + p + 1; ns += sc[(size_t)p]; nr += rc[(size_t)p]; }
+    std::vector<double> out((size_t)ns), in((size_t)nr, 0.0);
+    int64_t o = 0;
+    for (int p = 0; p < world; ++p)
+      for (int64_t k = 0; k < sc[(size_t)p]; ++k) out[(size_t)o++] = 1000.0 * sh.rank + p;
+    double *ds = h->be->scratch_buffer(0, ns), *dr = h->be->scratch_buffer(1, nr);
+    if (!ds || !dr) return hset(h, SABC_ERR_HIP, "out of memory for the self-test buffer");
+    if (h->be->to_backend(ds, out.data(), ns)) return hfail(h, SABC_ERR_HIP);
+    if (h->coll->alltoallv(ds, sc.data(), dr, rc.data())) return hset(h, SABC_ERR_COMM, "self-test alltoallv failed");
+    if (h->be->to_host(in.data(), dr, nr)) return hfail(h, SABC_ERR_HIP);
+    o = 0;
+    for (int p = 0; p < world; ++p)
+      for (int64_t k = 0; k < rc[(size_t)p]; ++k)
+        if (in[(size_t)o++] != 1000.0 * p + sh.rank) return hset(h, SABC_ERR_COMM, "self-test alltoallv gave wrong words");
   }
   return 0;
 }

@@ -106,9 +106,23 @@ void Engine::history(double *e, double *u, double *r) const {
 // block partials -> shard sums (ControlBlock::sums) -> allreduce over shards; nothing is read back
 int Engine::global_reduce(int64_t rows, bool guarded) {
   if (be_->reduce_partials(rows, guarded)) return fail(SABC_ERR_HIP, "reduce_partials failed");
-  if (sh_.world > 1 && coll_->allreduce_sum(be_->sums_buffer(), np_))
+  if (sh_.world > 1 && allreduce(be_->sums_buffer(), np_))
     return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
   return 0;
+}
+
+// the collectives, with the bytes that land in this shard's receive buffers counted
+int Engine::allreduce(double *buf, int64_t count) {
+  comm_bytes_ += count * (int64_t)sizeof(double);
+  return coll_->allreduce_sum(buf, count);
+}
+int Engine::allgather(const double *send, double *recv, int64_t count_per_rank) {
+  comm_bytes_ += (int64_t)sh_.world * count_per_rank * (int64_t)sizeof(double);
+  return coll_->allgather(send, recv, count_per_rank);
+}
+int Engine::alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) {
+  for (int p = 0; p < sh_.world; ++p) comm_bytes_ += rc[p] * (int64_t)sizeof(double);
+  return coll_->alltoallv(send, sc, recv, rc);
 }
 
 int Engine::stats_reduce() {
@@ -178,15 +192,88 @@ int Engine::resample(double delta, uint64_t iter) {
   const int d = m_.d, s = m_.s;
   if (be_->resample_weights(delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :126-127
   const int64_t rows = d + s + 1;
+  if (sh_.world > 1 && coll_->has_alltoallv()) {
+    const int rc = resample_exchange(iter);
+    if (rc) return rc;
+    return stats_reduce();
+  }
   const double *gathered = be_->pop_block();
-  if (sh_.world > 1) {
+  if (sh_.world > 1) {          // transport without a personalised exchange: every shard takes the whole population
     double *g = be_->gather_buffer((int64_t)sh_.world * rows * sh_.cap);
     if (!g) return fail(SABC_ERR_HIP, "out of memory for the resample gather buffer");
-    if (coll_->allgather(be_->pop_block(), g, rows * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of the population failed");
+    if (allgather(be_->pop_block(), g, rows * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of the population failed");
     gathered = g;
   }
   if (be_->resample_draw(gathered, iter)) return fail(SABC_ERR_HIP, "resample draw kernel failed");   // :129-132
   return stats_reduce();
+}
+
+// The sharded resample without moving the population: only the WEIGHT row is gathered (n doubles instead of
+// (d + s + 1) n); every shard runs the same scan over it (bitwise identical running sums), draws the sources of its own
+// n_local offspring from the global categorical (:129), asks each owner for the rows it drew (offsets inside the owner)
+// and gets exactly those rows back (:131-132): n_local (1 + d + s) doubles cross instead of n (d + s + 1).
+int Engine::resample_exchange(uint64_t iter) {
+  const int d = m_.d, s = m_.s, W = sh_.world;
+  const int64_t row_len = d + s;
+  double *gw = be_->gather_buffer((int64_t)W * sh_.cap);
+  if (!gw) return fail(SABC_ERR_HIP, "out of memory for the weight gather buffer");
+  if (allgather(be_->pop_block() + (int64_t)row_len * sh_.cap, gw, sh_.cap)) return fail(SABC_ERR_COMM, "allgather of the weights failed");
+  if (be_->resample_select(gw, iter)) return fail(SABC_ERR_HIP, "resample select kernel failed");
+  std::vector<int64_t> sendc((size_t)W, 0), recvc((size_t)W, 0), sendr((size_t)W), recvr((size_t)W);
+  double *req = be_->scratch_buffer(0, sh_.n_local > 0 ? sh_.n_local : 1);
+  if (!req) return fail(SABC_ERR_HIP, "out of memory for the resample request buffer");
+  if (be_->resample_bucket(sendc.data(), req)) return fail(SABC_ERR_HIP, "resample bucket kernel failed");
+  host_syncs_ += 1;
+  // who asks whom for how many rows: allgather of the W counts of every shard (exact as doubles)
+  std::vector<double> cnt((size_t)W * (size_t)(W + 1), 0.0);
+  for (int p = 0; p < W; ++p) cnt[(size_t)p] = (double)sendc[(size_t)p];
+  double *cdev = be_->scratch_buffer(1, (int64_t)W * (W + 1));
+  if (!cdev) return fail(SABC_ERR_HIP, "out of memory for the resample count buffer");
+  if (be_->to_backend(cdev, cnt.data(), W)) return fail(SABC_ERR_HIP, "uploading the request counts failed");
+  if (allgather(cdev, cdev + W, W)) return fail(SABC_ERR_COMM, "allgather of the request counts failed");
+  if (be_->to_host(cnt.data() + W, cdev + W, (int64_t)W * W)) return fail(SABC_ERR_HIP, "reading the request counts failed");
+  host_syncs_ += 1;
+  int64_t R = 0;
+  for (int p = 0; p < W; ++p) {
+    recvc[(size_t)p] = (int64_t)cnt[(size_t)W + (size_t)p * W + (size_t)sh_.rank];   // what shard p asks of this one
+    if (recvc[(size_t)p] < 0 || recvc[(size_t)p] > sh_.n_global) return fail(SABC_ERR_COMM, "corrupt request count in the resample exchange");
+    R += recvc[(size_t)p];
+    sendr[(size_t)p] = sendc[(size_t)p] * row_len;
+    recvr[(size_t)p] = recvc[(size_t)p] * row_len;
+  }
+  double *req_in = be_->scratch_buffer(1, R > 0 ? R : 1);
+  double *rows_out = be_->scratch_buffer(2, R > 0 ? R * row_len : 1);
+  double *rows_in = be_->scratch_buffer(3, sh_.n_local > 0 ? sh_.n_local * row_len : 1);
+  if (!req_in || !rows_out || !rows_in) return fail(SABC_ERR_HIP, "out of memory for the resample exchange buffers");
+  if (alltoallv(req, sendc.data(), req_in, recvc.data())) return fail(SABC_ERR_COMM, "exchange of the resample requests failed");
+  if (be_->resample_serve(req_in, R, rows_out)) return fail(SABC_ERR_HIP, "resample serve kernel failed");
+  if (alltoallv(rows_out, recvr.data(), rows_in, sendr.data())) return fail(SABC_ERR_COMM, "exchange of the resampled rows failed");
+  if (be_->resample_scatter(rows_in)) return fail(SABC_ERR_HIP, "resample scatter kernel failed");
+  return 0;
+}
+
+// Partners of DifferentialEvolution / StretchMove come from the inactive halves of ALL shards
+// (proposals.jl:105-106,141).  One shard reads them in place; several gather ONLY the inactive halves
+// (d * ceil(cap / 2) doubles per shard, not the whole theta block) into [world][d][hcap].
+int Engine::partner_source(int inactive_half, PartnerView *out) {
+  if (sh_.world == 1) {
+    *out = partner_view(be_->pop_block(), 0, inactive_half);
+    return 0;
+  }
+  const int d = m_.d;
+  const int64_t hcap = sh_.cap - sh_.cap / 2;                 // the larger (second) half of a full shard
+  const int64_t h = sh_.n_local / 2;
+  const int64_t off = inactive_half == 1 ? h : 0, cnt = inactive_half == 1 ? sh_.n_local - h : h;
+  double *g = be_->gather_buffer((int64_t)(sh_.world + 1) * d * hcap);
+  if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
+  double *send = g + (int64_t)sh_.world * d * hcap;
+  if (be_->copy_rows(be_->pop_block() + off, sh_.cap, send, hcap, d, cnt)) return fail(SABC_ERR_HIP, "packing the inactive half failed");
+  if (allgather(send, g, (int64_t)d * hcap)) return fail(SABC_ERR_COMM, "allgather of the inactive halves failed");
+  PartnerView pv = partner_view(g, (int64_t)d * hcap, inactive_half);
+  pv.cap = hcap;                                              // row stride inside a gathered block
+  pv.off_full = pv.off_last = 0;                              // the blocks hold the inactive half only
+  *out = pv;
+  return 0;
 }
 
 PartnerView Engine::partner_view(const double *base, int64_t rank_stride, int inactive_half) const {
@@ -236,7 +323,7 @@ int Engine::initialize(int64_t n_simulation) {
   if (sh_.world > 1) {
     double *g = be_->gather_buffer((int64_t)sh_.world * s * sh_.cap);
     if (!g) return fail(SABC_ERR_HIP, "out of memory for the rho gather buffer");
-    if (coll_->allgather(be_->rho_block(), g, (int64_t)s * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of rho failed");
+    if (allgather(be_->rho_block(), g, (int64_t)s * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of rho failed");
     gathered_rho = g;
   }
   int any_negative = 0;
@@ -262,7 +349,6 @@ int Engine::initialize(int64_t n_simulation) {
 // one population update, enqueued only: the per-particle kernels (:304-331), the fused sums and
 // their allreduce.  Nothing is read back here.
 int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded) {
-  const int d = m_.d;
   StepArgs c;
   std::memset(&c, 0, sizeof(c));
   c.iter = iter;
@@ -279,17 +365,10 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
       const int64_t h = sh_.n_local / 2;
       for (int half = 0; half < 2; ++half) {
         const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
-        const double *base = be_->pop_block();
-        int64_t stride = 0;
-        if (sh_.world > 1) {
-          double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
-          if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
-          if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
-          base = g;
-          stride = (int64_t)d * sh_.cap;
-        }
-        if (be_->host_update_range(c, partner_view(base, stride, 1 - half), lo, cnt))
-          return fail(SABC_ERR_CALLBACK, "host-simulator update failed");
+        PartnerView pv;
+        const int rc = partner_source(1 - half, &pv);
+        if (rc) return rc;
+        if (be_->host_update_range(c, pv, lo, cnt)) return fail(SABC_ERR_CALLBACK, "host-simulator update failed");
       }
     }
     if (be_->host_stats(&rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
@@ -306,16 +385,9 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
     const int64_t h = sh_.n_local / 2;
     for (int half = 0; half < 2; ++half) {                                  // :300-304
       const int64_t lo = half == 0 ? 0 : h, cnt = half == 0 ? h : sh_.n_local - h;
-      const double *base = be_->pop_block();
-      int64_t stride = 0;
-      if (sh_.world > 1) {          // partners come from the inactive halves of ALL shards
-        double *g = be_->gather_buffer((int64_t)sh_.world * d * sh_.cap);
-        if (!g) return fail(SABC_ERR_HIP, "out of memory for the partner gather buffer");
-        if (coll_->allgather(be_->pop_block(), g, (int64_t)d * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of theta failed");
-        base = g;
-        stride = (int64_t)d * sh_.cap;
-      }
-      const PartnerView pv = partner_view(base, stride, 1 - half);
+      PartnerView pv;                                                       // partners: the inactive halves of ALL shards
+      const int rc = partner_source(1 - half, &pv);
+      if (rc) return rc;
       if (be_->update_range(c, pv, lo, cnt, rows, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
       rows += r;
     }
@@ -326,8 +398,33 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
 // ------------------------------------------------------------------------------------------
 // update_population!(), :251-402
 // ------------------------------------------------------------------------------------------
+// Error contract (include/sabc_hip.h): the reference works on copies and leaves its state untouched when it throws
+// (:264-267, :387-397).  Here the population lives on the device and is updated in place, so after a failure inside
+// the loop the queue is drained, the counters and eps are put back to their values at entry, and the handle refuses
+// further updates until the caller has restored the particles with sabc_set_population().
 int Engine::update(const sabc_update_args &a) {
-  if (!initialized_) return fail(SABC_ERR_STATE, "population is not initialized");
+  if (!initialized_) return fail(SABC_ERR_STATE, "population is not initialized (or a failed update left it half-updated: "
+                                                 "restore it with sabc_set_population)");
+  const ControlBlock at_entry = cb_;
+  const int64_t resampling_at_entry = n_resampling_;
+  const size_t hist_at_entry[3] = {eps_hist_.size(), u_hist_.size(), rho_hist_.size()};
+  const int rc = update_loop(a);
+  if (rc && rc != SABC_ERR_BAD_V && rc != SABC_ERR_BAD_DELTA && rc != SABC_ERR_BAD_BETA && rc != SABC_ERR_BAD_CONFIG) {
+    const std::string why = err_;
+    ControlBlock scratch;
+    (void)be_->read_control(&scratch);                  // blocks until everything queued ahead has run
+    cb_ = at_entry;
+    cb_.halt = 0; cb_.error = 0; cb_.hist_rows = 0;
+    n_resampling_ = resampling_at_entry;
+    eps_hist_.resize(hist_at_entry[0]); u_hist_.resize(hist_at_entry[1]); rho_hist_.resize(hist_at_entry[2]);
+    (void)be_->write_control(cb_);
+    initialized_ = false;
+    err_ = why;
+  }
+  return rc;
+}
+
+int Engine::update_loop(const sabc_update_args &a) {
   if (!(a.v > 0)) return fail(SABC_ERR_BAD_V, "Annealing speed `v` must be positive.");                 // :261
   if (!(a.delta > 0)) return fail(SABC_ERR_BAD_DELTA, "Resamping intensity `δ` must be positive.");     // :262
   if (a.proposal_kind < SABC_PROP_RANDOMWALK || a.proposal_kind > SABC_PROP_STRETCH)

@@ -20,6 +20,11 @@ class Collectives {
   // pointers are in the Backend's memory space (device memory for HipBackend)
   virtual int allreduce_sum(double *buf, int64_t count) = 0;
   virtual int allgather(const double *send, double *recv, int64_t count_per_rank) = 0;
+  // personalised exchange: send_counts[p] doubles go to rank p (consecutive segments of `send`), recv_counts[p] arrive from
+  // rank p (consecutive segments of `recv`); the count arrays are host memory.  Optional: without it the resample falls
+  // back to an allgather of the whole population.
+  virtual bool has_alltoallv() const { return false; }
+  virtual int alltoallv(const double *, const int64_t *, double *, const int64_t *) { return -1; }
 };
 
 class Backend {
@@ -31,6 +36,13 @@ class Backend {
   virtual double *rho_block() = 0;                  // [s][cap]
   virtual double *sums_buffer() = 0;                // staging for the fused sums: reduction and allreduce target
   virtual double *gather_buffer(int64_t doubles) = 0;
+  // growable scratch areas in backend memory (which = 0..3), contents not preserved across a growth
+  virtual double *scratch_buffer(int which, int64_t doubles) = 0;
+  // rows x count doubles from src (row pitch src_pitch) to dst (row pitch dst_pitch), both in backend memory, in stream order
+  virtual int copy_rows(const double *src, int64_t src_pitch, double *dst, int64_t dst_pitch, int rows, int64_t count) = 0;
+  // small host <-> backend-memory transfers that complete before they return (counts of the resample exchange)
+  virtual int to_backend(double *dst, const double *src_host, int64_t n) = 0;
+  virtual int to_host(double *dst_host, const double *src, int64_t n) = 0;
   // host-simulator mode (SABC_MODEL_HOST): f_dist is a host callback; a backend without it says so
   virtual int set_host_simulator(sabc_simulate_fn, void *) { return -1; }
   virtual int host_prior_simulate() { return -1; }                      // :172-179 with f_dist on the host
@@ -60,6 +72,16 @@ class Backend {
   // K5
   virtual int resample_weights(double delta) = 0;   // ubar comes from ControlBlock::sums
   virtual int resample_draw(const double *gathered_pop, uint64_t iter) = 0;
+  // K5 on shards without moving the whole population (SimulatedAnnealingABC.jl:129-132):
+  //  select : running sum of the gathered weights [world][cap] + this shard's n_local draws -> global source indices
+  //  bucket : group the draws by owner shard; counts_host[r] = draws owned by shard r; req_out (n_local doubles) = their
+  //           offsets inside the owner, bucket after bucket; returns after the counts are known on the host
+  //  serve  : rows (theta, u) of the CURRENT population at the m requested offsets -> rows_out, one row of d + s per request
+  //  scatter: rows_in (bucket order of `bucket`) -> the resampled population (rho is NOT permuted, :131-132)
+  virtual int resample_select(const double *gathered_w, uint64_t iter) = 0;
+  virtual int resample_bucket(int64_t *counts_host, double *req_out) = 0;
+  virtual int resample_serve(const double *req_in, int64_t m, double *rows_out) = 0;
+  virtual int resample_scatter(const double *rows_in) = 0;
   virtual double last_ess() = 0;
   // state import/export (host buffers, column-major n_local x k)
   virtual int download(double *theta, double *u, double *rho) = 0;
@@ -95,6 +117,9 @@ class Engine {
   void set_collectives(Collectives *c) { coll_ = c; }
   // how often update() had to wait for the device (one per run-ahead window), for measurement
   int64_t host_syncs() const { return host_syncs_; }
+  // bytes that landed in this shard's receive buffers through collectives so far (allreduce: the vector; allgather: all
+  // blocks; alltoallv: what arrived)
+  int64_t comm_bytes() const { return comm_bytes_; }
 
  private:
   int fail(int code, const std::string &msg) { err_ = msg; return code; }
@@ -106,7 +131,14 @@ class Engine {
   int wait_step(int64_t seq, int64_t *n_accept, int *halted);   // poll the mailbox ring
   int sync_control();                               // device -> cb_, raises device-side errors
   int resample(double delta, uint64_t iter);        // :124-137
+  int resample_exchange(uint64_t iter);             // the sharded form: weights allgather + exchange of the drawn rows
+  int allreduce(double *buf, int64_t count);        // coll_ + byte accounting
+  int allgather(const double *send, double *recv, int64_t count_per_rank);
+  int alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc);
+  // where the partners of the half batch `1 - inactive_half` are read from (all shards' inactive halves)
+  int partner_source(int inactive_half, PartnerView *pv);
   int enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded);
+  int update_loop(const sabc_update_args &a);       // update() minus the error contract
   int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
 
@@ -124,7 +156,7 @@ class Engine {
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
-  int64_t host_syncs_ = 0, notify_seq_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0;
   std::vector<double> eps_hist_, u_hist_, rho_hist_;
 };
 

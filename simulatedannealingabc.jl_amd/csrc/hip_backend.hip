@@ -33,6 +33,12 @@ HipBackend::~HipBackend() {
   double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
+  for (double *p : scratch_)
+    if (p) (void)hipFree(p);
+  if (idx_dev_) (void)hipFree(idx_dev_);
+  if (slot_dev_) (void)hipFree(slot_dev_);
+  if (bucket_dev_) (void)hipFree(bucket_dev_);
+  if (bucket_host_) (void)hipHostFree(bucket_host_);
   if (host_thp_dev_) (void)hipFree(host_thp_dev_);
   if (host_aux_dev_) (void)hipFree(host_aux_dev_);
   if (host_rho_dev_) (void)hipFree(host_rho_dev_);
@@ -140,6 +146,41 @@ double *HipBackend::gather_buffer(int64_t doubles) {
     gather_cap_ = doubles;
   }
   return gather_;
+}
+
+double *HipBackend::scratch_buffer(int which, int64_t doubles) {
+  if (which < 0 || which >= 4) return nullptr;
+  if (doubles > scratch_cap_[which]) {
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (scratch_[which]) (void)hipFree(scratch_[which]);
+    scratch_[which] = nullptr;
+    scratch_cap_[which] = 0;
+    const int64_t want = doubles + doubles / 4 + 64;       // head room: the request count of a resample varies from one to the next
+    if (hipMalloc((void **)&scratch_[which], (size_t)want * sizeof(double)) != hipSuccess) return nullptr;
+    scratch_cap_[which] = want;
+  }
+  return scratch_[which];
+}
+
+int HipBackend::copy_rows(const double *src, int64_t src_pitch, double *dst, int64_t dst_pitch, int rows, int64_t count) {
+  if (rows <= 0 || count <= 0) return 0;
+  HB_CHECK(hipMemcpy2DAsync(dst, (size_t)dst_pitch * sizeof(double), src, (size_t)src_pitch * sizeof(double),
+                            (size_t)count * sizeof(double), (size_t)rows, hipMemcpyDeviceToDevice, stream_), "copy_rows");
+  return 0;
+}
+
+int HipBackend::to_backend(double *dst, const double *src_host, int64_t n) {
+  if (n <= 0) return 0;
+  HB_CHECK(hipMemcpyAsync(dst, src_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, stream_), "to_backend");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
+}
+
+int HipBackend::to_host(double *dst_host, const double *src, int64_t n) {
+  if (n <= 0) return 0;
+  HB_CHECK(hipMemcpyAsync(dst_host, src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_), "to_host");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  return 0;
 }
 
 double *HipBackend::host_stage(int64_t doubles) {
@@ -444,6 +485,55 @@ int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
             "k_resample_gather");
   prof_end(SABC_KERNEL_RESAMPLE);
   HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
+  cur_ = nxt;
+  return 0;
+}
+
+// ---- the sharded resample (engine.cpp: resample_exchange) -------------------------------------
+int HipBackend::resample_select(const double *gathered_w, uint64_t iter) {
+  if (!idx_dev_) {
+    const size_t cap = (size_t)(sh_.cap > 0 ? sh_.cap : 1);
+    HB_CHECK(hipMalloc((void **)&idx_dev_, cap * sizeof(int64_t)), "hipMalloc(resample indices)");
+    HB_CHECK(hipMalloc((void **)&slot_dev_, cap * sizeof(int64_t)), "hipMalloc(resample slots)");
+    HB_CHECK(hipMalloc((void **)&bucket_dev_, 2 * (size_t)sh_.world * sizeof(unsigned long long)), "hipMalloc(buckets)");
+    HB_CHECK(hipHostMalloc((void **)&bucket_host_, 2 * (size_t)sh_.world * sizeof(unsigned long long)), "hipHostMalloc(buckets)");
+  }
+  prof_begin(SABC_KERNEL_RESAMPLE);
+  HB_LAUNCH(launch_weight_scan(gathered_w, 1, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, stream_), "weight scan");
+  HB_LAUNCH(launch_resample_select(m_, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(cur_), idx_dev_, stream_),
+            "k_resample_select");
+  prof_end(SABC_KERNEL_RESAMPLE);
+  HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
+  return 0;
+}
+
+int HipBackend::resample_bucket(int64_t *counts_host, double *req_out) {
+  const int W = sh_.world;
+  const size_t bytes = (size_t)W * sizeof(unsigned long long);
+  HB_CHECK(hipMemsetAsync(bucket_dev_, 0, 2 * bytes, stream_), "hipMemset(buckets)");
+  HB_LAUNCH(launch_bucket_count(idx_dev_, sh_.n_local, sh_.cap, bucket_dev_, stream_), "k_bucket_count");
+  HB_CHECK(hipMemcpyAsync(bucket_host_, bucket_dev_, bytes, hipMemcpyDeviceToHost, stream_), "memcpy(bucket counts)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  unsigned long long run = 0;
+  for (int r = 0; r < W; ++r) {
+    counts_host[r] = (int64_t)bucket_host_[r];
+    bucket_host_[W + r] = run;                       // exclusive offsets = where each bucket's cursor starts
+    run += bucket_host_[r];
+  }
+  if ((int64_t)run != sh_.n_local) { err_ = "resample_bucket: the bucket counts do not add up to n_local"; return -1; }
+  HB_CHECK(hipMemcpyAsync(bucket_dev_ + W, bucket_host_ + W, bytes, hipMemcpyHostToDevice, stream_), "memcpy(bucket cursors)");
+  HB_LAUNCH(launch_bucket_scatter(idx_dev_, sh_.n_local, sh_.cap, bucket_dev_ + W, req_out, slot_dev_, stream_), "k_bucket_scatter");
+  return 0;
+}
+
+int HipBackend::resample_serve(const double *req_in, int64_t m, double *rows_out) {
+  HB_LAUNCH(launch_resample_serve(req_in, m, m_.d + m_.s, pop_ptrs(cur_), rows_out, stream_), "k_resample_serve");
+  return 0;
+}
+
+int HipBackend::resample_scatter(const double *rows_in) {
+  const int nxt = 1 - cur_;
+  HB_LAUNCH(launch_resample_scatter(rows_in, slot_dev_, sh_.n_local, m_.d + m_.s, pop_ptrs(nxt), stream_), "k_resample_scatter");
   cur_ = nxt;
   return 0;
 }

@@ -19,6 +19,10 @@ class HipBackend : public Backend {
   double *rho_block() override { return rho_; }
   double *sums_buffer() override;
   double *gather_buffer(int64_t doubles) override;
+  double *scratch_buffer(int which, int64_t doubles) override;
+  int copy_rows(const double *src, int64_t src_pitch, double *dst, int64_t dst_pitch, int rows, int64_t count) override;
+  int to_backend(double *dst, const double *src_host, int64_t n) override;
+  int to_host(double *dst_host, const double *src, int64_t n) override;
   int set_host_simulator(sabc_simulate_fn fn, void *ctx) override { host_fn_ = fn; host_ctx_ = ctx; return 0; }
   int host_prior_simulate() override;
   int host_update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt) override;
@@ -38,6 +42,10 @@ class HipBackend : public Backend {
   int read_history(double *out, int64_t rows, int row_len) override;
   int resample_weights(double delta) override;
   int resample_draw(const double *gathered_pop, uint64_t iter) override;
+  int resample_select(const double *gathered_w, uint64_t iter) override;
+  int resample_bucket(int64_t *counts_host, double *req_out) override;
+  int resample_serve(const double *req_in, int64_t m, double *rows_out) override;
+  int resample_scatter(const double *rows_in) override;
   double last_ess() override;
   int download(double *theta, double *u, double *rho) override;
   int upload(const double *theta, const double *u, const double *rho) override;
@@ -91,6 +99,11 @@ class HipBackend : public Backend {
   int64_t hist_cap_ = 0;
   double *gather_ = nullptr;
   int64_t gather_cap_ = 0;
+  double *scratch_[4] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t scratch_cap_[4] = {0, 0, 0, 0};
+  int64_t *idx_dev_ = nullptr, *slot_dev_ = nullptr;      // sharded resample: drawn source indices, reply -> destination
+  unsigned long long *bucket_dev_ = nullptr;              // [2][world]: counts, cursors
+  unsigned long long *bucket_host_ = nullptr;             // pinned staging of the same
   double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr, *totals_host_ = nullptr;
   double *col_a_ = nullptr, *col_b_ = nullptr;
   void *sort_tmp_ = nullptr;

@@ -839,23 +839,10 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
 // (64 per chunk, 0.5 MB at n = 1e6: L2-resident) -> the 16 elements of that group (one 128-byte line).
 constexpr int kGatherCoarseMax = 4096;     // chunks held in LDS (n <= 4.2e6); beyond that bs is searched in global memory
 constexpr int kGroupsPerChunk = kScanChunk / 16;
-__global__ void __launch_bounds__(kBlock)
-k_resample_gather(const uint64_t seed, const int d, const int s, const double *__restrict__ g, const int rows,
-                  const int64_t cap, const int64_t n, const double *__restrict__ cum, const double *__restrict__ bs,
-                  const double *__restrict__ cm, const int64_t nb, const double *__restrict__ totals, const uint64_t iter,
-                  const PopPtrs dst) {
-  extern __shared__ double bs_lds[];
-  const bool in_lds = nb <= kGatherCoarseMax;
-  if (in_lds) {
-    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
-    __syncthreads();
-  }
-  const double *B = in_lds ? bs_lds : bs;
-  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (li >= dst.n_local) return;
-  const uint64_t gid = (uint64_t)(dst.gid0 + li);
-  const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
-  const double t = u52(w.x, w.y) * totals[0];
+// first index k with cum[k] > t, by the three levels described above (B = the chunk offsets, in LDS or global memory)
+__device__ __forceinline__ int64_t resample_search(const double t, const double *B, const int64_t nb,
+                                                   const double *__restrict__ cm, const double *__restrict__ cum,
+                                                   const int64_t n) {
   int64_t blo = 0, bhi = nb;              // first chunk whose offset exceeds t; bs[0] = 0 <= t
   while (blo < bhi) {
     const int64_t mid = blo + ((bhi - blo) >> 1);
@@ -876,11 +863,107 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
     const int64_t mid = lo + ((hi - lo) >> 1);
     if (cum[mid] > t) hi = mid; else lo = mid + 1;
   }
-  const int64_t idx = lo < n ? lo : n - 1;
+  return lo < n ? lo : n - 1;
+}
+
+// One shard: the draw and the gather of its rows in one kernel.  Several shards (k_resample_select): the draws only,
+// as global source indices; the rows are fetched from their owners afterwards (k_resample_serve / _scatter).
+template <bool GATHER>
+__global__ void __launch_bounds__(kBlock)
+k_resample_gather(const uint64_t seed, const int d, const int s, const double *__restrict__ g, const int rows,
+                  const int64_t cap, const int64_t n, const double *__restrict__ cum, const double *__restrict__ bs,
+                  const double *__restrict__ cm, const int64_t nb, const double *__restrict__ totals, const uint64_t iter,
+                  const PopPtrs dst, int64_t *__restrict__ idx_out) {
+  extern __shared__ double bs_lds[];
+  const bool in_lds = nb <= kGatherCoarseMax;
+  if (in_lds) {
+    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    __syncthreads();
+  }
+  const double *B = in_lds ? bs_lds : bs;
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= dst.n_local) return;
+  const uint64_t gid = (uint64_t)(dst.gid0 + li);
+  const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
+  const double t = u52(w.x, w.y) * totals[0];
+  const int64_t idx = resample_search(t, B, nb, cm, cum, n);
+  if (!GATHER) { idx_out[li] = idx; return; }
   int64_t r, o;
   split_index(idx, cap, r, o);
   for (int row = 0; row < d + s; ++row)
     dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
+}
+
+// ---- the sharded resample: requests grouped by owner, served by the owner, scattered by the requester ----
+// counts[r] += number of draws whose source lives on shard r (wave-aggregated integer atomics)
+__global__ void __launch_bounds__(kBlock)
+k_bucket_count(const int64_t *__restrict__ idx, const int64_t n_local, const int64_t cap, unsigned long long *counts) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = li < n_local;
+  int64_t r = 0, o = 0;
+  if (live) split_index(idx[li], cap, r, o);
+  unsigned long long todo = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  while (todo) {                                   // one trip per distinct owner in the wave (<= world)
+    const int leader = __ffsll((long long)todo) - 1;
+    const int64_t r0 = __shfl(r, leader, 64);
+    const unsigned long long same = __ballot(live && r == r0);
+    if (lane == leader) atomicAdd(&counts[r0], (unsigned long long)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+// cursor[r] starts at the exclusive offset of bucket r; req[pos] = offset inside the owner (exact as a double),
+// slot[pos] = the local destination the reply belongs to.  The order inside a bucket is arbitrary (atomics); it only
+// pairs a request with its reply.
+__global__ void __launch_bounds__(kBlock)
+k_bucket_scatter(const int64_t *__restrict__ idx, const int64_t n_local, const int64_t cap, unsigned long long *cursor,
+                 double *__restrict__ req, int64_t *__restrict__ slot) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = li < n_local;
+  int64_t r = 0, o = 0;
+  if (live) split_index(idx[li], cap, r, o);
+  unsigned long long todo = __ballot(live);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int64_t r0 = __shfl(r, leader, 64);
+    const unsigned long long same = __ballot(live && r == r0);
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(&cursor[r0], (unsigned long long)__popcll(same));
+    base = __shfl(base, leader, 64);
+    if (live && r == r0) {
+      const int64_t pos = (int64_t)base + __popcll(same & below);
+      req[pos] = (double)o;
+      slot[pos] = li;
+    }
+    todo &= ~same;
+  }
+}
+
+// owner side: rows_out[q][row] = pop[row][offset_q] for the m requested offsets (AoS: one contiguous row per request)
+__global__ void __launch_bounds__(kBlock)
+k_resample_serve(const double *__restrict__ req, const int64_t m, const int row_len, const PopPtrs src,
+                 double *__restrict__ rows_out) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= m * row_len) return;
+  const int64_t q = e / row_len;
+  const int row = (int)(e - q * row_len);
+  int64_t o = (int64_t)req[q];
+  o = o < 0 ? 0 : (o >= src.n_local ? src.n_local - 1 : o);      // a corrupt request must not fault
+  rows_out[e] = src.pop[(int64_t)row * src.cap + o];
+}
+
+// requester side: rows_in is in the bucket order of k_bucket_scatter
+__global__ void __launch_bounds__(kBlock)
+k_resample_scatter(const double *__restrict__ rows_in, const int64_t *__restrict__ slot, const int64_t n_local,
+                   const int row_len, const PopPtrs dst) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= n_local * row_len) return;
+  const int64_t pos = e / row_len;
+  const int row = (int)(e - pos * row_len);
+  dst.pop[(int64_t)row * dst.cap + slot[pos]] = rows_in[e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1180,8 +1263,49 @@ int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows,
   if (dst.n_local <= 0) return 0;
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
-  hipLaunchKernelGGL(k_resample_gather, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
-                     m.s, gathered, rows, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst);
+  hipLaunchKernelGGL(k_resample_gather<true>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
+                     m.s, gathered, rows, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst,
+                     (int64_t *)nullptr);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_select(const ModelDesc &m, int64_t cap, int64_t n_global, const double *cum, const double *block_sums,
+                           const double *totals, uint64_t iter, PopPtrs dst, int64_t *idx_out, hipStream_t stream) {
+  if (dst.n_local <= 0) return 0;
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
+  hipLaunchKernelGGL(k_resample_gather<false>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
+                     m.s, (const double *)nullptr, 0, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter,
+                     dst, idx_out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_bucket_count(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *counts, hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_bucket_count, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, counts);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_bucket_scatter(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *cursor, double *req,
+                          int64_t *slot, hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, cursor,
+                     req, slot);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_serve(const double *req, int64_t m, int row_len, PopPtrs src, double *rows_out, hipStream_t stream) {
+  if (m <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_serve, dim3((unsigned)n_blocks(m * row_len)), dim3(kBlock), 0, stream, req, m, row_len, src,
+                     rows_out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_scatter(const double *rows_in, const int64_t *slot, int64_t n_local, int row_len, PopPtrs dst,
+                            hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_scatter, dim3((unsigned)n_blocks(n_local * row_len)), dim3(kBlock), 0, stream, rows_in, slot,
+                     n_local, row_len, dst);
   return SABC_LAUNCH_RC();
 }
 

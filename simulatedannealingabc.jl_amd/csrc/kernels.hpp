@@ -82,6 +82,16 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
 int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
                            const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
                            hipStream_t stream);
+// K5 on shards: the draws as global source indices (no gather); requests grouped by owner shard; rows served by the
+// owner (one contiguous row of d + s doubles per request) and scattered into the requester's next population
+int launch_resample_select(const ModelDesc &m, int64_t cap, int64_t n_global, const double *cum, const double *block_sums,
+                           const double *totals, uint64_t iter, PopPtrs dst, int64_t *idx_out, hipStream_t stream);
+int launch_bucket_count(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *counts, hipStream_t stream);
+int launch_bucket_scatter(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *cursor, double *req,
+                          int64_t *slot, hipStream_t stream);
+int launch_resample_serve(const double *req, int64_t m, int row_len, PopPtrs src, double *rows_out, hipStream_t stream);
+int launch_resample_scatter(const double *rows_in, const int64_t *slot, int64_t n_local, int row_len, PopPtrs dst,
+                            hipStream_t stream);
 // K2: knots = [0; sorted positives; 1.5 max] from an ascending-sorted column         cdf_estimators.jl:29-33
 // meta[0] = number of non-positive entries, meta[1] = 1 if any entry is negative
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream);

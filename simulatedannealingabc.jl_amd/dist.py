@@ -29,7 +29,7 @@ def _host_tensor(ptr, n):
 
 
 def make_hooks(device, group=None):
-    """Return (allreduce, allgather, device_buffers) for sabc_set_collectives."""
+    """Return (allreduce, allgather, alltoallv, device_buffers) for sabc_set_collectives / sabc_set_alltoallv."""
     import torch
     import torch.distributed as dist
 
@@ -67,7 +67,20 @@ def make_hooks(device, group=None):
             print(f"[sabc] allgather hook failed: {e!r}", flush=True)
             return -1
 
-    return allreduce, allgather, on_device
+    def alltoallv(ctx, send, send_counts, recv, recv_counts, nranks, stream):
+        try:
+            sc = [int(send_counts[p]) for p in range(nranks)]
+            rc = [int(recv_counts[p]) for p in range(nranks)]
+            with stream_ctx(stream):
+                inp = tensor(send, max(sum(sc), 1))[: sum(sc)]
+                out = tensor(recv, max(sum(rc), 1))[: sum(rc)]
+                dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=group)
+            return 0
+        except Exception as e:
+            print(f"[sabc] alltoallv hook failed: {e!r}", flush=True)
+            return -1
+
+    return allreduce, allgather, alltoallv, on_device
 
 
 def _all_ok(ok, device, group=None):
@@ -81,7 +94,7 @@ def _all_ok(ok, device, group=None):
     return bool(t.item())
 
 
-def install_collectives(handle, device, group=None, prefer=None):
+def install_collectives(handle, device, group=None, prefer=None, alltoallv=True):
     """Give `handle` its allreduce / allgather.
 
     prefer="rccl": RCCL bound inside the library (ncclAllReduce / ncclAllGather enqueued on the
@@ -89,7 +102,9 @@ def install_collectives(handle, device, group=None, prefer=None):
     existing torch.distributed group.  Used by default when the group's backend is "nccl"; if any
     rank fails to set it up or the self-test fails, every rank falls back to the hooks.
     prefer="hooks": torch.distributed collectives through the C-ABI hooks (the only choice for "gloo").
-    Returns the transport in use."""
+    alltoallv=False leaves the personalised exchange out (hooks only): the resample then allgathers the whole population.
+    Returns the transport in use: "rccl", "hooks-nccl" (device pointers, Python in the per-update path) or "hooks-gloo"
+    (host staged; for tests)."""
     import os
     import torch.distributed as dist
     from .handle import rccl_unique_id
@@ -114,7 +129,9 @@ def install_collectives(handle, device, group=None, prefer=None):
                 ok = False
             if _all_ok(ok, device, group):
                 return "rccl"
-    ar, ag, on_device = make_hooks(device, group)
+    ar, ag, a2a, on_device = make_hooks(device, group)
     handle.set_collectives(ar, ag, on_device)
+    if alltoallv:
+        handle.set_alltoallv(a2a)
     handle.comm_selftest()
-    return "hooks"
+    return "hooks-nccl" if on_device else "hooks-gloo"

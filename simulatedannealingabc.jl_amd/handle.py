@@ -94,6 +94,16 @@ class SabcHandle:
         self._keep += [ar, ag]
         self._check(self._L.sabc_set_collectives(self._h, ar, ag, None, int(device_buffers)))
 
+    def set_alltoallv(self, alltoallv):
+        fn = _lib.ALLTOALLV_FN(alltoallv)
+        self._keep.append(fn)
+        self._check(self._L.sabc_set_alltoallv(self._h, fn))
+
+    @property
+    def comm_bytes(self):
+        """Bytes that landed in this shard's receive buffers through the collectives so far."""
+        return int(self._L.sabc_comm_bytes(self._h))
+
     def comm_init_rccl(self, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self._L.sabc_comm_init_rccl(self._h, C.cast(buf, C.c_void_p)))

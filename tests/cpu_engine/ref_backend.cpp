@@ -49,6 +49,18 @@ class RefBackend : public Backend {
     return gather_.data();
   }
 
+  double *scratch_buffer(int which, int64_t doubles) override {
+    if (which < 0 || which >= 4) return nullptr;
+    if ((int64_t)scratch_[which].size() < doubles) scratch_[which].resize((size_t)doubles);
+    return scratch_[which].data();
+  }
+  int copy_rows(const double *src, int64_t sp, double *dst, int64_t dp, int rows, int64_t count) override {
+    for (int r = 0; r < rows; ++r) std::memcpy(dst + (size_t)r * dp, src + (size_t)r * sp, (size_t)count * sizeof(double));
+    return 0;
+  }
+  int to_backend(double *dst, const double *src, int64_t n) override { std::memcpy(dst, src, (size_t)n * sizeof(double)); return 0; }
+  int to_host(double *dst, const double *src, int64_t n) override { std::memcpy(dst, src, (size_t)n * sizeof(double)); return 0; }
+
   int prior_simulate() override {
     const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap;
     for (int64_t li = 0; li < sh_.n_local; ++li) {
@@ -268,6 +280,50 @@ class RefBackend : public Backend {
     cur_ = 1 - cur_;
     return 0;
   }
+  // the sharded resample (engine.cpp: resample_exchange), same protocol as HipBackend
+  int resample_select(const double *gw, uint64_t iter) override {
+    const int64_t cap = sh_.cap, N = sh_.n_global;
+    std::vector<double> w((size_t)N), cum((size_t)N), bs((size_t)orc_scan_chunks(N));
+    for (int64_t gid = 0; gid < N; ++gid) { const int64_t r = gid / cap, o = gid - r * cap; w[(size_t)gid] = gw[r * cap + o]; }
+    double totals[2];
+    orc_weight_scan(w.data(), N, cum.data(), bs.data(), totals);
+    ess_ = totals[1] > 0 ? totals[0] * totals[0] / totals[1] : 0.0;
+    idx_.assign((size_t)sh_.n_local, 0);
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      uint32_t w4[4];
+      orc_stream_block(m_.seed, (uint64_t)(sh_.gid0 + li), ORC_PURPOSE_RESAMPLE, iter, 0, w4);
+      idx_[(size_t)li] = orc_resample_index(cum.data(), bs.data(), N, orc_u52(w4[0], w4[1]) * totals[0]);
+    }
+    return 0;
+  }
+  int resample_bucket(int64_t *counts, double *req) override {
+    const int W = sh_.world; const int64_t cap = sh_.cap;
+    std::vector<int64_t> cur((size_t)W, 0);
+    for (int r = 0; r < W; ++r) counts[r] = 0;
+    for (int64_t li = 0; li < sh_.n_local; ++li) counts[idx_[(size_t)li] / cap] += 1;
+    for (int r = 1; r < W; ++r) cur[(size_t)r] = cur[(size_t)r - 1] + counts[r - 1];
+    slot_.assign((size_t)sh_.n_local, 0);
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      const int64_t r = idx_[(size_t)li] / cap, pos = cur[(size_t)r]++;
+      req[pos] = (double)(idx_[(size_t)li] - r * cap);
+      slot_[(size_t)pos] = li;
+    }
+    return 0;
+  }
+  int resample_serve(const double *req, int64_t m, double *rows_out) override {
+    const int rl = m_.d + m_.s; const int64_t cap = sh_.cap;
+    for (int64_t q = 0; q < m; ++q)
+      for (int row = 0; row < rl; ++row) rows_out[q * rl + row] = pop_[cur_][(size_t)row * cap + (int64_t)req[q]];
+    return 0;
+  }
+  int resample_scatter(const double *rows_in) override {
+    const int rl = m_.d + m_.s; const int64_t cap = sh_.cap;
+    std::vector<double> &dst = pop_[1 - cur_];
+    for (int64_t pos = 0; pos < sh_.n_local; ++pos)
+      for (int row = 0; row < rl; ++row) dst[(size_t)row * cap + slot_[(size_t)pos]] = rows_in[pos * rl + row];
+    cur_ = 1 - cur_;
+    return 0;
+  }
   double last_ess() override { return ess_; }
 
   int download(double *theta, double *u, double *rho) override {
@@ -299,7 +355,8 @@ class RefBackend : public Backend {
   Shard sh_{};
   orc_config oc_{};
   int np_ = 0, rows_ = 0, cur_ = 0;
-  std::vector<double> pop_[2], rho_, knots_, partials_, gather_, hist_;
+  std::vector<double> pop_[2], rho_, knots_, partials_, gather_, hist_, scratch_[4];
+  std::vector<int64_t> idx_, slot_;
   int64_t cdf_len_[kMaxStats] = {0};
   ControlBlock cb_{};
   Mailbox ring_[kMailboxRing] = {};
@@ -315,11 +372,17 @@ class NoColl : public Collectives {
 
 class HookColl : public Collectives {
  public:
-  HookColl(sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx) : ar_(ar), ag_(ag), ctx_(ctx) {}
+  HookColl(sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, int world) : ar_(ar), ag_(ag), ctx_(ctx), world_(world) {}
+  void set_alltoallv(sabc_alltoallv_fn fn) { a2a_ = fn; }
+  bool has_alltoallv() const override { return a2a_ != nullptr; }
+  int alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) override {
+    return a2a_(ctx_, send, sc, recv, rc, world_, nullptr);
+  }
   int allreduce_sum(double *buf, int64_t count) override { return ar_(ctx_, buf, count, nullptr); }
   int allgather(const double *send, double *recv, int64_t count) override { return ag_(ctx_, send, recv, count, nullptr); }
  private:
-  sabc_allreduce_fn ar_; sabc_allgather_fn ag_; void *ctx_;
+  sabc_allreduce_fn ar_; sabc_allgather_fn ag_; void *ctx_; int world_;
+  sabc_alltoallv_fn a2a_ = nullptr;
 };
 
 thread_local std::string g_err;
@@ -361,10 +424,19 @@ const char *sabc_last_error(const sabc_handle *h) { return h ? h->err.c_str() : 
 
 int sabc_set_collectives(sabc_handle *h, sabc_allreduce_fn ar, sabc_allgather_fn ag, void *ctx, int) {
   delete h->coll;
-  h->coll = new HookColl(ar, ag, ctx);
+  h->coll = new HookColl(ar, ag, ctx, h->eng->shard().world);
   h->eng->set_collectives(h->coll);
   return 0;
 }
+
+int sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn) {
+  HookColl *c = dynamic_cast<HookColl *>(h->coll);
+  if (!c || !fn) { h->err = "sabc_set_alltoallv needs sabc_set_collectives first"; return SABC_ERR_COMM; }
+  c->set_alltoallv(fn);
+  return 0;
+}
+
+int64_t sabc_comm_bytes(const sabc_handle *h) { return h->eng->comm_bytes(); }
 
 int sabc_comm_selftest(sabc_handle *h) {
   const Shard &sh = h->eng->shard();
@@ -376,6 +448,20 @@ int sabc_comm_selftest(sabc_handle *h) {
   bool ok = g[0] == 0.5 * world * (world + 1) && g[1] == 2.0 * world;
   for (int r = 0; r < world; ++r) ok = ok && g[4 + 4 * r] == (double)(r + 1) && g[4 + 4 * r + 3] == (double)(100 + r);
   if (!ok) { h->err = "self-test collective gave wrong values"; return SABC_ERR_COMM; }
+  if (h->coll->has_alltoallv()) {
+    std::vector<int64_t> sc((size_t)world), rc((size_t)world);
+    int64_t ns = 0, nr = 0;
+    for (int p = 0; p < world; ++p) { sc[(size_t)p] = rc[(size_t)p] = sh.rank + p + 1; ns += sc[(size_t)p]; nr += rc[(size_t)p]; }
+    std::vector<double> out((size_t)ns), in((size_t)nr, 0.0);
+    int64_t o = 0;
+    for (int p = 0; p < world; ++p)
+      for (int64_t k = 0; k < sc[(size_t)p]; ++k) out[(size_t)o++] = 1000.0 * sh.rank + p;
+    if (h->coll->alltoallv(out.data(), sc.data(), in.data(), rc.data())) { h->err = "self-test alltoallv failed"; return SABC_ERR_COMM; }
+    o = 0;
+    for (int p = 0; p < world; ++p)
+      for (int64_t k = 0; k < rc[(size_t)p]; ++k)
+        if (in[(size_t)o++] != 1000.0 * p + sh.rank) { h->err = "self-test alltoallv gave wrong words"; return SABC_ERR_COMM; }
+  }
   return 0;
 }
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--n", type=int, default=1001)
     ap.add_argument("--updates", type=int, default=10)
     ap.add_argument("--resample", type=float, default=0.0)
+    ap.add_argument("--alltoallv", type=int, default=1, help="0: no personalised exchange (the resample allgathers the population)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -55,8 +56,10 @@ def main():
     alg = S._lib.ALG_MULTI_EPS if a.alg == "multi_eps" else S._lib.ALG_SINGLE_EPS
     h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
     if world > 1:
-        install_collectives(h, device)
+        transport = install_collectives(h, device, alltoallv=bool(a.alltoallv))
+        assert transport in ("rccl", "hooks-nccl", "hooks-gloo"), transport
     h.initialize((a.updates + 1) * a.n)
+    bytes_init = h.comm_bytes
     h.update(n_simulation=a.updates * a.n, proposal=hip_proposal(S, a.prop, d),
              resample=a.resample if a.resample > 0 else None)
     th, u, rho = h.get_population()
@@ -68,7 +71,8 @@ def main():
         np.savez(a.out, theta=np.concatenate([p[1] for p in parts], 1), u=np.concatenate([p[2] for p in parts], 1),
                  rho=np.concatenate([p[3] for p in parts], 1), eps=h.eps, eps_hist=e, u_hist=uh, rho_hist=rh,
                  counters=np.array([h.counters[k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]),
-                 sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]))
+                 sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]),
+                 comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]))
     dist.barrier()
     h.close()
     dist.destroy_process_group()

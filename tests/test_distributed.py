@@ -82,6 +82,37 @@ def test_cpu_engine_sharded_randomwalk_equals_single_shard(S, tmp_path, world, c
     assert list(got["offsets"]) == [r * cap for r in range(world)]
 
 
+def test_cpu_engine_resample_without_alltoallv_is_the_same_run(S, tmp_path):
+    """A transport without the personalised exchange falls back to gathering the whole population: same draws, same
+    particles, more bytes."""
+    kw = dict(engine="cpu", backend="gloo", case="gauss2_2stats", alg="multi_eps", prop="rw", n=1000, updates=8, resample=250)
+    a = launch(3, str(tmp_path / "a.npz"), alltoallv=1, **kw)
+    b = launch(3, str(tmp_path / "b.npz"), alltoallv=0, **kw)
+    assert list(a["counters"]) == list(b["counters"]) and a["counters"][2] >= 3
+    for k in ("theta", "u", "rho", "eps"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert a["comm_bytes"][1] < b["comm_bytes"][1]
+
+
+@pytest.mark.parametrize("prop,d,case", [("de", 1, "gauss1_cfg2"), ("stretch", 2, "gauss2_meansd")])
+def test_cpu_engine_comm_bytes_per_update(S, tmp_path, prop, d, case):
+    """What crosses between shards per population update, counted by the engine (sabc_comm_bytes): DE / Stretch gather
+    only the inactive halves (two allgathers of d * ceil(cap / 2) doubles per shard) + the allreduce of the fused sums --
+    half of what gathering the whole theta block twice per update took."""
+    from sabc_amd._lib import MAX_PARA  # noqa: F401
+    world, n, k = 2, 1000, 6
+    s = 1
+    got = launch(world, str(tmp_path / "o.npz"), engine="cpu", backend="gloo", case=case, prop=prop, n=n, updates=k,
+                 resample=10 * n * k)                      # no resample inside the loop
+    cap = -(-n // world)
+    hcap = cap - cap // 2
+    np_ = 1 + 2 * s + d + d * (d + 1) // 2
+    per_update = 2 * world * d * hcap * 8 + np_ * 8
+    assert got["counters"][2] == 1
+    assert int(got["comm_bytes"][1]) == k * per_update
+    assert per_update * 2 <= (2 * world * d * cap * 8 + np_ * 8) + np_ * 8 + 2 * world * d * 8   # >= 2x below the round-1 volume
+
+
 @pytest.mark.parametrize("prop", ["de", "stretch"])
 def test_cpu_engine_sharded_partner_proposals(S, O, tmp_path, prop):
     """Partners are drawn from the inactive halves of ALL shards (exact global semantics); the run is
@@ -129,7 +160,7 @@ def test_nccl_hooks_single_rank(S, gpu):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        ar, ag, on_device = make_hooks(0)
+        ar, ag, a2a, on_device = make_hooks(0)
         assert on_device
         # the library's own RCCL binding: unique id, ncclCommInitRank on a 1-rank communicator
         from tests.cases import hip_model_prior
