@@ -40,7 +40,9 @@ extern "C" {
 /* device-coded simulators: the `f_dist` argument of sabc() (SimulatedAnnealingABC.jl:451)
    as data; definitions in DESIGN.md "Simulators" */
 enum { SABC_MODEL_HOST = 0,   /* f_dist stays a host callable (sabc_set_host_simulator): any d, s within the maxima */
-       SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4 };
+       SABC_MODEL_GAUSS_IID = 1, SABC_MODEL_GAUSS2D = 2, SABC_MODEL_GK = 3, SABC_MODEL_LV = 4,
+       SABC_MODEL_USER = 5    /* f_dist as HIP source, compiled at run time into the fused update kernel
+                                 (sabc_register_device_simulator): any d, s within the maxima */ };
 /* `prior` argument as data: product of univariate families (Distributions.jl parametrisation):
    Normal(mu, sigma), Uniform(a, b), Exponential(theta = scale; second parameter unused), LogNormal(mu, sigma) */
 enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1, SABC_PRIOR_EXPONENTIAL = 2, SABC_PRIOR_LOGNORMAL = 3 };
@@ -140,6 +142,21 @@ SABC_API int         sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn);
 /* bytes that landed in this shard's receive buffers through the collectives since sabc_create */
 SABC_API int64_t     sabc_comm_bytes(const sabc_handle *h);
 SABC_API int         sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx);   /* SABC_MODEL_HOST */
+/* SABC_MODEL_USER: the user's f_dist (SimulatedAnnealingABC.jl:164,175,315) as device code.  `hip_source` is HIP C++
+   defining, at global scope,
+       __device__ void sabc_user_simulate(const double *theta,        // the d parameters
+                                          const double *params,       // sabc_config::model_params
+                                          sabc::NormalStream &rng,    // rng.next() / rng.pair(z0, z1): N(0,1) draws;
+                                                                      // rng.uniform_pair(u0, u1): U(0,1) draws
+                                          double *rho_out);           // the s non-negative distances
+   It is compiled with hipRTC for gfx950 against csrc/update_kernel.hpp -- the same propose -> simulate -> ECDF -> accept
+   kernel, reductions and Philox streams as the built-in simulators -- and must be registered before sabc_initialize.
+   On failure sabc_last_error(h) holds the compiler log. */
+SABC_API int         sabc_register_device_simulator(sabc_handle *h, const char *hip_source);
+/* the compiler stage alone (needs hipRTC but no device): 0 if `hip_source` compiles into the update kernels for (d, s);
+   the compiler log is copied into log_out (may be NULL) */
+SABC_API int         sabc_op_compile_device_simulator(const char *hip_source, int32_t d, int32_t s, char *log_out,
+                                                      int64_t log_cap);
 SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
 SABC_API int         sabc_comm_unique_id(void *out_128b);
 /* one allreduce + one allgather through the installed collectives, checked on the host */
@@ -159,6 +176,7 @@ SABC_API int sabc_update(sabc_handle *h, const sabc_update_args *args);
    restored them. */
 
 /* ---- result / state (SABCresult :55-60, SABCstate :28-42) ---- */
+SABC_API int64_t sabc_n_global(const sabc_handle *h);         /* n_particles of the whole population (all shards) */
 SABC_API int64_t sabc_n_local(const sabc_handle *h);          /* particles held by this shard */
 SABC_API int64_t sabc_local_offset(const sabc_handle *h);     /* global id of the first local particle */
 /* local shard, column-major: theta n_local x d, u n_local x s, rho n_local x s; NULL skips */

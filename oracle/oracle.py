@@ -114,6 +114,7 @@ def lib():
         L.orc_last_ess.restype = C.c_double
         L.orc_proposal_sigma.argtypes = [C.c_void_p, dp]
         L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_literal.argtypes = [C.c_int]
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_stream_block.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_u52.argtypes = [C.c_uint32, C.c_uint32]
@@ -360,3 +361,8 @@ def prior_sample(cfg: Config, pid):
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+def set_literal(on):
+    """Literal expressions instead of the rewritten ones (see sabc_oracle.c: orc_set_literal)."""
+    lib().orc_set_literal(int(bool(on)))

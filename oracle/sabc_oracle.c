@@ -48,6 +48,13 @@ struct orc_state {
 static int g_threads = 1;
 void orc_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; }
 
+/* Literal mode: where the oracle's default arithmetic was rewritten into an algebraically equal form together with the
+   device code (the factored Lotka-Volterra step, the weight form of the ECDF interpolant), switch back to the expression
+   exactly as one writes it down from the model / from Interpolations' linear interpolant.  tests/test_oracle_units.py
+   runs both and bounds the difference, so a mistake made identically in both rewrites cannot hide. */
+static int g_literal = 0;
+void orc_set_literal(int on) { g_literal = on ? 1 : 0; }
+
 static int fail(orc_state *st, int code, const char *msg) {
   if (st) { strncpy(st->err, msg, sizeof(st->err) - 1); st->err[sizeof(st->err) - 1] = 0; }
   return code;
@@ -242,9 +249,16 @@ int orc_simulate(const orc_config *cfg, const double *th, uint64_t pid, uint64_t
       double z1 = ns_next(&ns), z2 = ns_next(&ns);
       /* dX = (aX - bXY) dt + sigma X sqrt(dt) z1 = X ((a - bY) dt + sigma sqrt(dt) z1): the factored form, both
          species from the OLD state */
+      if (g_literal) {         /* Euler-Maruyama as written: X += (aX - bXY) dt + sigma X dW1,  Y += (bXY - cY) dt + sigma Y dW2 */
+        double dW1 = sq * z1, dW2 = sq * z2;
+        double nX = X + (th[0] * X - th[1] * X * Y) * dt + sg * X * dW1;
+        double nY = Y + (th[1] * X * Y - th[2] * Y) * dt + sg * Y * dW2;
+        X = fmax(nX, 0.0); Y = fmax(nY, 0.0);
+      } else {
       double fx = (th[0] - th[1] * Y) * dt + sg * sq * z1;
       double fy = (th[1] * X - th[2]) * dt + sg * sq * z2;
       X = fmax(X + X * fx, 0.0); Y = fmax(Y + Y * fy, 0.0);
+      }
       SX += X; QX += X * X; SY += Y; QY += Y * Y;
     }
     double mX = SX / n_steps, mY = SY / n_steps;
@@ -291,6 +305,7 @@ double orc_cdf_apply(const double *knots, int64_t len, double x) {
   double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
   /* weight form t in [0, 1] (what a linear interpolant evaluates); the slope form overflows to inf * 0 = NaN when two
      knots are closer than ~1e-308 / len */
+  if (g_literal) return y0 + (x - knots[i0]) * ((y1 - y0) / (knots[i0 + 1] - knots[i0]));   /* slope form */
   double t = (x - knots[i0]) / (knots[i0 + 1] - knots[i0]);
   return y0 + t * (y1 - y0);
 }

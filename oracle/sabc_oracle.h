@@ -117,6 +117,8 @@ const double *orc_cdf_knots(const orc_state *st, int stat);
 double orc_last_ess(const orc_state *st);
 void orc_proposal_sigma(const orc_state *st, double *out /* d*d */);
 void orc_set_threads(int nthreads);
+/* 1: literal expressions (unfactored Lotka-Volterra step, slope-form interpolation) instead of the rewritten ones */
+void orc_set_literal(int on);
 
 /* ---- unit functions (each cites the reference lines it restates) ---- */
 void   orc_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]);

@@ -11,14 +11,14 @@ from .api import (SABCresult, SABCstate, initialization, is_logging, load_result
 from .distributions import Exponential, LogNormal, Normal, Product, Uniform, product_distribution  # noqa: F401
 from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
                      op_normal_pairs, op_philox, op_rng_peak)
-from .models import DeviceDistance, GandK, Gaussian2D, GaussianIID, HostDistance, LotkaVolterra  # noqa: F401
+from .models import DeviceDistance, DeviceSource, GandK, Gaussian2D, GaussianIID, HostDistance, LotkaVolterra  # noqa: F401
 from .proposals import DifferentialEvolution, Proposal, RandomWalk, StretchMove  # noqa: F401
 
 __all__ = [
     "sabc", "update_population_", "initialization", "save_result", "load_result", "SABCresult", "SABCstate", "SABCError",
     "RandomWalk", "DifferentialEvolution", "StretchMove", "Proposal",
     "Normal", "Uniform", "Exponential", "LogNormal", "Product", "product_distribution",
-    "DeviceDistance", "HostDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",
+    "DeviceDistance", "DeviceSource", "HostDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",
     "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox", "op_normal_pairs", "op_rng_peak",
     "build", "lib", "is_logging",
 ]

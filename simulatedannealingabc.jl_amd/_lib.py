@@ -17,7 +17,7 @@ HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
 ABI_VERSION = 1
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
-MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
+MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL = 0, 1, 2, 3
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
@@ -125,11 +125,14 @@ def bind(L, strict=True):
         "sabc_set_alltoallv": ([vp, ALLTOALLV_FN], C.c_int),
         "sabc_comm_bytes": ([vp], C.c_int64),
         "sabc_set_host_simulator": ([vp, SIMULATE_FN, vp], C.c_int),
+        "sabc_register_device_simulator": ([vp, C.c_char_p], C.c_int),
+        "sabc_op_compile_device_simulator": ([C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),
         "sabc_comm_unique_id": ([vp], C.c_int),
         "sabc_comm_selftest": ([vp], C.c_int),
         "sabc_initialize": ([vp, C.c_int64], C.c_int),
         "sabc_update": ([vp, C.POINTER(UpdateArgs)], C.c_int),
+        "sabc_n_global": ([vp], C.c_int64),
         "sabc_n_local": ([vp], C.c_int64),
         "sabc_local_offset": ([vp], C.c_int64),
         "sabc_get_population": ([vp, dp, dp, dp], C.c_int),

@@ -136,15 +136,11 @@ def _dist_env(distributed):
     return 0, 1, None
 
 
-_HOST_WRAPPERS = {}
-
-
 def as_host_distance(f_dist, prior, args=(), kwargs=None):
     """Wrap a plain callable as a HostDistance.  Like the reference (:163-165) the number of statistics is
-    found by calling it once on a draw from the prior; that call is not counted as a simulation (:213-214)."""
-    key = (id(f_dist), id(prior))
-    if key in _HOST_WRAPPERS and _HOST_WRAPPERS[key].fn is f_dist:
-        return _HOST_WRAPPERS[key]
+    found by calling it once on a draw from the prior; that call is not counted as a simulation (:213-214).
+    The wrapper lives on the SABCresult it initialises (`update_population_` finds it there): nothing is cached
+    per process, so a prior of another dimension can never meet a stale wrapper and no closure outlives its result."""
     rng = np.random.default_rng()
     draw = {_lib.PRIOR_NORMAL: lambda a, b: rng.normal(a, b), _lib.PRIOR_UNIFORM: lambda a, b: rng.uniform(a, b),
             _lib.PRIOR_EXPONENTIAL: lambda a, b: rng.exponential(a), _lib.PRIOR_LOGNORMAL: lambda a, b: rng.lognormal(a, b)}
@@ -152,8 +148,29 @@ def as_host_distance(f_dist, prior, args=(), kwargs=None):
     probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
     hd = HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
                       univariate=prior.univariate, args=args, kwargs=kwargs)
-    _HOST_WRAPPERS[key] = hd
     return hd
+
+
+def progress_chunk(n_pop, cph, show_checkpoint, show_progressbar):
+    """Progress output needs the device loop to come up for air: `update_population!` is split into chunks of population
+    updates.  Chunks are multiples of `checkpoint_history`, which leaves counters, histories and particles exactly as in
+    one call (the final history push of :378-382 then never fires in between); a checkpoint interval is a multiple of the
+    chunk.  The Julia wrapper has the same function."""
+    chunk = n_pop
+    if math.isfinite(show_checkpoint) and show_checkpoint >= 1:
+        k = int(show_checkpoint)
+        if k % cph == 0:
+            chunk = min(chunk, k)
+    if show_progressbar and n_pop > 0:
+        bar = max(cph, (n_pop // 50) // cph * cph)
+        if chunk < n_pop:                                  # both: a bar step that divides the checkpoint interval
+            while chunk % bar != 0 and bar > cph:
+                bar -= cph
+            if chunk % bar == 0:
+                chunk = bar
+        else:
+            chunk = min(chunk, bar)
+    return max(chunk, 1)
 
 
 def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.1, algorithm="single_eps",
@@ -232,33 +249,29 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
     n_global = h.cfg.n_particles
     if resample is None:
         resample = 2 * n_global                                                        # :255
+    explicit_checkpoint = show_checkpoint is not None
+    if show_progressbar is None:
+        show_progressbar = not is_logging(sys.stderr)                                  # :257
     if show_checkpoint is None:
-        show_checkpoint = math.inf                                                     # quiet by default (the reference logs every 100 when not on a TTY)
+        show_checkpoint = 100 if is_logging(sys.stderr) else math.inf                  # :258
     # the reference starts from the arrays held by the result (:264-267): push them to the device
     th = res.population.reshape(1, -1) if res._prior.univariate else np.ascontiguousarray(res.population.T)
     h.set_population(th, np.ascontiguousarray(res.u.T), np.ascontiguousarray(res.ρ.T))
 
     n_pop = n_simulation // n_global                                                   # :275
-    # Progress output needs the loop to come up for air: the call is split into chunks that are multiples
-    # of checkpoint_history, which leaves counters, histories and particles exactly as in one call.
-    if show_progressbar is None:
-        show_progressbar = not is_logging(sys.stderr)                                  # :257
     cph = max(int(checkpoint_history), 1)
-    chunk = n_pop
-    if math.isfinite(show_checkpoint) and show_checkpoint >= 1:
-        k = int(show_checkpoint)
-        if k % cph == 0:
-            chunk = k
-        else:
+    if math.isfinite(show_checkpoint) and show_checkpoint >= 1 and int(show_checkpoint) % cph != 0:
+        if explicit_checkpoint:
             warnings.warn("show_checkpoint is not a multiple of checkpoint_history; progress lines are disabled")
+        show_checkpoint = math.inf
     pbar = None
     if show_progressbar and n_pop > 0:
         try:
             from tqdm import tqdm
             pbar = tqdm(total=n_pop, desc=f"{n_pop} population updates:", file=sys.stderr)   # :290-291
-            chunk = min(chunk, max(cph, (n_pop // 50) // cph * cph))
         except ImportError:
             pbar = None
+    chunk = progress_chunk(n_pop, cph, show_checkpoint, pbar is not None)
     done, t0 = 0, time.time()
     while True:
         todo = min(chunk, n_pop - done) if n_pop > 0 else 0

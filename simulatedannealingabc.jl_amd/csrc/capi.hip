@@ -14,6 +14,7 @@
 #include "hip_backend.hpp"
 #include "host_math.hpp"
 #include "kernels.hpp"
+#include "rtc.hpp"
 
 using namespace sabc;
 
@@ -261,6 +262,23 @@ int sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn) {
 
 int64_t sabc_comm_bytes(const sabc_handle *h) { return h ? h->eng->comm_bytes() : 0; }
 
+int sabc_op_compile_device_simulator(const char *hip_source, int32_t d, int32_t s, char *log_out, int64_t log_cap) {
+  if (!hip_source) { g_err = "null device simulator source"; return SABC_ERR_BAD_CONFIG; }
+  std::string log;
+  size_t cs = 0;
+  const int rc = rtc_compile(hip_source, d, s, rtc_default_csrc_dir(), nullptr, &log, &cs);
+  if (log_out && log_cap > 0) { std::snprintf(log_out, (size_t)log_cap, "%s", log.c_str()); }
+  if (rc) { g_err = "compiling the device simulator failed:\n" + log; return SABC_ERR_BAD_CONFIG; }
+  return 0;
+}
+
+int sabc_register_device_simulator(sabc_handle *h, const char *hip_source) {
+  if (!h || !hip_source) return hset(h, SABC_ERR_BAD_CONFIG, "null device simulator source");
+  if (h->eng->model().model_id != SABC_MODEL_USER) return hset(h, SABC_ERR_BAD_CONFIG, "the handle was not created with SABC_MODEL_USER");
+  h->err.clear();
+  return h->be->register_device_simulator(hip_source) ? hfail(h, SABC_ERR_BAD_CONFIG) : 0;
+}
+
 int sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx) {
   if (!h || !fn) return hset(h, SABC_ERR_BAD_CONFIG, "null host simulator");
   if (h->eng->model().model_id != SABC_MODEL_HOST) return hset(h, SABC_ERR_BAD_CONFIG, "the handle was not created with SABC_MODEL_HOST");
@@ -349,6 +367,7 @@ int sabc_update(sabc_handle *h, const sabc_update_args *args) {
   return rc ? hfail(h, rc) : 0;
 }
 
+int64_t sabc_n_global(const sabc_handle *h) { return h ? h->eng->shard().n_global : 0; }
 int64_t sabc_n_local(const sabc_handle *h) { return h ? h->eng->shard().n_local : 0; }
 int64_t sabc_local_offset(const sabc_handle *h) { return h ? h->eng->shard().gid0 : 0; }
 

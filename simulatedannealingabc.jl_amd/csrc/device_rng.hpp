@@ -6,8 +6,13 @@
 // iteration, purpose).  One block = 128 bits = two 52-bit uniforms = one Box-Muller pair.
 // Keyed by GLOBAL particle id, so a run does not depend on how particles are sharded.
 #pragma once
+#if !defined(__HIPCC_RTC__)     // hipRTC pre-includes the HIP runtime
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
+#ifndef INFINITY                 // hipRTC has no <math.h>
+#define INFINITY (__builtin_huge_val())
+#endif
 
 namespace sabc {
 
@@ -231,6 +236,12 @@ struct NormalStream {
       : seed(seed_), pid(pid_), iter(iter_), purpose(purpose_), k(0), spare(0.0), have(false) {}
   __device__ __forceinline__ void pair(double &z0, double &z1) {  // consumes one whole block
     box_muller(stream_block(seed, pid, purpose, iter, k++), z0, z1);
+  }
+  // two U(0,1) draws from one whole block (the 52-bit uniforms the Box-Muller pair would have been made of)
+  __device__ __forceinline__ void uniform_pair(double &u0, double &u1) {
+    const u32x4 w = stream_block(seed, pid, purpose, iter, k++);
+    u0 = u52(w.x, w.y);
+    u1 = u52(w.z, w.w);
   }
   __device__ __forceinline__ double next() {
     if (have) { have = false; return spare; }

@@ -48,6 +48,7 @@ int Engine::validate() {
   host_mode_ = cfg_.model_id == SABC_MODEL_HOST;
   switch (cfg_.model_id) {
     case SABC_MODEL_HOST:
+    case SABC_MODEL_USER:
       ok = true;                                   // any d, s within the maxima; f_dist is the caller's
       break;
     case SABC_MODEL_GAUSS_IID:

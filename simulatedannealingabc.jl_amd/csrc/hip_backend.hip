@@ -49,6 +49,7 @@ HipBackend::~HipBackend() {
   if (cb_host_) (void)hipHostFree(cb_host_);
   if (mbox_host_) (void)hipHostFree(mbox_host_);
   if (totals_host_) (void)hipHostFree(totals_host_);
+  rtc_release(&rtc_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -299,9 +300,23 @@ int HipBackend::host_stats(int64_t *rows_out) {
   return 0;
 }
 
+int HipBackend::register_device_simulator(const char *hip_source) {
+  if (m_.model_id != SABC_MODEL_USER) { err_ = "the handle was not created with SABC_MODEL_USER"; return -1; }
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  if (stream_) HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  rtc_release(&rtc_);
+  std::string log;
+  if (rtc_build(hip_source, m_.d, m_.s, rtc_default_csrc_dir(), &rtc_, &log)) {
+    err_ = "compiling the device simulator failed:\n" + log;
+    return -1;
+  }
+  return 0;
+}
+
 int HipBackend::prior_simulate() {
+  if (m_.model_id == SABC_MODEL_USER && !rtc()) { err_ = "no device simulator registered (sabc_register_device_simulator)"; return -1; }
   prof_begin(SABC_KERNEL_INIT);
-  HB_LAUNCH(launch_prior_simulate(m_, pop_ptrs(cur_), stream_), "k_prior_simulate");
+  HB_LAUNCH(launch_prior_simulate(m_, pop_ptrs(cur_), stream_, rtc()), "k_prior_simulate");
   prof_end(SABC_KERNEL_INIT);
   return 0;
 }
@@ -359,13 +374,13 @@ int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t l
     else if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) e = EvPair{nullptr, nullptr};
     if (e.a && e.b) { ev_[SABC_KERNEL_UPDATE].push_back(e); ev0 = e.a; ev1 = e.b; }
   }
-  HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_, ev0, ev1), "k_update");
+  HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_, ev0, ev1, rtc()), "k_update");
   *rows_out = rows;
   return 0;
 }
 
 int HipBackend::stats(int64_t *rows_out) {
-  HB_LAUNCH(launch_stats(m_, cb_dev_, pop_ptrs(cur_), partials_, stream_), "k_stats");
+  HB_LAUNCH(launch_stats(m_, cb_dev_, pop_ptrs(cur_), partials_, stream_, rtc()), "k_stats");
   *rows_out = n_blocks(sh_.n_local);
   return 0;
 }
@@ -611,7 +626,7 @@ int HipBackend::simulate_host(const double *theta, int64_t n, uint64_t pid0, uin
   HB_CHECK(hipMalloc((void **)&d_in, (size_t)n * m_.d * sizeof(double)), "hipMalloc");
   HB_CHECK(hipMalloc((void **)&d_out, (size_t)n * m_.s * sizeof(double)), "hipMalloc");
   int rc = check(hipMemcpyAsync(d_in, theta, (size_t)n * m_.d * sizeof(double), hipMemcpyHostToDevice, stream_), "memcpy");
-  if (!rc) rc = check((hipError_t)launch_simulate_batch(m_, d_in, n, pid0, iter, d_out, stream_), "k_simulate_batch");
+  if (!rc) rc = check((hipError_t)launch_simulate_batch(m_, d_in, n, pid0, iter, d_out, stream_, rtc()), "k_simulate_batch");
   if (!rc) rc = check(hipMemcpyAsync(rho_out, d_out, (size_t)n * m_.s * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
   if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   (void)hipFree(d_in); (void)hipFree(d_out);

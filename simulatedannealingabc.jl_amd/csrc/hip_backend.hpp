@@ -24,6 +24,8 @@ class HipBackend : public Backend {
   int to_backend(double *dst, const double *src_host, int64_t n) override;
   int to_host(double *dst_host, const double *src, int64_t n) override;
   int set_host_simulator(sabc_simulate_fn fn, void *ctx) override { host_fn_ = fn; host_ctx_ = ctx; return 0; }
+  // SABC_MODEL_USER: compile the simulator source into the update kernels (rtc.hpp); the compiler log goes to error()
+  int register_device_simulator(const char *hip_source);
   int host_prior_simulate() override;
   int host_update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt) override;
   int host_stats(int64_t *rows_out) override;
@@ -116,6 +118,8 @@ class HipBackend : public Backend {
   double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr;
   unsigned long long *host_acc_dev_ = nullptr;
   int ensure_host_buffers();
+  RtcKernels rtc_;                                        // SABC_MODEL_USER: kernels compiled from the user's source
+  const RtcKernels *rtc() const { return rtc_.module ? &rtc_ : nullptr; }
   int prof_ = 0, prof_open_ = -1;
   struct EvPair { hipEvent_t a, b; };
   std::vector<EvPair> ev_[SABC_KERNEL_COUNT];

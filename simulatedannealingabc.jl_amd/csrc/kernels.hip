@@ -13,194 +13,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include "control.hpp"
-#include "device_models.hpp"
-#include "kernels.hpp"
+#include "update_kernel.hpp"
 
 namespace sabc {
-
-// ------------------------------------------------------------------------------------------
-// block reduction of NP per-lane values: wave shuffles, then LDS across the 4 wavefronts
-// ------------------------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], double *__restrict__ out) {
-  __shared__ double sm[kBlock / 64][NP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // step-major order: the NP shuffles of one step are independent and go out back to back (one LDS round trip per
-  // step instead of one per step AND column -- 6 instead of 6 NP dependent trips at the end of every wave's life)
-  double v[NP];
-#pragma unroll
-  for (int c = 0; c < NP; ++c) v[c] = acc[c];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double t[NP];
-#pragma unroll
-    for (int c = 0; c < NP; ++c) t[c] = __shfl_down(v[c], off, 64);
-#pragma unroll
-    for (int c = 0; c < NP; ++c) v[c] += t[c];
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int c = 0; c < NP; ++c) sm[wave][c] = v[c];
-  }
-  __syncthreads();
-  if (threadIdx.x < NP) {
-    const int c = threadIdx.x;
-    out[c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
-  }
-}
-
-template <int D, int S>
-__device__ __forceinline__ void moment_terms(const double *__restrict__ pivot, bool accepted, const double *th,
-                                             const double *u, const double *rho, double (&acc)[n_partials(D, S)]) {
-  acc[0] = accepted ? 1.0 : 0.0;
-#pragma unroll
-  for (int j = 0; j < S; ++j) { acc[1 + j] = u[j]; acc[1 + S + j] = rho[j]; }
-  double dk[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) { dk[k] = th[k] - pivot[k]; acc[1 + 2 * S + k] = dk[k]; }
-  int q = 1 + 2 * S + D;
-#pragma unroll
-  for (int k = 0; k < D; ++k)
-#pragma unroll
-    for (int l = 0; l <= k; ++l) acc[q++] = dk[k] * dk[l];
-}
-
-__device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
-
-// (gid / cap, gid % cap) for 0 <= gid < 2^53 without a 64-bit integer division (~100 instructions on this ISA): one
-// shard needs none (gid < cap), several take the f64 quotient, which is off by at most one, and correct it
-__device__ __forceinline__ void split_index(int64_t gid, int64_t cap, int64_t &r, int64_t &o) {
-  if (gid < cap) { r = 0; o = gid; return; }
-  r = (int64_t)((double)gid / (double)cap);
-  if (r * cap > gid) r -= 1;
-  else if ((r + 1) * cap <= gid) r += 1;
-  o = gid - r * cap;
-}
-
-__device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint64_t j) {
-  if (pv.world == 1) return pv.base + pv.off_last + (int64_t)j;        // one shard: no 64-bit division (uniform branch)
-  // shard index j / m_full without a 64-bit integer division: j < 2^53, so the f64 quotient is off by at most one
-  int64_t r = (int64_t)((double)j / (double)pv.m_full);
-  if (r * pv.m_full > (int64_t)j) r -= 1;
-  else if ((r + 1) * pv.m_full <= (int64_t)j) r += 1;
-  if (r > pv.world - 1) r = pv.world - 1;
-  const int64_t o = (int64_t)j - r * pv.m_full;
-  const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
-  return pv.base + r * pv.rank_stride + off + o;
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
-//     + fused block partials.   SimulatedAnnealingABC.jl:308-331
-// ------------------------------------------------------------------------------------------
-template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(kBlock, 4)
-k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
-         const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
-  constexpr int NP = n_partials(D, S);
-  if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
-  rng_tables_load();
-  __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
-  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
-  __syncthreads();                         // publishes both the generator tables and the index
-  double acc[NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
-
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t < act_n) {
-    const int64_t li = act_lo + t;
-    const uint64_t gid = (uint64_t)(pp.gid0 + li);
-    double th[D], u[S], rho[S];
-#pragma unroll
-    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
-      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
-    }
-
-    // ---- proposal (:311) ----
-    double thp[D];
-    double logf = 0.0;
-    if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
-      NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
-      double z[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) z[k] = ns.next();
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
-        thp[k] = th[k] + a;
-      }
-    } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
-      uint64_t i1 = 0, i2 = 0;
-      for (uint32_t a = 0;; ++a) {                 // :103-107, redraw both until distinct
-        const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
-        i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
-        i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
-        if (i1 != i2 || a > 64u) break;
-      }
-      double z0, z1;
-      box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
-      const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);      // :110
-      const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
-#pragma unroll
-      for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
-    } else {                                       // StretchMove, proposals.jl:137-148
-      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
-      const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
-      const double U = u52(w.z, w.w);
-      const double a = c.prop_p0;
-      const double tt = (a - 1.0) * U + 1.0;
-      const double z = tt * tt / a;                                          // :144
-      const double *p = partner_ptr(pv, ip);
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double pk = p[(int64_t)k * pv.cap];
-        thp[k] = pk + z * (th[k] - pk);                                      // :147
-      }
-      logf = log(z) * (double)(D - 1);                                       // :146
-    }
-
-    // ---- acceptance probability (:314-322) ----
-    const double lpp = prior_logpdf<D>(m, thp);
-    double log_accept = -INFINITY;
-    double up[S], rp[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
-    if (lpp > -INFINITY) {
-      Sim<MODEL, D, S>::run(m, thp, gid, c.iter, rp);                        // :315
-      double a = 0.0;
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        up[j] = cdf_apply_3level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
-                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
-        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
-        a += (u[j] - up[j]) / e;                                             // :319
-      }
-      log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
-    }
-
-    // ---- accept / store (:324-329) ----
-    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
-    if (accepted) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        u[j] = up[j]; rho[j] = rp[j];
-        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
-        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
-      }
-    }
-    moment_terms<D, S>(cb->pivot, accepted, th, u, rho, acc);
-  }
-  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
-}
 
 // ------------------------------------------------------------------------------------------
 // g-and-k (BASELINE config 4): wave-per-particle variants.  A block of 4 waves covers
@@ -383,34 +198,56 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   }
 }
 
-// one wave per row of theta: used for the prior sample at initialization and for sabc_op_simulate
+// one wave per row of theta: used for the prior sample at initialization and for sabc_op_simulate.
+// Same phase structure as k_update_gk: lanes 0..15 draw / load the parameters of the wave's 16 particles in parallel
+// (the prior draw is four Philox blocks + Box-Muller pairs per particle: done by all 64 lanes for one particle at a
+// time it cost more than the simulation itself -- 1.8 ms for the 1e6 simulations k_update_gk does in 0.7 ms), the whole
+// wave then simulates them one after the other, lanes 0..15 store.
 __global__ void __launch_bounds__(kBlock)
 k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int64_t n, const int64_t stride,
               const uint64_t pid0, const uint64_t iter, const int sample_prior, double *__restrict__ theta_out,
               double *__restrict__ rho_out, const int64_t out_stride) {
-  constexpr int D = kGkD, S = kGkS;
+  constexpr int D = kGkD, S = kGkS, PW = kGkParticlesPerWave;
   rng_tables_init();
+  __shared__ double sth[kBlock / 64][PW][D];
+  __shared__ double srho[kBlock / 64][PW][S];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int it = 0; it < kGkParticlesPerWave; ++it) {
-    const int64_t i = (int64_t)blockIdx.x * kGkPerBlock + wave * kGkParticlesPerWave + it;
-    if (i >= n) break;
-    const uint64_t pid = pid0 + (uint64_t)i;
-    double th[D], rho[S];
+  const int64_t i0 = (int64_t)blockIdx.x * kGkPerBlock + wave * PW;
+  const int64_t i_mine = i0 + lane;
+  const bool mine = lane < PW && i_mine < n;
+  if (mine) {
+    double th[D];
     if (sample_prior) {
-      prior_sample<D>(m, pid, th);
+      prior_sample<D>(m, pid0 + (uint64_t)i_mine, th);
     } else {
 #pragma unroll
-      for (int k = 0; k < D; ++k) th[k] = theta_in[(int64_t)k * stride + i];
+      for (int k = 0; k < D; ++k) th[k] = theta_in[(int64_t)k * stride + i_mine];
     }
-    gk_simulate_wave<S>(m, th, pid, iter, rho);
+#pragma unroll
+    for (int k = 0; k < D; ++k) sth[wave][lane][k] = th[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int it = 0; it < PW; ++it) {
+    if (i0 + it >= n) break;                          // uniform over the wave
+    double th[D], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = sth[wave][it][k];
+    gk_simulate_wave<S>(m, th, pid0 + (uint64_t)(i0 + it), iter, rho);
     if (lane == 0) {
-      if (theta_out) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) theta_out[(int64_t)k * out_stride + i] = th[k];
-      }
-#pragma unroll
-      for (int j = 0; j < S; ++j) rho_out[(int64_t)j * out_stride + i] = rho[j];
+      for (int j = 0; j < S; ++j) srho[wave][it][j] = rho[j];
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (mine) {
+    if (theta_out) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) theta_out[(int64_t)k * out_stride + i_mine] = sth[wave][lane][k];
+    }
+#pragma unroll
+    for (int j = 0; j < S; ++j) rho_out[(int64_t)j * out_stride + i_mine] = srho[wave][lane][j];
   }
 }
 
@@ -574,29 +411,6 @@ k_stats_rt(const int d, const int s, const ControlBlock *__restrict__ cb, const 
   }
 }
 
-// moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
-template <int D, int S>
-__global__ void __launch_bounds__(kBlock)
-k_stats(const ControlBlock *__restrict__ cb, const PopPtrs pp, double *__restrict__ partials) {
-  constexpr int NP = n_partials(D, S);
-  double acc[NP];
-#pragma unroll
-  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
-  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (li < pp.n_local) {
-    double th[D], u[S], rho[S];
-#pragma unroll
-    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
-      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
-    }
-    moment_terms<D, S>(cb->pivot, false, th, u, rho, acc);
-  }
-  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
-}
-
 // fixed-order sum of the per-block partial rows: block c reduces component c
 __global__ void __launch_bounds__(kBlock)
 k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ sums,
@@ -696,24 +510,6 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
   if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
   __syncthreads();
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, stage);
-}
-
-// ------------------------------------------------------------------------------------------
-// K1: prior sample + simulate (SimulatedAnnealingABC.jl:172-179), iteration 0
-// ------------------------------------------------------------------------------------------
-template <int MODEL, int D, int S>
-__global__ void __launch_bounds__(kBlock) k_prior_simulate(const ModelDesc m, const PopPtrs pp) {
-  rng_tables_init();
-  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (li >= pp.n_local) return;
-  const uint64_t gid = (uint64_t)(pp.gid0 + li);
-  double th[D], rho[S];
-  prior_sample<D>(m, gid, th);
-  Sim<MODEL, D, S>::run(m, th, gid, 0, rho);
-#pragma unroll
-  for (int k = 0; k < D; ++k) pp.pop[(int64_t)k * pp.cap + li] = th[k];
-#pragma unroll
-  for (int j = 0; j < S; ++j) pp.rho[(int64_t)j * pp.cap + li] = rho[j];
 }
 
 // K3 over the shard: u = cdf(rho)  (:190-192)
@@ -1036,21 +832,6 @@ k_cdf_apply_matrix(const CdfPtrs cdf, const int s, const double *__restrict__ rh
     u[(int64_t)j * m + i] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rho[(int64_t)j * m + i]);
 }
 
-template <int MODEL, int D, int S>
-__global__ void __launch_bounds__(kBlock)
-k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,
-                 const uint64_t iter, double *__restrict__ rho_out) {
-  rng_tables_init();
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  double th[D], rho[S];
-#pragma unroll
-  for (int k = 0; k < D; ++k) th[k] = theta[(int64_t)k * n + i];
-  Sim<MODEL, D, S>::run(m, th, pid0 + (uint64_t)i, iter, rho);
-#pragma unroll
-  for (int j = 0; j < S; ++j) rho_out[(int64_t)j * n + i] = rho[j];
-}
-
 __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                                uint32_t *words, double *normals) {
   rng_tables_init();
@@ -1095,6 +876,17 @@ k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, ui
 // ------------------------------------------------------------------------------------------
 #define SABC_LAUNCH_RC() ((int)hipGetLastError())
 
+// launch of a kernel from the run-time compiled module of a user simulator (rtc.hpp): same argument list as the
+// template it was instantiated from; timing events ride on the dispatch packet like hipExtLaunchKernelGGL's
+template <class... A>
+static int module_launch(hipFunction_t f, unsigned grid, unsigned block, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+                         A... a) {
+  void *args[] = {(void *)&a...};
+  if (ev0)
+    return (int)hipExtModuleLaunchKernel(f, grid * block, 1, 1, block, 1, 1, 0, stream, args, nullptr, ev0, ev1, 0);
+  return (int)hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, stream, args, nullptr);
+}
+
 // dispatch on the (model, d, s) combinations that exist
 #define SABC_DISPATCH_MODEL(m, CALL)                                                              \
   do {                                                                                            \
@@ -1112,8 +904,12 @@ k_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, ui
 
 inline unsigned gk_blocks(int64_t n) { return (unsigned)((n + kGkPerBlock - 1) / kGkPerBlock); }
 
-int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
+int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream, const RtcKernels *rtc) {
   if (pp.n_local <= 0) return 0;
+  if (m.model_id == SABC_MODEL_USER) {
+    if (!rtc || !rtc->prior_simulate) return (int)hipErrorInvalidValue;
+    return module_launch(rtc->prior_simulate, (unsigned)n_blocks(pp.n_local), kBlock, stream, nullptr, nullptr, m, pp);
+  }
   if (m.model_id == SABC_MODEL_GK) {
     hipLaunchKernelGGL(k_simulate_gk, dim3(gk_blocks(pp.n_local)), dim3(kBlock), 0, stream, m, (const double *)nullptr,
                        pp.n_local, pp.cap, (uint64_t)pp.gid0, (uint64_t)0, 1, pp.pop, pp.rho, pp.cap);
@@ -1149,10 +945,14 @@ int64_t update_rows(const ModelDesc &m, int64_t act_n) {
 
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream, hipEvent_t ev0,
-                  hipEvent_t ev1) {
+                  hipEvent_t ev1, const RtcKernels *rtc) {
   if (act_n <= 0) return 0;
   const dim3 grid((unsigned)update_rows(m, act_n)), block(kBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
+  if (m.model_id == SABC_MODEL_USER) {
+    if (!rtc || c.prop_kind < 0 || c.prop_kind > 2 || !rtc->update[c.prop_kind]) return (int)hipErrorInvalidValue;
+    return module_launch(rtc->update[c.prop_kind], grid.x, kBlock, stream, ev0, ev1, m, c, cb, pp, cdf, pv, act_lo, act_n, out);
+  }
   if (m.model_id == SABC_MODEL_GK) {
     const dim3 g((unsigned)update_rows(m, act_n));
     switch (c.prop_kind) {
@@ -1208,9 +1008,14 @@ int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, doub
   return SABC_LAUNCH_RC();
 }
 
-int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream) {
+int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream,
+                 const RtcKernels *rtc) {
   if (pp.n_local <= 0) return 0;
   if (m.model_id == SABC_MODEL_HOST) return launch_stats_rt(m, cb, pp, partials, nullptr, stream);
+  if (m.model_id == SABC_MODEL_USER) {
+    if (!rtc || !rtc->stats) return (int)hipErrorInvalidValue;
+    return module_launch(rtc->stats, (unsigned)n_blocks(pp.n_local), kBlock, stream, nullptr, nullptr, cb, pp, partials);
+  }
   const dim3 grid((unsigned)n_blocks(pp.n_local)), block(kBlock);
 #define CALL(M, D, S) hipLaunchKernelGGL((k_stats<D, S>), grid, block, 0, stream, cb, pp, partials)
   if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
@@ -1345,8 +1150,13 @@ int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, do
 }
 
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
-                          double *rho_out, hipStream_t stream) {
+                          double *rho_out, hipStream_t stream, const RtcKernels *rtc) {
   if (n <= 0) return 0;
+  if (m.model_id == SABC_MODEL_USER) {
+    if (!rtc || !rtc->simulate_batch) return (int)hipErrorInvalidValue;
+    return module_launch(rtc->simulate_batch, (unsigned)n_blocks(n), kBlock, stream, nullptr, nullptr, m, theta, n, pid0, iter,
+                         rho_out);
+  }
   if (m.model_id == SABC_MODEL_GK) {
     hipLaunchKernelGGL(k_simulate_gk, dim3(gk_blocks(n)), dim3(kBlock), 0, stream, m, theta, n, n, pid0, iter, 0,
                        (double *)nullptr, rho_out, n);

@@ -1,8 +1,11 @@
 // kernels.hpp -- host-callable launchers of the gfx950 kernels (defined in kernels.hip, sort.hip).
 // Every launcher only enqueues work on `stream` and returns the hipError_t of the launch as int.
 #pragma once
-#include <hip/hip_runtime_api.h>
 #include "sabc_types.hpp"
+#if !defined(__HIPCC_RTC__)     // hipRTC (rtc.cpp) compiles the device half of this header only
+#include <hip/hip_runtime_api.h>
+#include "rtc.hpp"
+#endif
 
 namespace sabc {
 
@@ -41,8 +44,9 @@ constexpr int64_t kFuseReduceMaxDoubles = 8192;   // measured at n = 1e6 (19.5 k
 
 inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 
+#if !defined(__HIPCC_RTC__)
 // K1: theta_i ~ prior, rho_i = f_dist(theta_i)                       SimulatedAnnealingABC.jl:172-179
-int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
+int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream, const RtcKernels *rtc = nullptr);
 // K3: u_ij = cdf_j(rho_ij) for the whole shard                        :190-192
 int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
 // K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
@@ -50,11 +54,12 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 // ev0 / ev1: optional timing events carried by the kernel's own dispatch packet
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
-                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const RtcKernels *rtc = nullptr);
 // number of partial rows launch_update() writes for act_n particles (depends on the kernel's granularity)
 int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0
-int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream);
+int launch_stats(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, hipStream_t stream,
+                 const RtcKernels *rtc = nullptr);
 // sums[c] = sum over rows of partials[row][c] in a fixed order
 // halt != nullptr: guarded (no-op while *halt is set)
 int launch_reduce_partials(const double *partials, int64_t rows, int np, double *sums, const int *halt,
@@ -117,11 +122,13 @@ int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, doub
 int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m, double *out, hipStream_t stream);
 int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
-                          double *rho_out, hipStream_t stream);
+                          double *rho_out, hipStream_t stream, const RtcKernels *rtc = nullptr);
 int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,
                         hipStream_t stream);
 int launch_rng_peak(uint64_t seed, int pairs, int64_t n, double *out, hipStream_t stream);
 int launch_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k, uint32_t *words,
                         double *normals, hipStream_t stream);
+
+#endif  // !__HIPCC_RTC__
 
 }  // namespace sabc

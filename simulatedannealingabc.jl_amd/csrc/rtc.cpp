@@ -1,0 +1,166 @@
+// rtc.cpp -- see rtc.hpp.  hipRTC is bound with dlopen at first use: a host without libhiprtc can still load the
+// library and run the built-in simulators.
+#include "rtc.hpp"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/sabc_hip.h"
+
+namespace sabc {
+
+namespace {
+
+struct HiprtcApi {
+  void *lib = nullptr;
+  int (*CreateProgram)(void **, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*DestroyProgram)(void **) = nullptr;
+  int (*CompileProgram)(void *, int, const char **) = nullptr;
+  int (*GetProgramLogSize)(void *, size_t *) = nullptr;
+  int (*GetProgramLog)(void *, char *) = nullptr;
+  int (*GetCodeSize)(void *, size_t *) = nullptr;
+  int (*GetCode)(void *, char *) = nullptr;
+  int (*AddNameExpression)(void *, const char *) = nullptr;
+  int (*GetLoweredName)(void *, const char *, const char **) = nullptr;
+};
+
+HiprtcApi *hiprtc_api() {
+  static HiprtcApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char *n : names) {
+      api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+#define SABC_RTC_SYM(field, sym) api.field = (decltype(api.field))dlsym(api.lib, sym)
+      SABC_RTC_SYM(CreateProgram, "hiprtcCreateProgram");
+      SABC_RTC_SYM(DestroyProgram, "hiprtcDestroyProgram");
+      SABC_RTC_SYM(CompileProgram, "hiprtcCompileProgram");
+      SABC_RTC_SYM(GetProgramLogSize, "hiprtcGetProgramLogSize");
+      SABC_RTC_SYM(GetProgramLog, "hiprtcGetProgramLog");
+      SABC_RTC_SYM(GetCodeSize, "hiprtcGetCodeSize");
+      SABC_RTC_SYM(GetCode, "hiprtcGetCode");
+      SABC_RTC_SYM(AddNameExpression, "hiprtcAddNameExpression");
+      SABC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
+#undef SABC_RTC_SYM
+    }
+  }
+  const bool ok = api.lib && api.CreateProgram && api.DestroyProgram && api.CompileProgram && api.GetProgramLogSize &&
+                  api.GetProgramLog && api.GetCodeSize && api.GetCode && api.AddNameExpression && api.GetLoweredName;
+  return ok ? &api : nullptr;
+}
+
+void anchor() {}
+
+}  // namespace
+
+std::string rtc_default_csrc_dir() {
+  Dl_info info;
+  if (dladdr((void *)&anchor, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    const size_t slash = p.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/csrc";
+  }
+  return "csrc";
+}
+
+void rtc_release(RtcKernels *k) {
+  if (k && k->module) (void)hipModuleUnload(k->module);
+  if (k) *k = RtcKernels();
+}
+
+int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log) {
+  return rtc_compile(user_source, d, s, csrc_dir, out, log, nullptr);
+}
+
+// out == nullptr: compile only (needs no device); code_size (optional) receives the size of the code object
+int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
+                size_t *code_size) {
+  HiprtcApi *api = hiprtc_api();
+  if (!api) { *log = "libhiprtc.so could not be loaded: simulators from source need the hipRTC of ROCm"; return -1; }
+  if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_STATS) { *log = "n_para / n_stats out of range"; return -1; }
+  char tail[2048];
+  std::snprintf(tail, sizeof(tail),
+                "\nnamespace sabc {\n"
+                "template <int D, int S>\n"
+                "struct Sim<SABC_MODEL_USER, D, S> {\n"
+                "  static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,\n"
+                "                                             double *rho) {\n"
+                "    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);\n"
+                "    ::sabc_user_simulate(th, m.p, ns, rho);\n"
+                "  }\n"
+                "};\n"
+                "}  // namespace sabc\n");
+  std::string src = "#include \"update_kernel.hpp\"\n#line 1 \"f_dist.hip\"\n";
+  src += user_source;
+  src += tail;
+
+  char name[8][96];
+  std::snprintf(name[0], sizeof(name[0]), "sabc::k_prior_simulate<%d, %d, %d>", SABC_MODEL_USER, d, s);
+  for (int p = 0; p < 3; ++p) std::snprintf(name[1 + p], sizeof(name[1 + p]), "sabc::k_update<%d, %d, %d, %d>", SABC_MODEL_USER, d, s, p);
+  std::snprintf(name[4], sizeof(name[4]), "sabc::k_simulate_batch<%d, %d, %d>", SABC_MODEL_USER, d, s);
+  std::snprintf(name[5], sizeof(name[5]), "sabc::k_stats<%d, %d>", d, s);
+
+  void *prog = nullptr;
+  if (api->CreateProgram(&prog, src.c_str(), "sabc_user_simulator.hip", 0, nullptr, nullptr)) { *log = "hiprtcCreateProgram failed"; return -1; }
+  for (int i = 0; i < 6; ++i) api->AddNameExpression(prog, name[i]);
+  const char *rocm = std::getenv("ROCM_PATH");
+  const std::string inc_rocm = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
+  const std::string inc_csrc = "-I" + csrc_dir;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str()};
+  const int rc = api->CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  size_t ls = 0;
+  api->GetProgramLogSize(prog, &ls);
+  if (ls > 1) { log->assign(ls, '\0'); api->GetProgramLog(prog, &(*log)[0]); }
+  if (rc) {
+    if (log->empty()) *log = "hiprtcCompileProgram failed";
+    api->DestroyProgram(&prog);
+    return -1;
+  }
+  size_t cs = 0;
+  api->GetCodeSize(prog, &cs);
+  if (code_size) *code_size = cs;
+  if (!out) {                                         // compile-only check: every kernel must be there by name
+    for (int i = 0; i < 6; ++i) {
+      const char *lowered = nullptr;
+      if (api->GetLoweredName(prog, name[i], &lowered) || !lowered) {
+        *log = std::string("kernel missing from the compiled module: ") + name[i];
+        api->DestroyProgram(&prog);
+        return -1;
+      }
+    }
+    api->DestroyProgram(&prog);
+    return 0;
+  }
+  std::vector<char> code(cs);
+  api->GetCode(prog, code.data());
+  RtcKernels k;
+  k.d = d; k.s = s;
+  if (hipModuleLoadData(&k.module, code.data()) != hipSuccess) {
+    *log = "hipModuleLoadData of the compiled simulator failed";
+    api->DestroyProgram(&prog);
+    return -1;
+  }
+  hipFunction_t *slots[6] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats};
+  for (int i = 0; i < 6; ++i) {
+    const char *lowered = nullptr;
+    if (api->GetLoweredName(prog, name[i], &lowered) || !lowered ||
+        hipModuleGetFunction(slots[i], k.module, lowered) != hipSuccess) {
+      *log = std::string("kernel not found in the compiled module: ") + name[i];
+      api->DestroyProgram(&prog);
+      rtc_release(&k);
+      return -1;
+    }
+  }
+  api->DestroyProgram(&prog);
+  *out = k;
+  return 0;
+}
+
+}  // namespace sabc

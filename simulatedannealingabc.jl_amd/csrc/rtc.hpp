@@ -1,0 +1,30 @@
+// rtc.hpp -- a simulator supplied as HIP source (SABC_MODEL_USER): compiled at run time with hipRTC into the same
+// fused update kernel the built-in simulators use (update_kernel.hpp), loaded as a code-object module.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <string>
+
+namespace sabc {
+
+struct RtcKernels {
+  hipModule_t module = nullptr;
+  hipFunction_t prior_simulate = nullptr;      // k_prior_simulate<USER, D, S>
+  hipFunction_t update[3] = {nullptr, nullptr, nullptr};   // k_update<USER, D, S, PROP>
+  hipFunction_t simulate_batch = nullptr;      // k_simulate_batch<USER, D, S>
+  hipFunction_t stats = nullptr;               // k_stats<D, S>
+  int d = 0, s = 0;
+};
+
+// Compiles `user_source` (it must define
+//     __device__ void sabc_user_simulate(const double *theta, const double *params, sabc::NormalStream &rng, double *rho_out);
+// ) for gfx950 and loads the kernels for (d, s).  `csrc_dir` holds update_kernel.hpp and what it includes.
+// Returns 0 or -1 with the compiler log / error text in `log`.
+int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log);
+// the same with out == nullptr stopping after the compiler (no device needed): a syntax / interface check of a source
+int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
+                size_t *code_size);
+void rtc_release(RtcKernels *k);
+// directory of this shared library + "/csrc" (the headers ship next to the library)
+std::string rtc_default_csrc_dir();
+
+}  // namespace sabc

@@ -1,0 +1,252 @@
+// update_kernel.hpp -- the per-particle kernels as templates over the simulator: K4 `k_update` (propose -> prior gate
+// -> simulate -> distance -> ECDF -> annealed MH accept -> store + fused block sums, SimulatedAnnealingABC.jl:308-331),
+// K1 `k_prior_simulate` (:172-179), `k_simulate_batch` and `k_stats`.  Device code only, no launchers: kernels.hip
+// instantiates them for the built-in simulators at build time, and rtc.cpp compiles this very header with hipRTC for a
+// simulator the user supplies as HIP source (SABC_MODEL_USER) -- same kernel, same reductions, same RNG streams.
+#pragma once
+#include "device_models.hpp"
+#include "kernels.hpp"
+
+namespace sabc {
+
+// ------------------------------------------------------------------------------------------
+// block reduction of NP per-lane values: wave shuffles, then LDS across the 4 wavefronts
+// ------------------------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], double *__restrict__ out) {
+  __shared__ double sm[kBlock / 64][NP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // step-major order: the NP shuffles of one step are independent and go out back to back (one LDS round trip per
+  // step instead of one per step AND column -- 6 instead of 6 NP dependent trips at the end of every wave's life)
+  double v[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) v[c] = acc[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double t[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) t[c] = __shfl_down(v[c], off, 64);
+#pragma unroll
+    for (int c = 0; c < NP; ++c) v[c] += t[c];
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c) sm[wave][c] = v[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < NP) {
+    const int c = threadIdx.x;
+    out[c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
+  }
+}
+
+template <int D, int S>
+__device__ __forceinline__ void moment_terms(const double *__restrict__ pivot, bool accepted, const double *th,
+                                             const double *u, const double *rho, double (&acc)[n_partials(D, S)]) {
+  acc[0] = accepted ? 1.0 : 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) { acc[1 + j] = u[j]; acc[1 + S + j] = rho[j]; }
+  double dk[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { dk[k] = th[k] - pivot[k]; acc[1 + 2 * S + k] = dk[k]; }
+  int q = 1 + 2 * S + D;
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int l = 0; l <= k; ++l) acc[q++] = dk[k] * dk[l];
+}
+
+__device__ __forceinline__ uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+
+// (gid / cap, gid % cap) for 0 <= gid < 2^53 without a 64-bit integer division (~100 instructions on this ISA): one
+// shard needs none (gid < cap), several take the f64 quotient, which is off by at most one, and correct it
+__device__ __forceinline__ void split_index(int64_t gid, int64_t cap, int64_t &r, int64_t &o) {
+  if (gid < cap) { r = 0; o = gid; return; }
+  r = (int64_t)((double)gid / (double)cap);
+  if (r * cap > gid) r -= 1;
+  else if ((r + 1) * cap <= gid) r += 1;
+  o = gid - r * cap;
+}
+
+__device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint64_t j) {
+  if (pv.world == 1) return pv.base + pv.off_last + (int64_t)j;        // one shard: no 64-bit division (uniform branch)
+  // shard index j / m_full without a 64-bit integer division: j < 2^53, so the f64 quotient is off by at most one
+  int64_t r = (int64_t)((double)j / (double)pv.m_full);
+  if (r * pv.m_full > (int64_t)j) r -= 1;
+  else if ((r + 1) * pv.m_full <= (int64_t)j) r += 1;
+  if (r > pv.world - 1) r = pv.world - 1;
+  const int64_t o = (int64_t)j - r * pv.m_full;
+  const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
+  return pv.base + r * pv.rank_stride + off + o;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
+//     + fused block partials.   SimulatedAnnealingABC.jl:308-331
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int D, int S, int PROP>
+__global__ void __launch_bounds__(kBlock, 4)
+k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
+         const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
+  constexpr int NP = n_partials(D, S);
+  if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
+  rng_tables_load();
+  __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
+  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
+  __syncthreads();                         // publishes both the generator tables and the index
+  double acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < act_n) {
+    const int64_t li = act_lo + t;
+    const uint64_t gid = (uint64_t)(pp.gid0 + li);
+    double th[D], u[S], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
+      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
+    }
+
+    // ---- proposal (:311) ----
+    double thp[D];
+    double logf = 0.0;
+    if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
+      NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
+      double z[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) z[k] = ns.next();
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
+        thp[k] = th[k] + a;
+      }
+    } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
+      uint64_t i1 = 0, i2 = 0;
+      for (uint32_t a = 0;; ++a) {                 // :103-107, redraw both until distinct
+        const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
+        i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+        i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
+        if (i1 != i2 || a > 64u) break;
+      }
+      double z0, z1;
+      box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
+      const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);      // :110
+      const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
+#pragma unroll
+      for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+    } else {                                       // StretchMove, proposals.jl:137-148
+      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
+      const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
+      const double U = u52(w.z, w.w);
+      const double a = c.prop_p0;
+      const double tt = (a - 1.0) * U + 1.0;
+      const double z = tt * tt / a;                                          // :144
+      const double *p = partner_ptr(pv, ip);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double pk = p[(int64_t)k * pv.cap];
+        thp[k] = pk + z * (th[k] - pk);                                      // :147
+      }
+      logf = log(z) * (double)(D - 1);                                       // :146
+    }
+
+    // ---- acceptance probability (:314-322) ----
+    const double lpp = prior_logpdf<D>(m, thp);
+    double log_accept = -INFINITY;
+    double up[S], rp[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
+    if (lpp > -INFINITY) {
+      Sim<MODEL, D, S>::run(m, thp, gid, c.iter, rp);                        // :315
+      double a = 0.0;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        up[j] = cdf_apply_3level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
+                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
+        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
+        a += (u[j] - up[j]) / e;                                             // :319
+      }
+      log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
+    }
+
+    // ---- accept / store (:324-329) ----
+    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
+    const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
+    if (accepted) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        u[j] = up[j]; rho[j] = rp[j];
+        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+      }
+    }
+    moment_terms<D, S>(cb->pivot, accepted, th, u, rho, acc);
+  }
+  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+}
+
+// moment sums of the shard as it stands (after a resample, or at update_population! entry :284)
+template <int D, int S>
+__global__ void __launch_bounds__(kBlock)
+k_stats(const ControlBlock *__restrict__ cb, const PopPtrs pp, double *__restrict__ partials) {
+  constexpr int NP = n_partials(D, S);
+  double acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li < pp.n_local) {
+    double th[D], u[S], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
+      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
+    }
+    moment_terms<D, S>(cb->pivot, false, th, u, rho, acc);
+  }
+  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: prior sample + simulate (SimulatedAnnealingABC.jl:172-179), iteration 0
+// ------------------------------------------------------------------------------------------
+template <int MODEL, int D, int S>
+__global__ void __launch_bounds__(kBlock) k_prior_simulate(const ModelDesc m, const PopPtrs pp) {
+  rng_tables_init();
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  double th[D], rho[S];
+  prior_sample<D>(m, gid, th);
+  Sim<MODEL, D, S>::run(m, th, gid, 0, rho);
+#pragma unroll
+  for (int k = 0; k < D; ++k) pp.pop[(int64_t)k * pp.cap + li] = th[k];
+#pragma unroll
+  for (int j = 0; j < S; ++j) pp.rho[(int64_t)j * pp.cap + li] = rho[j];
+}
+
+template <int MODEL, int D, int S>
+__global__ void __launch_bounds__(kBlock)
+k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,
+                 const uint64_t iter, double *__restrict__ rho_out) {
+  rng_tables_init();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double th[D], rho[S];
+#pragma unroll
+  for (int k = 0; k < D; ++k) th[k] = theta[(int64_t)k * n + i];
+  Sim<MODEL, D, S>::run(m, th, pid0 + (uint64_t)i, iter, rho);
+#pragma unroll
+  for (int j = 0; j < S; ++j) rho_out[(int64_t)j * n + i] = rho[j];
+}
+
+}  // namespace sabc

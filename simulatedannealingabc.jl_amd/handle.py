@@ -44,6 +44,12 @@ class SabcHandle:
         self._h = h
         self._keep = []   # ctypes callbacks must outlive the handle
         self._host_model = None
+        if getattr(model, "model_id", None) == _lib.MODEL_USER:
+            rc = self._L.sabc_register_device_simulator(self._h, model.source.encode())
+            if rc:
+                msg = self._L.sabc_last_error(self._h).decode("utf-8", "replace")
+                self.close()
+                raise SABCError(rc, msg)
         if getattr(model, "model_id", None) == _lib.MODEL_HOST:
             cb = model.callback()
             self._keep.append(cb)

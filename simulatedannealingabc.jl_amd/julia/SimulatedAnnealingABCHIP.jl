@@ -6,14 +6,19 @@
 # nothing but marshal arguments into `ccall`s.  All numerics live in the library.
 #
 # NOT EXECUTED IN THE BUILD CONTAINER: Julia is not installed there (SURVEY.md section 8c).  The
-# Python mirror in ../api.py makes exactly the same calls and is what the test-suite drives.
+# Python mirror in ../api.py makes exactly the same calls and is what the test-suite drives; what CAN be
+# checked without Julia is checked by tests/test_julia_binding.py: the field order, widths and offsets of
+# CConfig / CUpdateArgs against sizeof / offsetof of the C structs, every ccall's symbol, return type and
+# argument list against the prototypes of include/sabc_hip.h, and the enum values used below.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Product, UnivariateDistribution
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, UnivariateDistribution
+using ProgressMeter: Progress, next!, finish!          # same progress UI as the reference (:290-292,374)
+import Dates
 import Base: show
 
 export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
-       DeviceDistance, GaussianIID, Gaussian2D, GandK, LotkaVolterra
+       DeviceDistance, GaussianIID, Gaussian2D, GandK, LotkaVolterra, comm_unique_id
 
 const libsabc = get(ENV, "SABC_HIP_LIB", joinpath(@__DIR__, "..", "libsabc_hip.so"))
 
@@ -125,6 +130,9 @@ model_id(::HostDistance) = Int32(0)
 n_stats(m::HostDistance) = m.n_stats
 params(::HostDistance) = Float64[]
 
+# `@cfunction($cb, ...)` builds a runtime closure: supported on x86-64 / aarch64 Linux (where MI355X hosts run), not on
+# every platform Julia supports.  The returned Base.CFunction must stay rooted for as long as the library may call it:
+# it is kept in HOST_CALLBACKS until the handle's finalizer has run.
 function host_callback(m::HostDistance)
     function cb(ctx::Ptr{Cvoid}, theta::Ptr{Float64}, ids::Ptr{Int64}, n::Int64, iter::UInt64, rho::Ptr{Float64})::Cint
         try
@@ -148,7 +156,13 @@ prior_descriptor(d::Uniform) = (Int32(1), d.a, d.b)
 prior_descriptor(d::Exponential) = (Int32(2), d.θ, 0.0)
 prior_descriptor(d::LogNormal) = (Int32(3), d.μ, d.σ)
 prior_descriptors(d::UnivariateDistribution) = [prior_descriptor(d)]
-prior_descriptors(d::Product) = [prior_descriptor(c) for c in d.v]
+# product_distribution([...]): Distributions.jl names the vector of marginals `v` (Product, <= 0.25.x) or `dists`
+# (ProductDistribution); neither has an exported accessor, so both spellings are accepted and anything else is refused
+function prior_descriptors(d::Distribution)
+    comps = hasproperty(d, :v) ? getproperty(d, :v) : hasproperty(d, :dists) ? getproperty(d, :dists) :
+            error("prior must be Normal, Uniform, Exponential, LogNormal or product_distribution([...]) of those")
+    [prior_descriptor(c) for c in comps]
+end
 
 # ---- result types: same field names as SimulatedAnnealingABC.jl:28-60 ----
 mutable struct SABCstate
@@ -164,13 +178,18 @@ mutable struct SABCstate
     n_population_updates::Int
 end
 
-struct SABCresult{T,S}
+struct SABCresult{T,S}                  # the reference's four fields, nothing else (:55-60)
     population::Vector{T}
     u::Array{S}
     ρ::Array{S}
     state::SABCstate
-    handle::Base.RefValue{Ptr{Cvoid}}     # owns the device-resident population
 end
+
+# The device-resident population behind a result: a side table keyed by the (mutable) state object, so that the handle
+# lives exactly as long as the result and SABCresult keeps the reference's constructor.
+const HANDLES = WeakKeyDict{SABCstate,Base.RefValue{Ptr{Cvoid}}}()
+handle_of(res::SABCresult) = get(() -> error("this SABCresult has no device population (it was not created by sabc of SimulatedAnnealingABCHIP)"),
+                                 HANDLES, res.state)
 
 function check(h::Ptr{Cvoid}, rc::Integer)
     rc == 0 && return
@@ -181,17 +200,42 @@ end
 
 padtuple(v, n, T) = ntuple(i -> i <= length(v) ? T(v[i]) : zero(T), n)
 
-function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v, δ, seed, device=0)
+"""
+    comm_unique_id() -> Vector{UInt8}
+
+The 128-byte RCCL id of a multi-GPU run: rank 0 calls this and hands the bytes to the other ranks (MPI.jl `bcast`, a
+file, a socket ...); every rank then passes them as `comm_id` to `sabc`.
+"""
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(C_NULL, ccall((:sabc_comm_unique_id, libsabc), Cint, (Ptr{Cvoid},), id))
+    id
+end
+
+function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v, δ, seed, device=0, rank=0, world=1,
+                       comm_id=nothing)
     pd = prior_descriptors(prior)
     p = params(f_dist)
     cfg = Ref(CConfig(1, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
                       padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(last.(pd), MAX_PARA, Float64),
-                      algorithm == :multi_eps ? 1 : 0, 0, 1, 0, v, δ, seed))
+                      algorithm == :multi_eps ? 1 : 0, rank, world, 0, v, δ, seed))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sabc_create, libsabc), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))
-    finalizer(r -> (r[] != C_NULL && ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[]); r[] = C_NULL), h)
+    finalizer(h) do r
+        if r[] != C_NULL
+            ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[])
+            delete!(HOST_CALLBACKS, r[])               # the library can no longer call back: release the closure
+            r[] = C_NULL
+        end
+    end
+    if world > 1                                       # one process per GPU: RCCL bound inside the library
+        (comm_id isa Vector{UInt8} && length(comm_id) == 128) ||
+            error("world > 1 needs `comm_id`: the 128 bytes of comm_unique_id() from rank 0")
+        GC.@preserve comm_id check(h[], ccall((:sabc_comm_init_rccl, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm_id))
+        check(h[], ccall((:sabc_comm_selftest, libsabc), Cint, (Ptr{Cvoid},), h[]))
+    end
     if f_dist isa HostDistance
         cb = host_callback(f_dist)
         HOST_CALLBACKS[h[]] = (cb, f_dist)             # keep the closure (and the wrapped model) alive with the handle
@@ -206,7 +250,7 @@ const HOST_CALLBACKS = Dict{Ptr{Cvoid},Any}()
 function sabc(f_dist::Function, prior::Distribution, args...; kwargs...)
     f_dist isa DeviceDistance && return invoke(sabc, Tuple{DeviceDistance,Distribution}, f_dist, prior; kwargs...)
     own = (:n_particles, :n_simulation, :algorithm, :proposal, :resample, :v, :δ, :checkpoint_history,
-           :show_progressbar, :show_checkpoint, :seed, :device)
+           :show_progressbar, :show_checkpoint, :seed, :device, :rank, :world, :comm_id)
     mine = (; (k => v for (k, v) in kwargs if k in own)...)
     theirs = (; (k => v for (k, v) in kwargs if !(k in own))...)
     ρ = f_dist(rand(prior), args...; theirs...)
@@ -216,7 +260,7 @@ end
 
 # copies device state into the Julia arrays in place (`.=` at SimulatedAnnealingABC.jl:395-397)
 function refresh!(res::SABCresult, d::Int, s::Int)
-    h = res.handle[]
+    h = handle_of(res)[]
     n = length(res.population)
     θ = Matrix{Float64}(undef, n, d)               # column-major n x d == the library's [d][n]
     GC.@preserve θ check(h, ccall((:sabc_get_population, libsabc), Cint,
@@ -243,40 +287,96 @@ function refresh!(res::SABCresult, d::Int, s::Int)
     res
 end
 
-"""
-    update_population!(population_state, f_dist, prior; n_simulation, v=1.0, δ=0.1, proposal, resample, checkpoint_history=1)
+# Check if a stream is logged (SimulatedAnnealingABC.jl:500)
+is_logging(io) = isa(io, Base.TTY) == false || (get(ENV, "CI", nothing) == "true")
 
-Same keywords as SimulatedAnnealingABC.jl:251-259.  Mutates and returns `population_state`.
+# Progress output needs the device loop to come up for air: the call is split into chunks of population updates.  Chunks
+# are multiples of `checkpoint_history`, which leaves counters, histories and particles exactly as in one call (the final
+# history push of :378-382 then never fires in between).  Same rule as progress_chunk() in ../api.py.
+function progress_chunk(n_pop, cph, show_checkpoint, show_progressbar)
+    chunk = n_pop
+    if isfinite(show_checkpoint) && show_checkpoint >= 1
+        k = Int(show_checkpoint)
+        k % cph == 0 && (chunk = min(chunk, k))
+    end
+    if show_progressbar && n_pop > 0
+        bar = max(cph, (n_pop ÷ 50) ÷ cph * cph)
+        if chunk < n_pop                                # both: a bar step that divides the checkpoint interval
+            while chunk % bar != 0 && bar > cph
+                bar -= cph
+            end
+            chunk % bar == 0 && (chunk = bar)
+        else
+            chunk = min(chunk, bar)
+        end
+    end
+    max(chunk, 1)
+end
+
+"""
+    update_population!(population_state, f_dist, prior; n_simulation, v=1.0, δ=0.1, proposal, resample, checkpoint_history=1,
+                       show_progressbar, show_checkpoint)
+
+Same keywords and defaults as SimulatedAnnealingABC.jl:251-259.  Mutates and returns `population_state`.
 """
 function update_population!(res::SABCresult, f_dist::DeviceDistance, prior::Distribution;
                             n_simulation, v=1.0, δ=0.1,
                             proposal::Proposal=DifferentialEvolution(n_para=length(prior)),
-                            resample=2 * length(res.population), checkpoint_history=1,
-                            show_progressbar::Bool=false, show_checkpoint=Inf)
+                            resample=nothing, checkpoint_history=1,
+                            show_progressbar::Bool=!is_logging(stderr),
+                            show_checkpoint=is_logging(stderr) ? 100 : Inf)
     v <= 0 && error("Annealing speed `v` must be positive.")                       # :261
     δ <= 0 && error("Resamping intensity `δ` must be positive.")                   # :262
-    h = res.handle[]
+    h = handle_of(res)[]
     d, s = length(prior), size(res.u, 2)
+    n_global = ccall((:sabc_n_global, libsabc), Int64, (Ptr{Cvoid},), h)           # == length(population) on one GPU
+    resample = something(resample, 2 * n_global)                                   # :255
     θ = eltype(res.population) <: Real ? reshape(copy(res.population), :, 1) : permutedims(reduce(hcat, res.population))
     GC.@preserve θ check(h, ccall((:sabc_set_population, libsabc), Cint,
                                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h, θ, res.u, res.ρ))
     kind, p0, p1 = descriptor(proposal)
-    args = Ref(CUpdateArgs(n_simulation, v, δ, resample, checkpoint_history, kind, 0, p0, p1))
-    check(h, ccall((:sabc_update, libsabc), Cint, (Ptr{Cvoid}, Ref{CUpdateArgs}), h, args))
+    n_pop = n_simulation ÷ n_global                                                # :275
+    cph = max(Int(checkpoint_history), 1)
+    chunk = progress_chunk(n_pop, cph, show_checkpoint, show_progressbar)
+    pmeter = Progress(n_pop; desc="$n_pop population updates:", output=stderr, enabled=show_progressbar)   # :290-291
+    t_start = Dates.now()
+    done = 0
+    while true
+        todo = n_pop > 0 ? min(chunk, n_pop - done) : 0
+        budget = n_pop > 0 ? todo * n_global : n_simulation                        # a top-up below one update is a no-op (:275)
+        args = Ref(CUpdateArgs(budget, v, δ, resample, checkpoint_history, kind, 0, p0, p1))
+        check(h, ccall((:sabc_update, libsabc), Cint, (Ptr{Cvoid}, Ref{CUpdateArgs}), h, args))
+        done += todo
+        if show_progressbar || (isfinite(show_checkpoint) && done < n_pop)
+            eps = Vector{Float64}(undef, MAX_STATS); len = Ref{Int32}(0)
+            check(h, ccall((:sabc_get_epsilon, libsabc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int32}), h, eps, len))
+            ϵ = round.(eps[1:len[]], sigdigits=4)
+            show_progressbar && next!(pmeter; step=todo, showvalues=[("ϵ", ϵ)])    # :292,374
+            if isfinite(show_checkpoint) && done < n_pop && done % Int(show_checkpoint) == 0   # :359-364
+                eta = ((Dates.now() - t_start) ÷ done) * (n_pop - done)
+                etastr = eta > Dates.Second(1) ? Dates.canonicalize(round(eta, Dates.Second)) : "< 1 Second"
+                @info "Update $done of $n_pop. ϵ: $ϵ, ETA: $(etastr)"; flush(stderr)
+            end
+        end
+        done >= n_pop && break
+    end
+    show_progressbar && finish!(pmeter)
     if proposal isa RandomWalk
         Σ = Matrix{Float64}(undef, d, d)
         check(h, ccall((:sabc_get_proposal_sigma, libsabc), Cint, (Ptr{Cvoid}, Ptr{Float64}), h, Σ))
         d == 1 ? (proposal.Σ = Σ[1, 1]) : (proposal.Σ .= Σ)
     end
     refresh!(res, d, s)
+    @info "All particles have been updated $(n_pop) times."; flush(stderr)          # :399
+    res
 end
 
 # update_population!(res, f_dist, prior, args...; kwargs...) with the plain function the result was created
 # with (SimulatedAnnealingABC.jl:251): look the wrapped model up by handle; args/kwargs go to f_dist (:315)
 function update_population!(res::SABCresult, f_dist::Function, prior::Distribution, args...; kwargs...)
     f_dist isa DeviceDistance && return invoke(update_population!, Tuple{SABCresult,DeviceDistance,Distribution}, res, f_dist, prior; kwargs...)
-    haskey(HOST_CALLBACKS, res.handle[]) || error("this SABCresult was not created with a host `f_dist`")
-    hd = HOST_CALLBACKS[res.handle[]][2]
+    haskey(HOST_CALLBACKS, handle_of(res)[]) || error("this SABCresult was not created with a host `f_dist`")
+    hd = HOST_CALLBACKS[handle_of(res)[]][2]
     hd.f === f_dist || error("`f_dist` differs from the one this SABCresult was initialised with")
     own = (:n_simulation, :v, :δ, :proposal, :resample, :checkpoint_history, :show_progressbar, :show_checkpoint)
     mine = (; (k => v for (k, v) in kwargs if k in own)...)
@@ -286,22 +386,29 @@ end
 """
     sabc(f_dist::DeviceDistance, prior; n_particles=100, n_simulation=10_000, algorithm=:single_eps, ...)
 
-Same keywords as SimulatedAnnealingABC.jl:451-460 (+ `seed`, `device`).
+Same keywords as SimulatedAnnealingABC.jl:451-460, plus `seed` (Philox key), `device` and -- one process per GPU --
+`rank`, `world`, `comm_id` (see `comm_unique_id`).  On a sharded run `n_particles` is the GLOBAL count, the result holds
+this rank's shard and every rank must pass the same `seed`.
 """
 function sabc(f_dist::DeviceDistance, prior::Distribution;
               n_particles=100, n_simulation=10_000, algorithm=:single_eps,
               proposal::Proposal=DifferentialEvolution(n_para=length(prior)),
               resample=2 * n_particles, v=1.0, δ=0.1, checkpoint_history=1,
-              show_progressbar::Bool=false, show_checkpoint=Inf, seed=rand(UInt64) >> 1, device=0)
+              show_progressbar::Bool=!is_logging(stderr), show_checkpoint=is_logging(stderr) ? 100 : Inf,
+              seed=nothing, device=0, rank=0, world=1, comm_id=nothing)
     (algorithm == :multi_eps || algorithm == :single_eps) ||
         error("Argument `algorithm` must be :multi_eps or :single_eps, not `$algorithm`!")   # :462-464
     n_simulation < n_particles &&
         error("`n_simulation = $n_simulation` is too small for $n_particles particles.")     # :155-156
-    h = create_handle(f_dist, prior; n_particles, algorithm, v, δ, seed, device)
+    world > 1 && isnothing(seed) && error("world > 1 needs an explicit `seed`: every shard must use the same Philox key")
+    seed = something(seed, rand(UInt64) >> 1)
+    @info "Initialization for '$(algorithm)'"                                                # :158
+    h = create_handle(f_dist, prior; n_particles, algorithm, v, δ, seed, device, rank, world, comm_id)
     check(h[], ccall((:sabc_initialize, libsabc), Cint, (Ptr{Cvoid}, Int64), h[], n_simulation))
     d, s = length(prior), n_stats(f_dist)
+    n_local = ccall((:sabc_n_local, libsabc), Int64, (Ptr{Cvoid},), h[])
     T = d == 1 ? Float64 : Vector{Float64}
-    pop = d == 1 ? zeros(n_particles) : [zeros(d) for _ in 1:n_particles]
+    pop = d == 1 ? zeros(n_local) : [zeros(d) for _ in 1:n_local]
     cdf = ρ -> begin
         out = Vector{Float64}(undef, s)
         r = collect(Float64, ρ)
@@ -309,11 +416,13 @@ function sabc(f_dist::DeviceDistance, prior::Distribution;
         out
     end
     st = SABCstate(Float64[], algorithm, [], [], [], cdf, 0, 0, 0, 0)
-    res = SABCresult{T,Float64}(pop, zeros(n_particles, s), zeros(n_particles, s), st, h)
+    HANDLES[st] = h
+    res = SABCresult{T,Float64}(pop, zeros(n_local, s), zeros(n_local, s), st)
     refresh!(res, d, s)
     n_sim_remaining = n_simulation - st.n_simulation                                         # :478
     n_sim_remaining < n_particles && @warn "`n_simulation` too small to update all particles!"
-    update_population!(res, f_dist, prior; n_simulation=n_sim_remaining, resample, proposal, v, δ, checkpoint_history)
+    update_population!(res, f_dist, prior; n_simulation=n_sim_remaining, resample, proposal, v, δ, checkpoint_history,
+                       show_progressbar, show_checkpoint)
 end
 
 function show(io::IO, s::SABCresult)     # SimulatedAnnealingABC.jl:65-82

@@ -131,3 +131,35 @@ class HostDistance(DeviceDistance):
                 return -1
 
         return _lib.SIMULATE_FN(cb)
+
+
+class DeviceSource(DeviceDistance):
+    """`f_dist` as HIP source (SimulatedAnnealingABC.jl:164,175,315 for a simulator of your own ON the device):
+
+        __device__ void sabc_user_simulate(const double *theta, const double *params, sabc::NormalStream &rng, double *rho_out);
+
+    `rng.next()` / `rng.pair(z0, z1)` are N(0,1) draws, `rng.uniform_pair(u0, u1)` U(0,1) draws of the particle's
+    simulation stream; `params` is the `params` list given here.  The source is compiled at run time (hipRTC, gfx950) into
+    the same fused propose -> simulate -> ECDF -> accept kernel as the built-in simulators."""
+    model_id = _lib.MODEL_USER
+
+    def __init__(self, hip_source: str, n_para: int, n_stats: int, params=()):
+        self.source = str(hip_source)
+        self.n_para = (int(n_para),)
+        self.n_stats = int(n_stats)
+        self._params = [float(p) for p in params]
+        if len(self._params) > _lib.MAX_MODEL_PARAMS:
+            raise ValueError(f"at most {_lib.MAX_MODEL_PARAMS} parameters")
+
+    @property
+    def params(self):
+        return list(self._params)
+
+    def compile_check(self):
+        """Run the compiler stage only (no GPU needed); raises SABCError with the compiler log on failure."""
+        import ctypes as C
+        log = C.create_string_buffer(1 << 16)
+        rc = _lib.lib().sabc_op_compile_device_simulator(self.source.encode(), self.n_para[0], self.n_stats, log, len(log))
+        if rc:
+            raise _lib.SABCError(rc, "compiling the device simulator failed:\n" + log.value.decode("utf-8", "replace"))
+        return True

@@ -475,6 +475,7 @@ int sabc_update(sabc_handle *h, const sabc_update_args *a) {
   if (rc) h->err = h->eng->error();
   return rc;
 }
+int64_t sabc_n_global(const sabc_handle *h) { return h ? h->eng->shard().n_global : 0; }
 int64_t sabc_n_local(const sabc_handle *h) { return h->eng->shard().n_local; }
 int64_t sabc_local_offset(const sabc_handle *h) { return h->eng->shard().gid0; }
 int sabc_get_population(sabc_handle *h, double *t, double *u, double *r) { return h->be->download(t, u, r); }

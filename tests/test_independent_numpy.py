@@ -1,0 +1,109 @@
+"""A second opinion on the oracle's reading of the algorithm.  tests/independent/sabc_numpy.py restates the reference
+(src/SimulatedAnnealingABC.jl, proposals.jl, cdf_estimators.jl) in vectorised NumPy with its own RNG, interpolation, root
+finder and resampler -- no code and no random stream shared with oracle/sabc_oracle.c.  Two independent implementations
+of the same algorithm must agree in distribution along the whole annealing trajectory: acceptances per particle, resample
+count, epsilon, population variance.  (A misreading in one of them -- a wrong sign in the acceptance ratio, partners from
+the wrong half, rho permuted by the resample, n instead of n-1 ... -- moves these by tens of percent.)
+
+What the trajectory also shows, in BOTH implementations: the long-run population of this algorithm is NOT the analytic
+posterior.  With the 1-D Gaussian model (conjugate posterior variance 1/(1/4+100)) the population variance falls through
+the analytic value around update 60-90 and settles ~20 % (RandomWalk) / ~6 % (DifferentialEvolution) BELOW it, for every
+annealing speed v tried (1, 0.1, 0.03): late in the annealing a particle only moves when its new distance beats its old
+one, arrivals are distributed like (population * jump) x likelihood -- narrower than the posterior -- and departures no
+longer balance them.  That is the reference algorithm's behaviour, not an artefact of this restatement or of the device
+code; DESIGN.md section 7 has the numbers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "independent"))
+import models_numpy as M  # noqa: E402
+from sabc_numpy import SabcNumpy, build_cdf, eps_multi, eps_single  # noqa: E402
+
+from tests.cases import oracle_config, oracle_proposal  # noqa: E402
+
+N = 40_000
+
+
+def oracle_trajectory(O, case, alg, prop, d, marks, seed):
+    O.set_threads(8)
+    run = O.OracleRun(oracle_config(O, case, N, alg, seed=seed))
+    run.initialize(N)
+    out, done = [], 0
+    for k in marks:
+        run.update(O.make_update_args(n_simulation=(k - done) * N, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=N))
+        done = k
+        out.append(dict(theta=run.theta.copy(), eps=run.eps.copy(), acc=run.counters["n_accept"] / N,
+                        res=run.counters["n_resampling"], ubar=run.u.mean(1)))
+    O.set_threads(1)
+    return out
+
+
+def numpy_trajectory(model, alg, prop, marks, seed):
+    s = SabcNumpy(model["sim"], model["sample"], model["logpdf"], N, algorithm=alg, seed=seed)
+    out, done = [], 0
+    for k in marks:
+        s.update(k - done, kind=prop)
+        done = k
+        out.append(dict(theta=s.theta.T.copy(), eps=s.eps.copy(), acc=s.n_accept / N, res=s.n_resampling, ubar=s.u.mean(0)))
+    return out
+
+
+@pytest.mark.parametrize("prop", ["rw", "de", "stretch"])
+def test_cfg2_trajectory_oracle_vs_independent_numpy(O, prop):
+    marks = (25, 100, 250)
+    a = oracle_trajectory(O, "gauss1_cfg2", "single_eps", prop, 1, marks, seed=11)
+    b = numpy_trajectory(M.cfg2(), "single_eps", prop, marks, seed=12)
+    for k, x, y in zip(marks, a, b):
+        assert abs(x["acc"] / y["acc"] - 1) < 0.025, (k, x["acc"], y["acc"])           # acceptances per particle
+        assert abs(x["res"] - y["res"]) <= 1, (k, x["res"], y["res"])                      # the trigger is a threshold on a count
+        vx, vy = x["theta"][0].var(), y["theta"][0].var()
+        # steep at 25 (the variance halves in ~10 updates); a resample that one run has just done and the other is about to do
+        # shows as a ~9 % step in the variance
+        tol = 0.15 if k == 25 else (0.04 if x["res"] == y["res"] else 0.12)
+        assert abs(vx / vy - 1) < tol, (k, vx, vy)
+        assert abs(x["theta"][0].mean() - y["theta"][0].mean()) < 0.004                # 0.04 posterior sd
+    assert abs(a[0]["eps"][0] / b[0]["eps"][0] - 1) < 0.15
+    # the finding of the module docstring, in both implementations: under-dispersed against the conjugate posterior
+    pv = M.cfg2()["post_var"]
+    for t in (a, b):
+        late = t[-1]["theta"][0].var() / pv - 1
+        assert {"rw": -0.26 < late < -0.12, "de": -0.12 < late < 0.0, "stretch": -0.24 < late < -0.10}[prop], late
+
+
+def test_cfg3_multistat_trajectory_oracle_vs_independent_numpy(O):
+    """3 statistics, 2 parameters, multi-epsilon schedule, population-covariance RandomWalk."""
+    marks = (30, 120, 300)
+    a = oracle_trajectory(O, "gauss2d_cfg3", "multi_eps", "rw", 2, marks, seed=21)
+    b = numpy_trajectory(M.cfg3(), "multi_eps", "rw", marks, seed=22)
+    for k, x, y in zip(marks, a, b):
+        assert abs(x["acc"] / y["acc"] - 1) < 0.03, (k, x["acc"], y["acc"])
+        assert abs(x["res"] - y["res"]) <= 1
+        cx, cy = np.cov(x["theta"]), np.cov(y["theta"])
+        assert np.linalg.norm(cx - cy) / np.linalg.norm(cy) < 0.12, (k, cx, cy)
+        assert np.linalg.norm(x["theta"].mean(1) - y["theta"].mean(1)) < 0.06 * np.sqrt(np.trace(cy)), (k, x["theta"].mean(1), y["theta"].mean(1))
+        # the two ancillary statistics (variance sum, covariance) trade places from run to run (+-15 % at this n, in either
+        # implementation): their sum and the informative first statistic are compared tightly, the rest loosely
+        assert abs(x["ubar"][0] / y["ubar"][0] - 1) < 0.08 and abs(x["ubar"][1:].sum() / y["ubar"][1:].sum() - 1) < 0.08
+        np.testing.assert_allclose(x["ubar"], y["ubar"], rtol=0.30)
+        np.testing.assert_allclose(x["eps"], y["eps"], rtol=0.30)
+
+
+def test_operators_oracle_vs_independent_numpy(O):
+    """ECDF (np.interp), both epsilon schedules (brentq): value-level agreement with the oracle's operators."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.gamma(2.0, 1.0, 500), [0.0, 0.0, 1.0, 1.0]])
+    f, knots = build_cdf(x), O.build_cdf(x)
+    # (exactly AT a duplicated knot -- here 1.0 -- the value is a convention: np.interp takes the last duplicate's ordinate,
+    # Interpolations.jl, which the oracle follows, the first's; a continuous distance never lands there)
+    q = np.concatenate([[-1.0, 0.0, 0.999, 1.001, x.max() * 1.5, 1e9], rng.random(200) * x.max() * 1.6])
+    np.testing.assert_allclose(f(q), [O.cdf_apply(knots, v) for v in q], rtol=1e-12, atol=1e-15)
+    for ub in (1e-17, 1e-4, 0.05, 0.3, 0.9):
+        for v in (0.1, 1.0, 10.0):
+            assert eps_single(ub, v) == pytest.approx(O.eps_single(ub, v), rel=1e-10, abs=0)
+    for ub in ([0.4], [0.3, 0.2], [0.45, 0.3, 0.1], [0.02, 0.03, 0.04, 0.05]):
+        for v in (0.3, 1.0, 5.0):
+            np.testing.assert_allclose(eps_multi(np.array(ub), v), O.eps_multi(np.array(ub), v), rtol=1e-9)

@@ -1,0 +1,212 @@
+"""Julia is not installed here, so the Julia wrapper (simulatedannealingabc.jl_amd/julia/SimulatedAnnealingABCHIP.jl)
+cannot run; what can be checked without Julia is checked here, so that the wrapper cannot be silently wrong:
+  * `struct CConfig` / `struct CUpdateArgs`: field names, order, widths, offsets and total size against
+    sizeof / offsetof of `sabc_config` / `sabc_update_args` as gcc lays them out (Julia lays isbits structs out by
+    the C rules);
+  * every `ccall((:sabc_..., libsabc), RET, (ARGS...), ...)`: the symbol is declared in include/sabc_hip.h and
+    exported by the built library, and return type and argument list agree with the prototype;
+  * the enum values the wrapper hard-codes (model ids, prior kinds, proposal kinds, ABI version);
+  * the four-field `SABCresult` and the keyword sets of `sabc` / `update_population!` of the reference."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JL = os.path.join(ROOT, "simulatedannealingabc.jl_amd", "julia", "SimulatedAnnealingABCHIP.jl")
+HDR = os.path.join(ROOT, "include", "sabc_hip.h")
+
+JL_SCALARS = {"Int32": (4, 4), "Int64": (8, 8), "UInt64": (8, 8), "Float64": (8, 8), "UInt32": (4, 4)}
+
+
+def jl_source():
+    return open(JL, encoding="utf-8").read()
+
+
+def jl_consts(src):
+    m = re.search(r"const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = (\d+), (\d+), (\d+)", src)
+    return dict(MAX_PARA=int(m.group(1)), MAX_STATS=int(m.group(2)), MAX_MODEL_PARAMS=int(m.group(3)))
+
+
+def jl_struct_layout(src, name):
+    """[(field, offset, size)], total size -- C layout rules applied to the Julia field list."""
+    body = re.search(r"^struct %s\n(.*?)^end" % name, src, re.S | re.M).group(1)
+    consts = jl_consts(src)
+    fields, off, max_al = [], 0, 1
+    for line in body.strip().splitlines():
+        fname, ftype = [x.strip() for x in line.split("#")[0].split("::")]
+        m = re.fullmatch(r"NTuple\{(\w+),(\w+)\}", ftype)
+        if m:
+            cnt = consts[m.group(1)] if m.group(1) in consts else int(m.group(1))
+            sz, al = JL_SCALARS[m.group(2)]
+            size = cnt * sz
+        else:
+            size, al = JL_SCALARS[ftype]
+        off = (off + al - 1) // al * al
+        fields.append((fname, off, size))
+        off += size
+        max_al = max(max_al, al)
+    return fields, (off + max_al - 1) // max_al * max_al
+
+
+def c_struct_layout(tmp_path, cname, fields):
+    """offsetof / sizeof as gcc sees the header."""
+    prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HDR}"', "int main(void) {"]
+    for f in fields:
+        prog.append(f'  printf("{f} %zu %zu\\n", offsetof({cname}, {f}), sizeof((({cname} *)0)->{f}));')
+    prog.append(f'  printf("__total %zu 0\\n", sizeof({cname}));')
+    prog.append("  return 0; }")
+    src = tmp_path / f"layout_{cname}.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / f"layout_{cname}"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True)
+    rows = [ln.split() for ln in out.strip().splitlines()]
+    return [(r[0], int(r[1]), int(r[2])) for r in rows[:-1]], int(rows[-1][1])
+
+
+def c_struct_fields(hdr, cname):
+    body = re.search(r"typedef struct \{([^{}]*)\} %s;" % cname, hdr).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    return [re.match(r"\s*\w+\s+(\w+)", decl).group(1) for decl in body.split(";") if decl.strip()]
+
+
+@pytest.mark.parametrize("jname,cname", [("CConfig", "sabc_config"), ("CUpdateArgs", "sabc_update_args")])
+def test_struct_layouts_match_the_header(tmp_path, jname, cname):
+    hdr = open(HDR).read()
+    jl_fields, jl_total = jl_struct_layout(jl_source(), jname)
+    names = c_struct_fields(hdr, cname)
+    assert [f[0] for f in jl_fields] == names                      # same fields, same order
+    c_fields, c_total = c_struct_layout(tmp_path, cname, names)
+    assert jl_fields == c_fields                                   # same offsets and widths
+    assert jl_total == c_total
+    # and the ctypes mirror the tests actually run agrees with both
+    import ctypes as C
+    from sabc_amd._lib import Config, UpdateArgs
+    py = {"sabc_config": Config, "sabc_update_args": UpdateArgs}[cname]
+    assert [(n, getattr(py, n).offset, getattr(py, n).size) for n, _ in py._fields_] == c_fields and C.sizeof(py) == c_total
+
+
+def header_prototypes():
+    hdr = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"SABC_API\s+([\w\s\*]+?)\s*\b(sabc_\w+)\s*\(([^;]*?)\)\s*;", hdr, re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        protos[name] = (ckind(ret), [] if args in ("void", "") else [ckind(a) for a in args.split(",")])
+    return protos
+
+
+def ckind(decl):
+    decl = decl.strip()
+    if "*" in decl or "[" in decl or re.search(r"\bsabc_\w+_fn\b", decl):
+        return "ptr"
+    for key, kind in (("uint64_t", "u64"), ("int64_t", "i64"), ("uint32_t", "u32"), ("int32_t", "i32"), ("double", "f64"),
+                      ("void", "void"), ("int", "i32")):
+        if re.search(r"\b%s\b" % key, decl):
+            return kind
+    raise AssertionError(f"unparsed C declaration: {decl!r}")
+
+
+def jkind(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "UInt32": "u32", "Float64": "f64", "Cdouble": "f64",
+            "Cvoid": "void"}[t]
+
+
+def test_every_ccall_matches_its_prototype():
+    src = jl_source()
+    protos = header_prototypes()
+    calls = re.findall(r"ccall\(\(:(sabc_\w+),\s*libsabc\),\s*([\w{}]+),\s*\(([^()]*)\)", src)
+    assert len(calls) >= 15
+    assert len(re.findall(r"ccall\(", src)) == len(calls)          # nothing the pattern missed
+    for name, ret, args in calls:
+        assert name in protos, f"{name} is not declared in include/sabc_hip.h"
+        want_ret, want_args = protos[name]
+        got_args = [jkind(a) for a in args.split(",") if a.strip()]
+        assert jkind(ret) == want_ret, (name, ret, want_ret)
+        assert got_args == want_args, (name, got_args, want_args)
+    used = {c[0] for c in calls}
+    for needed in ("sabc_create", "sabc_destroy", "sabc_initialize", "sabc_update", "sabc_get_population", "sabc_set_population",
+                   "sabc_get_counters", "sabc_get_epsilon", "sabc_get_history", "sabc_cdf_apply", "sabc_get_proposal_sigma",
+                   "sabc_set_host_simulator", "sabc_comm_unique_id", "sabc_comm_init_rccl", "sabc_comm_selftest", "sabc_n_local"):
+        assert needed in used, needed
+    # ... and the built library exports them (the same check _lib.bind(strict=True) does for the whole header)
+    import sabc_amd
+    sabc_amd.build()
+    import ctypes as C
+    L = C.CDLL(sabc_amd._lib.LIB_PATH)
+    for name in used:
+        assert hasattr(L, name), name
+
+
+def header_enum(name_prefix):
+    hdr = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    return {k: int(v) for k, v in re.findall(r"\b(%s\w+)\s*=\s*(-?\d+)" % name_prefix, hdr)}
+
+
+def test_hard_coded_enum_values():
+    src = jl_source()
+    models, priors, props = header_enum("SABC_MODEL_"), header_enum("SABC_PRIOR_"), header_enum("SABC_PROP_")
+    for jl_type, key in (("GaussianIID", "SABC_MODEL_GAUSS_IID"), ("Gaussian2D", "SABC_MODEL_GAUSS2D"), ("GandK", "SABC_MODEL_GK"),
+                         ("LotkaVolterra", "SABC_MODEL_LV"), ("HostDistance", "SABC_MODEL_HOST")):
+        assert int(re.search(r"model_id\(::%s\) = Int32\((\d+)\)" % jl_type, src).group(1)) == models[key]
+    for jl_type, key in (("Normal", "SABC_PRIOR_NORMAL"), ("Uniform", "SABC_PRIOR_UNIFORM"), ("Exponential", "SABC_PRIOR_EXPONENTIAL"),
+                         ("LogNormal", "SABC_PRIOR_LOGNORMAL")):
+        assert int(re.search(r"prior_descriptor\(d::%s\) = \(Int32\((\d+)\)" % jl_type, src).group(1)) == priors[key]
+    for jl_type, key in (("RandomWalk", "SABC_PROP_RANDOMWALK"), ("DifferentialEvolution", "SABC_PROP_DIFFEVO"),
+                         ("StretchMove", "SABC_PROP_STRETCH")):
+        assert int(re.search(r"descriptor\(p::%s\) = \(Int32\((\d+)\)" % jl_type, src).group(1)) == props[key]
+    abi = int(re.search(r"#define SABC_ABI_VERSION (\d+)", open(HDR).read()).group(1))
+    assert re.search(r"Ref\(CConfig\(%d, device," % abi, src)                       # abi_version is the first field
+    consts = jl_consts(src)
+    hdr = open(HDR).read()
+    for k in ("MAX_PARA", "MAX_STATS", "MAX_MODEL_PARAMS"):
+        assert consts[k] == int(re.search(r"#define SABC_%s (\d+)" % k, hdr).group(1))
+    # the host-simulator callback signature == sabc_simulate_fn
+    cb = re.search(r"@cfunction\(\$cb, (\w+), \(([^()]*)\)\)", src)
+    assert jkind(cb.group(1)) == "i32" and [jkind(a) for a in cb.group(2).split(",")] == ["ptr", "ptr", "ptr", "i64", "u64", "ptr"]
+
+
+def test_reference_surface_is_kept():
+    """SABCresult has exactly the reference's four fields (SimulatedAnnealingABC.jl:55-60), SABCstate its ten (:28-42), and
+    `sabc` / `update_population!` take the reference's keywords with the reference's defaults (:251-259, :451-460)."""
+    src = jl_source()
+    res = re.search(r"^struct SABCresult\{T,S\}.*?\n(.*?)^end", src, re.S | re.M).group(1)
+    assert [ln.split("::")[0].strip() for ln in res.strip().splitlines()] == ["population", "u", "ρ", "state"]
+    st = re.search(r"^mutable struct SABCstate\n(.*?)^end", src, re.S | re.M).group(1)
+    assert [ln.split("::")[0].strip() for ln in st.strip().splitlines()] == [
+        "ϵ", "algorithm", "ϵ_history", "ρ_history", "u_history", "cdfs_dist_prior", "n_simulation", "n_accept", "n_resampling",
+        "n_population_updates"]
+    upd = re.search(r"function update_population!\(res::SABCresult, f_dist::DeviceDistance.*?\n    v <= 0", src, re.S).group(0)
+    for kw in ("n_simulation", "v=1.0", "δ=0.1", "proposal::Proposal=DifferentialEvolution(n_para=length(prior))", "checkpoint_history=1",
+               "show_progressbar::Bool=!is_logging(stderr)", "show_checkpoint=is_logging(stderr) ? 100 : Inf"):
+        assert kw in upd, kw
+    sabc = re.search(r"function sabc\(f_dist::DeviceDistance, prior::Distribution;.*?\n    \(algorithm ==", src, re.S).group(0)
+    for kw in ("n_particles=100", "n_simulation=10_000", "algorithm=:single_eps", "resample=2 * n_particles", "v=1.0", "δ=0.1",
+               "checkpoint_history=1", "rank=0", "world=1", "comm_id=nothing"):
+        assert kw in sabc, kw
+    assert "handle::" not in src and "delete!(HOST_CALLBACKS" in src
+
+
+def test_progress_chunking_rule():
+    """The rule that splits update_population! into sabc_update chunks (same function in api.py and in the Julia wrapper):
+    chunks are multiples of checkpoint_history, a checkpoint interval is a multiple of the chunk."""
+    import sabc_amd
+    from sabc_amd.api import progress_chunk
+    for n_pop in (0, 1, 7, 100, 1000, 12345):
+        for cph in (1, 3, 10):
+            for chk in (float("inf"), 100, 50, 7):
+                for bar in (False, True):
+                    c = progress_chunk(n_pop, cph, chk, bar)
+                    assert c >= 1
+                    if c < n_pop:
+                        assert c % cph == 0
+                        if chk != float("inf") and int(chk) % cph == 0:
+                            assert int(chk) % c == 0
+    # the Julia text implements the same rule (kept in step by eye; this pins the tokens that matter)
+    body = re.search(r"function progress_chunk\(.*?\nend", jl_source(), re.S).group(0)
+    for tok in ("k % cph == 0", "(n_pop ÷ 50) ÷ cph * cph", "chunk % bar != 0", "max(chunk, 1)"):
+        assert tok in body

@@ -255,3 +255,24 @@ def test_epsilon_schedules_property(O):
 
     single()
     beta()
+
+
+@pytest.mark.parametrize("case,alg,prop", [("lv_cfg5", "single_eps", "rw"), ("gauss2d_cfg3", "multi_eps", "de"),
+                                           ("gauss1_cfg2", "single_eps", "stretch")])
+def test_rewritten_arithmetic_against_the_literal_expressions(O, case, alg, prop):
+    """The factored Lotka-Volterra step and the weight-form ECDF interpolant were introduced in the oracle and the
+    device code together; a frozen literal form of both (orc_set_literal) must give the same run up to rounding."""
+    from tests.cases import oracle_run
+    n, budget = 600, 600 * 9
+    a = oracle_run(O, case, n, budget, alg, prop)
+    O.set_literal(True)
+    try:
+        b = oracle_run(O, case, n, budget, alg, prop)
+    finally:
+        O.set_literal(False)
+    assert a.counters == b.counters
+    np.testing.assert_allclose(a.theta, b.theta, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.rho, b.rho, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(a.u, b.u, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(a.eps, b.eps, rtol=1e-9)
+    assert not np.array_equal(a.rho, b.rho) or case != "lv_cfg5"      # the two forms do round differently
