@@ -291,6 +291,12 @@ def stream_block(seed, pid, purpose, it, k):
     return [int(x) for x in o]
 
 
+def u52(hi, lo):
+    L = lib()
+    L.orc_u52.argtypes, L.orc_u52.restype = [C.c_uint32, C.c_uint32], C.c_double
+    return float(L.orc_u52(hi, lo))
+
+
 def normal_pair(seed, pid, purpose, it, k):
     z = np.zeros(2)
     lib().orc_normal_pair(seed, pid, purpose, it, k, _dp(z))

@@ -191,6 +191,11 @@ int Engine::drain_history() {
 // kernel takes ubar from there); leaves the sums of the resampled population in its place.
 int Engine::resample(double delta, uint64_t iter) {
   const int d = m_.d, s = m_.s;
+  if (sh_.world == 1) {
+    int64_t rows = -1;
+    if (be_->resample_local(delta, iter, &rows)) return fail(SABC_ERR_HIP, "resample kernels failed");   // :126-132
+    return rows >= 0 ? global_reduce(rows) : stats_reduce();
+  }
   if (be_->resample_weights(delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :126-127
   const int64_t rows = d + s + 1;
   if (sh_.world > 1 && coll_->has_alltoallv()) {

@@ -82,6 +82,14 @@ class Backend {
   virtual int resample_bucket(int64_t *counts_host, double *req_out) = 0;
   virtual int resample_serve(const double *req_in, int64_t m, double *rows_out) = 0;
   virtual int resample_scatter(const double *rows_in) = 0;
+  // K5 on ONE shard, everything in one call: weights, scan, draws, gather.  A backend that also leaves the moment sums of
+  // the resampled population in its partial rows says how many through stats_rows (the engine then skips the stats pass);
+  // the default runs the two steps above and leaves the sums to the caller (*stats_rows = -1).
+  virtual int resample_local(double delta, uint64_t iter, int64_t *stats_rows) {
+    *stats_rows = -1;
+    if (resample_weights(delta)) return -1;
+    return resample_draw(pop_block(), iter);
+  }
   virtual double last_ess() = 0;
   // state import/export (host buffers, column-major n_local x k)
   virtual int download(double *theta, double *u, double *rho) = 0;

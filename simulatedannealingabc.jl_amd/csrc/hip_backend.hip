@@ -30,7 +30,7 @@ HipBackend::~HipBackend() {
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_};
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_, stage_dev_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   for (double *p : scratch_)
@@ -131,8 +131,9 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
   HB_CHECK(hipMalloc((void **)&block_sums_, (size_t)weight_scan_doubles((int64_t)N) * sizeof(double)), "hipMalloc(block_sums)");
   HB_CHECK(hipMalloc((void **)&totals_dev_, 2 * sizeof(double)), "hipMalloc(totals)");
-  HB_CHECK(hipHostMalloc((void **)&totals_host_, 2 * sizeof(double)), "hipHostMalloc(totals)");
+  HB_CHECK(hipHostMalloc((void **)&totals_host_, 2 * sizeof(double), hipHostMallocMapped), "hipHostMalloc(totals)");
   totals_host_[0] = totals_host_[1] = 0.0;
+  HB_CHECK(hipHostGetDevicePointer((void **)&totals_host_dev_, totals_host_, 0), "hipHostGetDevicePointer(totals)");
   HB_CHECK(hipMalloc((void **)&meta_dev_, 2 * kMaxStats * sizeof(int64_t)), "hipMalloc(meta)");
   return 0;
 }
@@ -494,12 +495,25 @@ int HipBackend::resample_weights(double delta) {
 int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
   const int rows = m_.d + m_.s + 1;
   prof_begin(SABC_KERNEL_RESAMPLE);
-  HB_LAUNCH(launch_weight_scan(gathered_pop, rows, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, stream_), "weight scan");
+  HB_LAUNCH(launch_weight_scan(gathered_pop, rows, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
   const int nxt = 1 - cur_;
   HB_LAUNCH(launch_resample_gather(m_, gathered_pop, rows, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_),
             "k_resample_gather");
   prof_end(SABC_KERNEL_RESAMPLE);
-  HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
+  cur_ = nxt;
+  return 0;
+}
+
+// one shard: the whole of :124-137 in four launches (kernels.hpp: launch_resample_local)
+int HipBackend::resample_local(double delta, uint64_t iter, int64_t *stats_rows) {
+  if (!stage_dev_)
+    HB_CHECK(hipMalloc((void **)&stage_dev_, (size_t)(sh_.cap > 0 ? sh_.cap : 1) * (size_t)(m_.d + m_.s) * sizeof(double)), "hipMalloc(resample staging)");
+  if (pending_rows_ >= 0 && flush_reduce()) return -1;      // the partial rows are about to be overwritten
+  const int nxt = 1 - cur_;
+  prof_begin(SABC_KERNEL_RESAMPLE);
+  HB_LAUNCH(launch_resample_local(m_, pop_ptrs(cur_), pop_ptrs(nxt), cb_dev_, delta, iter, block_sums_, cum_, totals_dev_, totals_host_dev_,
+                                  stage_dev_, partials_, stats_rows, stream_), "resample kernels");
+  prof_end(SABC_KERNEL_RESAMPLE);
   cur_ = nxt;
   return 0;
 }
@@ -514,11 +528,10 @@ int HipBackend::resample_select(const double *gathered_w, uint64_t iter) {
     HB_CHECK(hipHostMalloc((void **)&bucket_host_, 2 * (size_t)sh_.world * sizeof(unsigned long long)), "hipHostMalloc(buckets)");
   }
   prof_begin(SABC_KERNEL_RESAMPLE);
-  HB_LAUNCH(launch_weight_scan(gathered_w, 1, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, stream_), "weight scan");
+  HB_LAUNCH(launch_weight_scan(gathered_w, 1, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
   HB_LAUNCH(launch_resample_select(m_, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(cur_), idx_dev_, stream_),
             "k_resample_select");
   prof_end(SABC_KERNEL_RESAMPLE);
-  HB_CHECK(hipMemcpyAsync(totals_host_, totals_dev_, 2 * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy(totals)");
   return 0;
 }
 

@@ -44,6 +44,7 @@ class HipBackend : public Backend {
   int read_history(double *out, int64_t rows, int row_len) override;
   int resample_weights(double delta) override;
   int resample_draw(const double *gathered_pop, uint64_t iter) override;
+  int resample_local(double delta, uint64_t iter, int64_t *stats_rows) override;
   int resample_select(const double *gathered_w, uint64_t iter) override;
   int resample_bucket(int64_t *counts_host, double *req_out) override;
   int resample_serve(const double *req_in, int64_t m, double *rows_out) override;
@@ -106,7 +107,9 @@ class HipBackend : public Backend {
   int64_t *idx_dev_ = nullptr, *slot_dev_ = nullptr;      // sharded resample: drawn source indices, reply -> destination
   unsigned long long *bucket_dev_ = nullptr;              // [2][world]: counts, cursors
   unsigned long long *bucket_host_ = nullptr;             // pinned staging of the same
-  double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr, *totals_host_ = nullptr;
+  double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr;
+  double *totals_host_ = nullptr, *totals_host_dev_ = nullptr;   // pinned + mapped: k_scan_offsets posts (sum w, sum w^2) there
+  double *stage_dev_ = nullptr;                                  // one shard: interleaved (theta, u) copy the gather reads
   double *col_a_ = nullptr, *col_b_ = nullptr;
   void *sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0;

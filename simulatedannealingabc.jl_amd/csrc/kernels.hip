@@ -12,6 +12,7 @@
 //    later in a fixed order (bitwise reproducible for a given grid).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstring>
 #include "control.hpp"
 #include "update_kernel.hpp"
 
@@ -524,17 +525,23 @@ __global__ void __launch_bounds__(kBlock) k_cdf_population(const int d, const in
 // ------------------------------------------------------------------------------------------
 // K5: resample (SimulatedAnnealingABC.jl:124-137)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_resample_weights(const int d, const int s, const PopPtrs pp, const ControlBlock *__restrict__ cb,
-                   const double n_global, const double delta) {
-  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (li >= pp.n_local) return;
+// w_i = exp(-sum_j u_ij delta / ubar_j), :126-127
+__device__ __forceinline__ double particle_weight(const int d, const int s, const PopPtrs &pp, const ControlBlock *__restrict__ cb,
+                                                  const double n_global, const double delta, const int64_t li) {
   double a = 0.0;
   for (int j = 0; j < s; ++j) {
     const double ubar = cb->sums[1 + j] / n_global;                                         // :126
     a += pp.pop[(int64_t)(d + j) * pp.cap + li] * delta / ubar;                             // :127
   }
-  pp.pop[(int64_t)(d + s) * pp.cap + li] = exp(-a);
+  return exp(-a);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_resample_weights(const int d, const int s, const PopPtrs pp, const ControlBlock *__restrict__ cb,
+                   const double n_global, const double delta) {
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= pp.n_local) return;
+  pp.pop[(int64_t)(d + s) * pp.cap + li] = particle_weight(d, s, pp, cb, n_global, delta, li);
 }
 
 __device__ __forceinline__ double gathered_weight(const double *g, int rows, int64_t cap, int64_t gid) {
@@ -543,17 +550,33 @@ __device__ __forceinline__ double gathered_weight(const double *g, int rows, int
   return g[(r * rows + (rows - 1)) * cap + o];
 }
 
-// pass 1: per-chunk sums of w and w^2
+// pass 1: per-chunk sums of w and w^2.  One shard (wargs.fused): the weights are computed here from the u rows and
+// written to the weight row on the way (no separate k_resample_weights launch); same arithmetic, same values.
+struct WeightArgs {
+  int fused, d, s, reserved;
+  PopPtrs pp;
+  const ControlBlock *cb;
+  double n_global, delta;
+};
+
 __global__ void __launch_bounds__(kBlock)
 k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n, double *__restrict__ bs,
-            double *__restrict__ bq) {
+            double *__restrict__ bq, const WeightArgs wa) {
   __shared__ double sm[2][kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
   double s = 0.0, q = 0.0;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t i = base + e;
-    const double w = i < n ? gathered_weight(g, rows, cap, i) : 0.0;
+    double w = 0.0;
+    if (i < n) {
+      if (wa.fused) {
+        w = particle_weight(wa.d, wa.s, wa.pp, wa.cb, wa.n_global, wa.delta, i);
+        wa.pp.pop[(int64_t)(wa.d + wa.s) * wa.pp.cap + i] = w;
+      } else {
+        w = gathered_weight(g, rows, cap, i);
+      }
+    }
     s += w; q += w * w;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -571,7 +594,8 @@ k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, con
 // `per` consecutive chunks; the 1024 thread totals are scanned in LDS by a fixed-shape
 // Hillis-Steele network (same result on every run and every shard).
 __global__ void __launch_bounds__(1024)
-k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int64_t nb, double *__restrict__ totals) {
+k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int64_t nb, double *__restrict__ totals,
+               double *__restrict__ totals_host) {
   __shared__ double sa[2][1024];
   __shared__ double sq[1024];
   const int t = threadIdx.x;
@@ -591,15 +615,21 @@ k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int
     if (t < off) sq[t] += sq[t + off];
     __syncthreads();
   }
-  if (t == 0) { totals[0] = sa[cur][1023]; totals[1] = sq[0]; }
+  if (t == 0) {
+    totals[0] = sa[cur][1023]; totals[1] = sq[0];
+    if (totals_host) { totals_host[0] = sa[cur][1023]; totals_host[1] = sq[0]; }   // pinned + mapped: the ESS of :134, no memcpy
+  }
   double run = t > 0 ? sa[cur][t - 1] : 0.0;          // exclusive offset of this thread's first chunk
   for (int64_t b = lo; b < hi; ++b) { const double v = bs[b]; bs[b] = run; run += v; }
 }
 
 // pass 3: inclusive scan inside each chunk + chunk offset
+// stage != nullptr (one shard): the particles' (theta, u) rows are also copied into an interleaved staging array, row_len
+// consecutive doubles per particle, so that a draw of the gather touches ONE line instead of one per row
 __global__ void __launch_bounds__(kBlock)
 k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n,
-             const double *__restrict__ bs, double *__restrict__ cum, double *__restrict__ cm) {
+             const double *__restrict__ bs, double *__restrict__ cum, double *__restrict__ cm, double *__restrict__ stage,
+             const int row_len) {
   __shared__ double sm[kBlock];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
   double w[4];
@@ -626,6 +656,14 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
     // mid level of the resample search: cm[g] = cum at the end of 16-element group g (one 128-byte line of `cum`);
     // weights behind n are 0, so `run` is the total there; groups entirely behind n get +inf
     if ((i & 15) == 15) cm[i >> 4] = (i - 15 < n) ? run : INFINITY;
+  }
+  if (stage) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = base + e;
+      if (i < n)
+        for (int row = 0; row < row_len; ++row) stage[i * row_len + row] = g[(int64_t)row * cap + i];
+    }
   }
 }
 
@@ -688,6 +726,66 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
   split_index(idx, cap, r, o);
   for (int row = 0; row < d + s; ++row)
     dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
+}
+
+// One shard, staged: the draw reads its (theta, u) row from the interleaved staging array (one line), and -- with D, S
+// known at compile time -- the moment sums of the RESAMPLED population (what k_stats would compute in a pass of its
+// own: Sigma, eps and the history row are taken from the resampled population, :348-353) come out of the same kernel,
+// in the same per-workgroup order.
+template <int D, int S>
+__global__ void __launch_bounds__(kBlock)
+k_resample_gather_stats(const uint64_t seed, const double *__restrict__ stage, const int64_t n, const double *__restrict__ cum,
+                        const double *__restrict__ bs, const double *__restrict__ cm, const int64_t nb,
+                        const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst,
+                        const ControlBlock *__restrict__ cb, double *__restrict__ partials) {
+  constexpr int NP = n_partials(D, S), RL = D + S;
+  extern __shared__ double bs_lds[];
+  const bool in_lds = nb <= kGatherCoarseMax;
+  if (in_lds) {
+    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    __syncthreads();
+  }
+  const double *B = in_lds ? bs_lds : bs;
+  double acc[NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li < dst.n_local) {
+    const uint64_t gid = (uint64_t)(dst.gid0 + li);
+    const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
+    const double t = u52(w.x, w.y) * totals[0];
+    const int64_t idx = resample_search(t, B, nb, cm, cum, n);
+    double th[D], u[S], rho[S];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { th[k] = stage[idx * RL + k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = stage[idx * RL + D + j];
+      dst.pop[(int64_t)(D + j) * dst.cap + li] = u[j];
+      rho[j] = dst.rho[(int64_t)j * dst.cap + li];                        // rho stays where it is (:131-132)
+    }
+    moment_terms<D, S>(cb->pivot, false, th, u, rho, acc);
+  }
+  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+}
+
+// the same without the sums, d and s at run time (host-callback and source-compiled simulators)
+__global__ void __launch_bounds__(kBlock)
+k_resample_gather_staged(const uint64_t seed, const int row_len, const double *__restrict__ stage, const int64_t n,
+                         const double *__restrict__ cum, const double *__restrict__ bs, const double *__restrict__ cm,
+                         const int64_t nb, const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
+  extern __shared__ double bs_lds[];
+  const bool in_lds = nb <= kGatherCoarseMax;
+  if (in_lds) {
+    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    __syncthreads();
+  }
+  const double *B = in_lds ? bs_lds : bs;
+  const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (li >= dst.n_local) return;
+  const u32x4 w = stream_block(seed, (uint64_t)(dst.gid0 + li), PURPOSE_RESAMPLE, iter, 0);
+  const int64_t idx = resample_search(u52(w.x, w.y) * totals[0], B, nb, cm, cum, n);
+  for (int row = 0; row < row_len; ++row) dst.pop[(int64_t)row * dst.cap + li] = stage[idx * row_len + row];
 }
 
 // ---- the sharded resample: requests grouped by owner, served by the owner, scattered by the requester ----
@@ -1053,12 +1151,54 @@ int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *
 }
 
 int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
-                       double *cum, double *totals, hipStream_t stream) {
+                       double *cum, double *totals, double *totals_host, hipStream_t stream) {
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   double *bs = block_sums, *bq = block_sums + nb, *cm = block_sums + 2 * nb;
-  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, bq);
-  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum, cm);
+  WeightArgs wa;
+  std::memset(&wa, 0, sizeof(wa));
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, bq, wa);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum, cm,
+                     (double *)nullptr, 0);
+  return SABC_LAUNCH_RC();
+}
+
+// One shard: weights (fused into the first scan pass), scan, staging copy, draw + gather (+ the moment sums of the
+// resampled population when the model's (d, s) is one the kernels are instantiated for): 4 launches.
+// *stats_rows = partial rows written, or -1 when the caller still has to run the stats pass.
+int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const ControlBlock *cb, double delta, uint64_t iter,
+                          double *block_sums, double *cum, double *totals, double *totals_host, double *stage,
+                          double *partials, int64_t *stats_rows, hipStream_t stream) {
+  const int64_t n = src.n_local, cap = src.cap;
+  *stats_rows = -1;
+  if (n <= 0) return 0;
+  const int rows = m.d + m.s + 1, rl = m.d + m.s;
+  const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
+  double *bs = block_sums, *bq = block_sums + nb, *cm = block_sums + 2 * nb;
+  WeightArgs wa;
+  std::memset(&wa, 0, sizeof(wa));
+  wa.fused = 1; wa.d = m.d; wa.s = m.s; wa.pp = src; wa.cb = cb; wa.n_global = (double)n; wa.delta = delta;
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
+  hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, cum, cm,
+                     stage, rl);
+  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
+  const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
+#define CALL(M, D, S)                                                                                                    \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((k_resample_gather_stats<D, S>), grid, block, lds, stream, m.seed, (const double *)stage, n,      \
+                       (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst, \
+                       cb, partials);                                                                                    \
+    *stats_rows = n_blocks(n);                                                                                           \
+  } while (0)
+  if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
+  if (m.model_id == SABC_MODEL_HOST || m.model_id == SABC_MODEL_USER) {
+    hipLaunchKernelGGL(k_resample_gather_staged, grid, block, lds, stream, m.seed, rl, (const double *)stage, n,
+                       (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst);
+    return SABC_LAUNCH_RC();
+  }
+  SABC_DISPATCH_MODEL(m, CALL);
+#undef CALL
   return SABC_LAUNCH_RC();
 }
 

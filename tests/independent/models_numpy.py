@@ -27,6 +27,21 @@ def cfg3(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55):
     obs = np.array(obs_mean)
 
     def sim(th, rng):
+        # sufficient statistics drawn directly instead of the n_obs points: the sample mean is N(theta, Sigma / n_obs), the
+        # scatter matrix is Wishart(n_obs - 1, Sigma) and independent of it (Bartlett decomposition: S = L A A' L')
+        m = len(th)
+        mean = th + (rng.standard_normal((m, 2)) @ L.T) / np.sqrt(n_obs)
+        a11 = np.sqrt(rng.chisquare(n_obs - 1, m))
+        a22 = np.sqrt(rng.chisquare(n_obs - 2, m))
+        a21 = rng.standard_normal(m)
+        A = np.zeros((m, 2, 2))
+        A[:, 0, 0], A[:, 1, 0], A[:, 1, 1] = a11, a21, a22
+        LA = L @ A
+        Sc = LA @ np.transpose(LA, (0, 2, 1)) / (n_obs - 1)
+        return np.stack([np.linalg.norm(mean - obs, axis=1), np.abs(Sc[:, 0, 0] + Sc[:, 1, 1] - obs_varsum),
+                         np.abs(Sc[:, 0, 1] - obs_cov)], axis=1)
+
+    def sim_pointwise(th, rng):                       # the definition itself, for the cross-check in the tests
         x = th[:, None, :] + rng.standard_normal((len(th), n_obs, 2)) @ L.T
         m = x.mean(1)
         c = x - m[:, None, :]
@@ -39,4 +54,5 @@ def cfg3(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55):
     Sig = np.array([[1.0, r], [r, 1.0]])
     Lam = np.eye(2) / 9.0 + n_obs * np.linalg.inv(Sig)
     C = np.linalg.inv(Lam)
-    return dict(sim=sim, sample=sample, logpdf=logpdf, post_mean=C @ (n_obs * np.linalg.inv(Sig) @ obs), post_cov=C)
+    return dict(sim=sim, sim_pointwise=sim_pointwise, sample=sample, logpdf=logpdf,
+                post_mean=C @ (n_obs * np.linalg.inv(Sig) @ obs), post_cov=C)

@@ -37,12 +37,16 @@ def test_cfg2_ecdf_table(cfg2):
     assert np.all(np.diff(u) >= 0) and u[0] >= 0 and u[-1] <= 1
 
 
-def test_cfg2_posterior_matches_analytic_within_1_percent(cfg2):
+def test_cfg2_posterior_mean_matches_analytic_within_1_percent(cfg2):
+    """The population mean is within 1 % of the conjugate posterior mean.  The VARIANCE is deliberately not held to the
+    analytic value: the reference algorithm's population falls through it around update 60-90 and settles ~20 % below
+    (RandomWalk; tests/test_independent_numpy.py and tests/test_gpu_anchors.py show the same trajectory in an independent
+    NumPy restatement) -- UPDATES = 55 happens to sit near the crossing, which is why a 5 % band used to pass here."""
     post_var = 1 / (1 / 4 + 100)
     post_mean = post_var * 100 * y_obs_mean()
     th = cfg2.population
     assert abs(th.mean() / post_mean - 1) < 0.01
-    assert abs(th.var() / post_var - 1) < 0.05          # finite eps; 1 % is asserted against the CPU run below
+    assert 0.7 < th.var() / post_var < 1.6              # on its way through the analytic value, see above
 
 
 def test_cfg2_moments_match_cpu_run_within_1_percent(S, O, cfg2):

@@ -92,6 +92,18 @@ def test_cfg3_multistat_trajectory_oracle_vs_independent_numpy(O):
         np.testing.assert_allclose(x["eps"], y["eps"], rtol=0.30)
 
 
+def test_cfg3_sufficient_statistic_shortcut_is_the_same_distribution():
+    """models_numpy.cfg3 draws the sample mean and the Wishart scatter matrix directly; the point-by-point definition gives
+    the same distribution of distances (two-sample KS per statistic)."""
+    from scipy import stats
+    m = M.cfg3()
+    rng = np.random.default_rng(9)
+    th = rng.normal(0.0, 1.0, (40_000, 2)) + np.array([1.0, -0.5])
+    a, b = m["sim"](th, rng), m["sim_pointwise"](th, rng)
+    for j in range(3):
+        assert stats.ks_2samp(a[:, j], b[:, j]).statistic < 0.012, j
+
+
 def test_operators_oracle_vs_independent_numpy(O):
     """ECDF (np.interp), both epsilon schedules (brentq): value-level agreement with the oracle's operators."""
     rng = np.random.default_rng(5)
