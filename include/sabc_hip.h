@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SABC_ABI_VERSION 1
+#define SABC_ABI_VERSION 2      /* 2: sabc_config gained prior_c / prior_d (Gamma, Beta, truncated Normal priors) */
 #define SABC_MAX_PARA 8
 #define SABC_MAX_STATS 8
 #define SABC_MAX_MODEL_PARAMS 32
@@ -44,8 +44,10 @@ enum { SABC_MODEL_HOST = 0,   /* f_dist stays a host callable (sabc_set_host_sim
        SABC_MODEL_USER = 5    /* f_dist as HIP source, compiled at run time into the fused update kernel
                                  (sabc_register_device_simulator): any d, s within the maxima */ };
 /* `prior` argument as data: product of univariate families (Distributions.jl parametrisation):
-   Normal(mu, sigma), Uniform(a, b), Exponential(theta = scale; second parameter unused), LogNormal(mu, sigma) */
-enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1, SABC_PRIOR_EXPONENTIAL = 2, SABC_PRIOR_LOGNORMAL = 3 };
+   Normal(mu, sigma), Uniform(a, b), Exponential(theta = scale; second parameter unused), LogNormal(mu, sigma),
+   Gamma(alpha = shape, theta = scale), Beta(alpha, beta), truncated(Normal(mu, sigma), lower, upper) */
+enum { SABC_PRIOR_NORMAL = 0, SABC_PRIOR_UNIFORM = 1, SABC_PRIOR_EXPONENTIAL = 2, SABC_PRIOR_LOGNORMAL = 3,
+       SABC_PRIOR_GAMMA = 4, SABC_PRIOR_BETA = 5, SABC_PRIOR_TRUNCNORMAL = 6 };
 /* `proposal` argument (proposals.jl:24 RandomWalk, :85 DifferentialEvolution, :132 StretchMove) */
 enum { SABC_PROP_RANDOMWALK = 0, SABC_PROP_DIFFEVO = 1, SABC_PROP_STRETCH = 2 };
 /* `algorithm` argument (SimulatedAnnealingABC.jl:453,462) */
@@ -84,8 +86,12 @@ typedef struct {
   int32_t n_model_params;
   double  model_params[SABC_MAX_MODEL_PARAMS];
   int32_t prior_kind[SABC_MAX_PARA];
-  double  prior_a[SABC_MAX_PARA]; /* Normal, LogNormal: mu    | Uniform: lower | Exponential: scale theta */
-  double  prior_b[SABC_MAX_PARA]; /* Normal, LogNormal: sigma | Uniform: upper | Exponential: unused */
+  double  prior_a[SABC_MAX_PARA]; /* Normal, LogNormal, truncated Normal: mu    | Uniform: lower | Exponential: scale theta |
+                                     Gamma: shape alpha | Beta: alpha */
+  double  prior_b[SABC_MAX_PARA]; /* Normal, LogNormal, truncated Normal: sigma | Uniform: upper | Exponential: unused |
+                                     Gamma: scale theta | Beta: beta */
+  double  prior_c[SABC_MAX_PARA]; /* truncated Normal: lower bound (others: unused) */
+  double  prior_d[SABC_MAX_PARA]; /* truncated Normal: upper bound (others: unused) */
   int32_t algorithm;              /* SABC_ALG_* */
   int32_t rank;                   /* this process' shard (0 when world == 1) */
   int32_t world;                  /* number of shards (GPUs) */
@@ -214,6 +220,9 @@ SABC_API int sabc_op_eps_multi(const double *ubar, int32_t s, double v, double *
    particle ids pid0..pid0+m-1 at iteration `iter` */
 SABC_API int sabc_op_simulate(sabc_handle *h, const double *theta, int64_t m, uint64_t pid0, uint64_t iter,
                               double *rho_out);
+/* rand(prior) and logpdf(prior, .) on device (SimulatedAnnealingABC.jl:174,314,318) for particle ids pid0..pid0+m-1:
+   theta_out column-major m x d, logpdf_out m values (the log density of each draw) */
+SABC_API int sabc_op_prior(sabc_handle *h, uint64_t pid0, int64_t m, double *theta_out, double *logpdf_out);
 /* Philox4x32-10 block and the Box-Muller pair derived from it, evaluated on device */
 SABC_API int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                             uint32_t out_words[4], double out_normals[2]);

@@ -20,7 +20,7 @@ MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))
-PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL = 0, 1, 2, 3
+PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
 PURPOSE_PRIOR, PURPOSE_SIM, PURPOSE_PROP, PURPOSE_PROP2, PURPOSE_ACCEPT, PURPOSE_RESAMPLE = range(6)
@@ -48,6 +48,8 @@ class Config(C.Structure):
         ("prior_kind", C.c_int32 * MAX_PARA),
         ("prior_a", C.c_double * MAX_PARA),
         ("prior_b", C.c_double * MAX_PARA),
+        ("prior_c", C.c_double * MAX_PARA),
+        ("prior_d", C.c_double * MAX_PARA),
         ("algorithm", C.c_int32),
         ("_pad", C.c_int32),
         ("v", C.c_double),
@@ -165,15 +167,17 @@ def host_simulator(fn, d, s):
 
 def make_config(*, n_particles, n_para, n_stats, model_id, model_params, prior, algorithm=ALG_SINGLE_EPS,
                 v=1.0, delta=0.1, seed=20241220, host_fn=None) -> Config:
-    """prior: list of (kind, a, b) per dimension."""
+    """prior: list of (kind, a, b) or (kind, a, b, c, d) per dimension."""
     cfg = Config()
     cfg.n_particles, cfg.n_para, cfg.n_stats = int(n_particles), int(n_para), int(n_stats)
     cfg.model_id, cfg.n_model_params = int(model_id), len(model_params)
     for i, p in enumerate(model_params):
         cfg.model_params[i] = float(p)
     assert len(prior) == n_para
-    for k, (kind, a, b) in enumerate(prior):
+    for k, desc in enumerate(prior):
+        kind, a, b, c, d = (tuple(desc) + (0.0, 0.0))[:5]
         cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
+        cfg.prior_c[k], cfg.prior_d[k] = float(c), float(d)
     cfg.algorithm, cfg.v, cfg.delta, cfg.seed = int(algorithm), float(v), float(delta), int(seed)
     if host_fn is not None:
         cfg.host_fn = host_fn      # keep a reference to the CFUNCTYPE object alive in the caller

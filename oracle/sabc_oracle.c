@@ -130,18 +130,94 @@ static uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned _
 /* Prior: product of Normal / Uniform.  Distributions.jl rand / logpdf */
 /* as used at SimulatedAnnealingABC.jl:163,174,314,318.                */
 /* ------------------------------------------------------------------ */
+/* standard normal quantile: Wichura, Algorithm AS 241 (PPND16), Applied Statistics 37 (1988) */
+double orc_norm_quantile(double p) {
+  static const double a[8] = { 3.3871328727963666080e0, 1.3314166789178437745e2, 1.9715909503065514427e3, 1.3731693765509461125e4,
+                               4.5921953931549871457e4, 6.7265770927008700853e4, 3.3430575583588128105e4, 2.5090809287301226727e3 };
+  static const double b[8] = { 1.0, 4.2313330701600911252e1, 6.8718700749205790830e2, 5.3941960214247511077e3,
+                               2.1213794301586595867e4, 3.9307895800092710610e4, 2.8729085735721942674e4, 5.2264952788528545610e3 };
+  static const double c[8] = { 1.42343711074968357734e0, 4.63033784615654529590e0, 5.76949722146069140550e0, 3.64784832476320460504e0,
+                               1.27045825245236838258e0, 2.41780725177450611770e-1, 2.27238449892691845833e-2, 7.74545014278341407640e-4 };
+  static const double d[8] = { 1.0, 2.05319162663775882187e0, 1.67638483018380384940e0, 6.89767334985100004550e-1,
+                               1.48103976427480074590e-1, 1.51986665636164571966e-2, 5.47593808499534494600e-4, 1.05075007164441684324e-9 };
+  static const double e[8] = { 6.65790464350110377720e0, 5.46378491116411436990e0, 1.78482653991729133580e0, 2.96560571828504891230e-1,
+                               2.65321895265761230930e-2, 1.24266094738807843860e-3, 2.71155556874348757815e-5, 2.01033439929228813265e-7 };
+  static const double f[8] = { 1.0, 5.99832206555887937690e-1, 1.36929880922735805310e-1, 1.48753612908506148525e-2,
+                               7.86869131145613259100e-4, 1.84631831751005468180e-5, 1.42151175831644588870e-7, 2.04426310338993978564e-15 };
+  const double q = p - 0.5;
+  double num = 0.0, den = 0.0, r;
+  if (fabs(q) <= 0.425) {
+    r = 0.180625 - q * q;
+    for (int i = 7; i >= 0; --i) { num = num * r + a[i]; den = den * r + b[i]; }
+    return q * num / den;
+  }
+  r = q < 0.0 ? p : 1.0 - p;
+  if (!(r > 0.0)) return q < 0.0 ? -INFINITY : INFINITY;
+  r = sqrt(-log(r));
+  if (r <= 5.0) {
+    r -= 1.6;
+    for (int i = 7; i >= 0; --i) { num = num * r + c[i]; den = den * r + d[i]; }
+  } else {
+    r -= 5.0;
+    for (int i = 7; i >= 0; --i) { num = num * r + e[i]; den = den * r + f[i]; }
+  }
+  return q < 0.0 ? -(num / den) : num / den;
+}
+
+static double norm_cdf(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
+
+/* mass of the standard normal between the standardised bounds (complement form in the upper tail) */
+static void truncnormal_mass(const orc_config *cfg, int k, double *p_lo, double *mass) {
+  const double lo = (cfg->prior_c[k] - cfg->prior_a[k]) / cfg->prior_b[k], hi = (cfg->prior_d[k] - cfg->prior_a[k]) / cfg->prior_b[k];
+  *p_lo = norm_cdf(lo);
+  *mass = lo > 0 ? norm_cdf(-lo) - norm_cdf(-hi) : norm_cdf(hi) - norm_cdf(lo);
+}
+
+/* Gamma(shape, 1): Marsaglia & Tsang (2000); attempt t: normal from block base + 8 (2t), uniform from base + 8 (2t+1) */
+static double gamma_sample(uint64_t seed, uint64_t pid, uint32_t base, double shape) {
+  const double al = shape < 1.0 ? shape + 1.0 : shape;
+  const double dd = al - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+  double g = dd, boost = 1.0;
+  for (uint32_t t = 0; t < 64u; ++t) {
+    double z[2];
+    uint32_t w[4];
+    orc_normal_pair(seed, pid, ORC_PURPOSE_PRIOR, 0, base + 8u * (2u * t), z);
+    orc_stream_block(seed, pid, ORC_PURPOSE_PRIOR, 0, base + 8u * (2u * t + 1u), w);
+    if (t == 0) boost = orc_u52(w[2], w[3]);
+    const double v1 = 1.0 + cc * z[0];
+    if (!(v1 > 0.0)) continue;
+    const double v = v1 * v1 * v1;
+    g = dd * v;
+    if (log(orc_u52(w[0], w[1])) < 0.5 * z[0] * z[0] + dd - dd * v + dd * log(v)) break;
+  }
+  return shape < 1.0 ? g * pow(boost, 1.0 / shape) : g;
+}
+
 void orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta) {
   for (int k = 0; k < cfg->n_para; ++k) {
+    const int kind = cfg->prior_kind[k];
+    if (kind == ORC_PRIOR_GAMMA) { theta[k] = cfg->prior_b[k] * gamma_sample(cfg->seed, pid, (uint32_t)k, cfg->prior_a[k]); continue; }
+    if (kind == ORC_PRIOR_BETA) {
+      const double x = gamma_sample(cfg->seed, pid, (uint32_t)k, cfg->prior_a[k]);
+      const double y = gamma_sample(cfg->seed, pid, (uint32_t)k + (1u << 16), cfg->prior_b[k]);
+      theta[k] = x / (x + y);
+      continue;
+    }
     uint32_t w[4];
     orc_stream_block(cfg->seed, pid, ORC_PURPOSE_PRIOR, 0, (uint32_t)k, w);
     double ua = orc_u52(w[0], w[1]);
-    if (cfg->prior_kind[k] == ORC_PRIOR_NORMAL || cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL) {
+    if (kind == ORC_PRIOR_NORMAL || kind == ORC_PRIOR_LOGNORMAL) {
       double ub = orc_u52(w[2], w[3]);
       double z0 = sqrt(-2.0 * log(ua)) * cos(2.0 * ORC_PI * ub);
       double x = cfg->prior_a[k] + cfg->prior_b[k] * z0;
-      theta[k] = cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL ? exp(x) : x;
-    } else if (cfg->prior_kind[k] == ORC_PRIOR_EXPONENTIAL) {
+      theta[k] = kind == ORC_PRIOR_LOGNORMAL ? exp(x) : x;
+    } else if (kind == ORC_PRIOR_EXPONENTIAL) {
       theta[k] = -cfg->prior_a[k] * log(ua);               /* inverse CDF, scale parametrisation */
+    } else if (kind == ORC_PRIOR_TRUNCNORMAL) {            /* inverse CDF on [Phi(lo'), Phi(hi')] */
+      double p_lo, mass;
+      truncnormal_mass(cfg, k, &p_lo, &mass);
+      double x = cfg->prior_a[k] + cfg->prior_b[k] * orc_norm_quantile(p_lo + ua * mass);
+      theta[k] = fmin(fmax(x, cfg->prior_c[k]), cfg->prior_d[k]);
     } else {
       theta[k] = cfg->prior_a[k] + (cfg->prior_b[k] - cfg->prior_a[k]) * ua;
     }
@@ -152,19 +228,32 @@ double orc_prior_logpdf(const orc_config *cfg, const double *theta) {
   double lp = 0.0;
   for (int k = 0; k < cfg->n_para; ++k) {
     double x = theta[k];
+    const double a = cfg->prior_a[k], b = cfg->prior_b[k];
     if (cfg->prior_kind[k] == ORC_PRIOR_NORMAL) {
-      double z = (x - cfg->prior_a[k]) / cfg->prior_b[k];
-      lp += -(z * z + ORC_LOG2PI) / 2.0 - log(cfg->prior_b[k]);
+      double z = (x - a) / b;
+      lp += -(z * z + ORC_LOG2PI) / 2.0 - log(b);
     } else if (cfg->prior_kind[k] == ORC_PRIOR_EXPONENTIAL) {      /* Distributions.Exponential(theta): support x >= 0 */
-      if (x >= 0.0) lp += -x / cfg->prior_a[k] - log(cfg->prior_a[k]);
+      if (x >= 0.0) lp += -x / a - log(a);
       else return -INFINITY;
     } else if (cfg->prior_kind[k] == ORC_PRIOR_LOGNORMAL) {        /* support x > 0 */
       if (x > 0.0) {
-        double lx = log(x), z = (lx - cfg->prior_a[k]) / cfg->prior_b[k];
-        lp += -(z * z + ORC_LOG2PI) / 2.0 - log(cfg->prior_b[k]) - lx;
+        double lx = log(x), z = (lx - a) / b;
+        lp += -(z * z + ORC_LOG2PI) / 2.0 - log(b) - lx;
+      } else return -INFINITY;
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_GAMMA) {            /* Gamma(shape a, scale b) */
+      if (x > 0.0) lp += (a - 1.0) * log(x) - x / b - (lgamma(a) + a * log(b));
+      else return -INFINITY;
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_BETA) {
+      if (x > 0.0 && x < 1.0) lp += (a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - (lgamma(a) + lgamma(b) - lgamma(a + b));
+      else return -INFINITY;
+    } else if (cfg->prior_kind[k] == ORC_PRIOR_TRUNCNORMAL) {      /* truncated(Normal(a, b), c, d) */
+      if (x >= cfg->prior_c[k] && x <= cfg->prior_d[k]) {
+        double p_lo, mass, z = (x - a) / b;
+        truncnormal_mass(cfg, k, &p_lo, &mass);
+        lp += -(z * z + ORC_LOG2PI) / 2.0 - (log(b) + log(mass));
       } else return -INFINITY;
     } else {
-      if (x >= cfg->prior_a[k] && x <= cfg->prior_b[k]) lp += -log(cfg->prior_b[k] - cfg->prior_a[k]);
+      if (x >= a && x <= b) lp += -log(b - a);
       else return -INFINITY;
     }
   }

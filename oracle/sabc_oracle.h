@@ -35,7 +35,8 @@ extern "C" {
 /* model ids (device-coded simulators; see DESIGN.md "Simulators") */
 enum { ORC_MODEL_HOST = 0, ORC_MODEL_GAUSS_IID = 1, ORC_MODEL_GAUSS2D = 2, ORC_MODEL_GK = 3, ORC_MODEL_LV = 4 };
 /* prior kinds (per dimension; product distribution) */
-enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1, ORC_PRIOR_EXPONENTIAL = 2, ORC_PRIOR_LOGNORMAL = 3 };
+enum { ORC_PRIOR_NORMAL = 0, ORC_PRIOR_UNIFORM = 1, ORC_PRIOR_EXPONENTIAL = 2, ORC_PRIOR_LOGNORMAL = 3,
+       ORC_PRIOR_GAMMA = 4, ORC_PRIOR_BETA = 5, ORC_PRIOR_TRUNCNORMAL = 6 };
 /* proposal kinds (proposals.jl:24,85,132) */
 enum { ORC_PROP_RANDOMWALK = 0, ORC_PROP_DIFFEVO = 1, ORC_PROP_STRETCH = 2 };
 /* algorithm (SimulatedAnnealingABC.jl:462) */
@@ -69,7 +70,9 @@ typedef struct {
   double  model_params[ORC_MAX_MODEL_PARAMS];
   int32_t prior_kind[ORC_MAX_PARA];
   double  prior_a[ORC_MAX_PARA];  /* Normal: mu    | Uniform: lower */
-  double  prior_b[ORC_MAX_PARA];  /* Normal: sigma | Uniform: upper */
+  double  prior_b[ORC_MAX_PARA];  /* Normal: sigma | Uniform: upper | Gamma: scale | Beta: beta */
+  double  prior_c[ORC_MAX_PARA];  /* truncated Normal: lower */
+  double  prior_d[ORC_MAX_PARA];  /* truncated Normal: upper */
   int32_t algorithm;
   int32_t _pad;
   double  v;                      /* used by initialization for eps_0 */
@@ -133,6 +136,8 @@ double orc_eps_single(double ubar, double v);
 /* SimulatedAnnealingABC.jl:100-117; ubar[s] column means */
 int    orc_eps_multi(const double *ubar, int s, double v, double *eps_out);
 double orc_multi_eps_beta(double ubar_i);
+/* standard normal quantile (Wichura, AS 241 PPND16) */
+double orc_norm_quantile(double p);
 /* prior */
 double orc_prior_logpdf(const orc_config *cfg, const double *theta);
 void   orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta);

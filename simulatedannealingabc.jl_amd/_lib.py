@@ -15,10 +15,10 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
-PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL = 0, 1, 2, 3
+PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
 KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT = 0, 1, 2, 3
@@ -44,6 +44,7 @@ class Config(C.Structure):
         ("n_para", C.c_int32), ("n_stats", C.c_int32), ("model_id", C.c_int32), ("n_model_params", C.c_int32),
         ("model_params", C.c_double * MAX_MODEL_PARAMS),
         ("prior_kind", C.c_int32 * MAX_PARA), ("prior_a", C.c_double * MAX_PARA), ("prior_b", C.c_double * MAX_PARA),
+        ("prior_c", C.c_double * MAX_PARA), ("prior_d", C.c_double * MAX_PARA),
         ("algorithm", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32),
         ("v", C.c_double), ("delta", C.c_double), ("seed", C.c_uint64),
     ]
@@ -155,6 +156,7 @@ def bind(L, strict=True):
         "sabc_op_eps_single": ([C.c_double, C.c_double, dp], C.c_int),
         "sabc_op_eps_multi": ([dp, C.c_int32, C.c_double, dp], C.c_int),
         "sabc_op_simulate": ([vp, dp, C.c_int64, C.c_uint64, C.c_uint64, dp], C.c_int),
+        "sabc_op_prior": ([vp, C.c_uint64, C.c_int64, dp, dp], C.c_int),
         "sabc_op_philox": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                             C.POINTER(C.c_uint32), dp], C.c_int),
         "sabc_op_normal_pairs": ([C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int64, dp],

@@ -142,9 +142,15 @@ def as_host_distance(f_dist, prior, args=(), kwargs=None):
     The wrapper lives on the SABCresult it initialises (`update_population_` finds it there): nothing is cached
     per process, so a prior of another dimension can never meet a stale wrapper and no closure outlives its result."""
     rng = np.random.default_rng()
-    draw = {_lib.PRIOR_NORMAL: lambda a, b: rng.normal(a, b), _lib.PRIOR_UNIFORM: lambda a, b: rng.uniform(a, b),
-            _lib.PRIOR_EXPONENTIAL: lambda a, b: rng.exponential(a), _lib.PRIOR_LOGNORMAL: lambda a, b: rng.lognormal(a, b)}
-    θ = np.array([draw[k](a, b) for k, a, b in prior.descriptors()])
+
+    def truncnorm(a, b, c, d):
+        from scipy import stats
+        return float(stats.truncnorm.rvs((c - a) / b, (d - a) / b, loc=a, scale=b, random_state=rng))
+    draw = {_lib.PRIOR_NORMAL: lambda a, b, c, d: rng.normal(a, b), _lib.PRIOR_UNIFORM: lambda a, b, c, d: rng.uniform(a, b),
+            _lib.PRIOR_EXPONENTIAL: lambda a, b, c, d: rng.exponential(a), _lib.PRIOR_LOGNORMAL: lambda a, b, c, d: rng.lognormal(a, b),
+            _lib.PRIOR_GAMMA: lambda a, b, c, d: rng.gamma(a, b), _lib.PRIOR_BETA: lambda a, b, c, d: rng.beta(a, b),
+            _lib.PRIOR_TRUNCNORMAL: truncnorm}
+    θ = np.array([draw[desc[0]](*(tuple(desc[1:]) + (0.0, 0.0))[:4]) for desc in prior.descriptors()])
     probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
     hd = HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
                       univariate=prior.univariate, args=args, kwargs=kwargs)
@@ -182,7 +188,8 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     if alg not in _ALGORITHMS:                                                # :462-464
         raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
     if not isinstance(prior, Distribution):
-        raise TypeError("prior must be Normal, Uniform, Exponential, LogNormal or product_distribution([...]) of those")
+        raise TypeError("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal) or "
+                        "product_distribution([...]) of those")
     if not isinstance(f_dist, DeviceDistance):
         if not callable(f_dist):
             raise TypeError("f_dist must be a DeviceDistance or a callable f_dist(θ, *args, **kwargs)")

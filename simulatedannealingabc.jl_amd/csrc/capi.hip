@@ -515,6 +515,11 @@ int sabc_op_simulate(sabc_handle *h, const double *theta, int64_t m, uint64_t pi
   return h->be->simulate_host(theta, m, pid0, iter, rho_out) ? hfail(h, SABC_ERR_HIP) : 0;
 }
 
+int sabc_op_prior(sabc_handle *h, uint64_t pid0, int64_t m, double *theta_out, double *logpdf_out) {
+  if (!h || !theta_out || !logpdf_out) return SABC_ERR_STATE;
+  return h->be->prior_host(pid0, m, theta_out, logpdf_out) ? hfail(h, SABC_ERR_HIP) : 0;
+}
+
 int sabc_op_philox(int32_t device, uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                    uint32_t out_words[4], double out_normals[2]) {
   std::string why;

@@ -3,6 +3,7 @@
 // (cdf_estimators.jl:39-42,68-70) as gfx950 device functions.
 #pragma once
 #include "device_rng.hpp"
+#include "prior_math.hpp"
 #include "kernels.hpp"
 #include "sabc_types.hpp"
 
@@ -16,26 +17,66 @@ namespace sabc {
 
 #define SABC_LOG2PI 1.8378770664093454835606594728112
 
-// ---- prior: product of univariate Normal / Uniform / Exponential / LogNormal ----
-// one dimension of Distributions.logpdf (:314,318); -inf outside the support
-// lc = the log of the family's scale constant, computed once on the host (ModelDesc::prior_logc):
-// log(sigma), log(b - a), log(theta)
-__device__ __forceinline__ double prior_logpdf_1d(int kind, double a, double b, double lc, double x) {
+// ---- prior: product of univariate Normal / Uniform / Exponential / LogNormal / Gamma / Beta / truncated Normal ----
+// one dimension of Distributions.logpdf (:314,318); -inf outside the support.
+// ModelDesc::prior_logc holds the family's normalising constant, computed once on the host (engine.cpp).
+__device__ __forceinline__ double prior_logpdf_dim(const ModelDesc &m, int k, double x) {
+  const int kind = m.prior_kind[k];
+  const double a = m.prior_a[k], b = m.prior_b[k], lc = m.prior_logc[k];
   if (kind == SABC_PRIOR_NORMAL) {
     const double z = (x - a) / b;
     return -(z * z + SABC_LOG2PI) / 2.0 - lc;
   }
   if (kind == SABC_PRIOR_UNIFORM) return (x >= a && x <= b) ? -lc : -INFINITY;
   if (kind == SABC_PRIOR_EXPONENTIAL) return x >= 0.0 ? -x / a - lc : -INFINITY;
-  if (x > 0.0) {                                               // LogNormal(mu = a, sigma = b)
+  if (kind == SABC_PRIOR_LOGNORMAL) {                           // LogNormal(mu = a, sigma = b)
+    if (!(x > 0.0)) return -INFINITY;
     const double lx = log(x), z = (lx - a) / b;
     return -(z * z + SABC_LOG2PI) / 2.0 - lc - lx;
+  }
+  if (kind == SABC_PRIOR_GAMMA)                                 // Gamma(shape a, scale b)
+    return x > 0.0 ? (a - 1.0) * log(x) - x / b - lc : -INFINITY;
+  if (kind == SABC_PRIOR_BETA)                                  // Beta(a, b)
+    return (x > 0.0 && x < 1.0) ? (a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lc : -INFINITY;
+  if (kind == SABC_PRIOR_TRUNCNORMAL) {                         // truncated(Normal(a, b), c, d)
+    if (!(x >= m.prior_c[k] && x <= m.prior_d[k])) return -INFINITY;
+    const double z = (x - a) / b;
+    return -(z * z + SABC_LOG2PI) / 2.0 - lc;
   }
   return -INFINITY;
 }
 
-// one dimension of rand(prior) (:174) from one Philox block
-__device__ __forceinline__ double prior_sample_1d(int kind, double a, double b, const u32x4 w) {
+// Gamma(shape, 1) by Marsaglia & Tsang (ACM TOMS 26, 2000); attempt t takes its normal from block base + 8 (2t) and its
+// uniform from block base + 8 (2t + 1) of the particle's PRIOR stream (the stride 8 keeps the dimensions apart); shape < 1
+// is drawn as Gamma(shape + 1) U^(1/shape) with U the second uniform of the first uniform block
+__device__ __forceinline__ double gamma_sample(uint64_t seed, uint64_t pid, uint32_t base, double shape) {
+  const double al = shape < 1.0 ? shape + 1.0 : shape;
+  const double dd = al - 1.0 / 3.0, cc = 1.0 / sqrt(9.0 * dd);
+  double g = dd, boost = 1.0;
+  for (uint32_t t = 0; t < 64u; ++t) {
+    double z0, z1;
+    box_muller(stream_block(seed, pid, PURPOSE_PRIOR, 0, base + 8u * (2u * t)), z0, z1);
+    const u32x4 w = stream_block(seed, pid, PURPOSE_PRIOR, 0, base + 8u * (2u * t + 1u));
+    if (t == 0) boost = u52(w.z, w.w);
+    const double v1 = 1.0 + cc * z0;
+    if (!(v1 > 0.0)) continue;
+    const double v = v1 * v1 * v1;
+    g = dd * v;
+    if (log(u52(w.x, w.y)) < 0.5 * z0 * z0 + dd - dd * v + dd * log(v)) break;
+  }
+  return shape < 1.0 ? g * pow(boost, 1.0 / shape) : g;
+}
+
+// one dimension of rand(prior) (:174): dimension k draws from blocks k, k + 8, k + 16, ... of the PRIOR stream
+__device__ __forceinline__ double prior_sample_dim(const ModelDesc &m, int k, uint64_t pid) {
+  const int kind = m.prior_kind[k];
+  const double a = m.prior_a[k], b = m.prior_b[k];
+  if (kind == SABC_PRIOR_GAMMA) return b * gamma_sample(m.seed, pid, (uint32_t)k, a);
+  if (kind == SABC_PRIOR_BETA) {
+    const double x = gamma_sample(m.seed, pid, (uint32_t)k, a), y = gamma_sample(m.seed, pid, (uint32_t)k + (1u << 16), b);
+    return x / (x + y);
+  }
+  const u32x4 w = stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k);
   if (kind == SABC_PRIOR_NORMAL || kind == SABC_PRIOR_LOGNORMAL) {
     double z0, z1;
     box_muller(w, z0, z1);
@@ -44,6 +85,10 @@ __device__ __forceinline__ double prior_sample_1d(int kind, double a, double b, 
   }
   const double ua = u52(w.x, w.y);
   if (kind == SABC_PRIOR_EXPONENTIAL) return -a * log(ua);
+  if (kind == SABC_PRIOR_TRUNCNORMAL) {                         // inverse CDF on [Phi(lo'), Phi(hi')]
+    const double x = a + b * hostmath::norm_quantile(m.prior_k0[k] + ua * m.prior_k1[k]);
+    return fmin(fmax(x, m.prior_c[k]), m.prior_d[k]);
+  }
   return a + (b - a) * ua;
 }
 
@@ -52,19 +97,17 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
   double lp = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], m.prior_logc[k], th[k]);
+    const double l = prior_logpdf_dim(m, k, th[k]);
     lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
 }
 
-// rand(prior) at :174; dimension k uses block k of the PRIOR stream
+// rand(prior) at :174
 template <int D>
 __device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
 #pragma unroll
-  for (int k = 0; k < D; ++k)
-    th[k] = prior_sample_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k],
-                            stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k));
+  for (int k = 0; k < D; ++k) th[k] = prior_sample_dim(m, k, pid);
 }
 
 // ---- empirical CDF: knots T[0..len), ordinates k/(len-1), piecewise linear, flat outside ----

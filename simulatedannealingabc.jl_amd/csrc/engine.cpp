@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "control.hpp"
+#include "prior_math.hpp"
 
 namespace sabc {
 
@@ -21,9 +22,24 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
     m_.prior_kind[k] = cfg.prior_kind[k];
     m_.prior_a[k] = cfg.prior_a[k];
     m_.prior_b[k] = cfg.prior_b[k];
-    const double scale = cfg.prior_kind[k] == SABC_PRIOR_UNIFORM ? cfg.prior_b[k] - cfg.prior_a[k]
-                         : cfg.prior_kind[k] == SABC_PRIOR_EXPONENTIAL ? cfg.prior_a[k] : cfg.prior_b[k];
-    m_.prior_logc[k] = scale > 0 ? std::log(scale) : 0.0;
+    m_.prior_c[k] = cfg.prior_c[k];
+    m_.prior_d[k] = cfg.prior_d[k];
+    const double a = cfg.prior_a[k], b = cfg.prior_b[k];
+    // the normalising constant of each family's logpdf, once, on the host
+    if (cfg.prior_kind[k] == SABC_PRIOR_GAMMA) {
+      m_.prior_logc[k] = (a > 0 && b > 0) ? std::lgamma(a) + a * std::log(b) : 0.0;
+    } else if (cfg.prior_kind[k] == SABC_PRIOR_BETA) {
+      m_.prior_logc[k] = (a > 0 && b > 0) ? std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b) : 0.0;
+    } else if (cfg.prior_kind[k] == SABC_PRIOR_TRUNCNORMAL) {
+      const double lo = b > 0 ? (cfg.prior_c[k] - a) / b : 0.0, hi = b > 0 ? (cfg.prior_d[k] - a) / b : 0.0;
+      m_.prior_k0[k] = hostmath::norm_cdf(lo);
+      // the mass between the bounds; for bounds in the upper tail the complement form keeps its digits
+      m_.prior_k1[k] = lo > 0 ? hostmath::norm_cdf(-lo) - hostmath::norm_cdf(-hi) : hostmath::norm_cdf(hi) - hostmath::norm_cdf(lo);
+      m_.prior_logc[k] = (b > 0 && m_.prior_k1[k] > 0) ? std::log(b) + std::log(m_.prior_k1[k]) : 0.0;
+    } else {
+      const double scale = cfg.prior_kind[k] == SABC_PRIOR_UNIFORM ? b - a : cfg.prior_kind[k] == SABC_PRIOR_EXPONENTIAL ? a : b;
+      m_.prior_logc[k] = scale > 0 ? std::log(scale) : 0.0;
+    }
   }
   m_.seed = cfg.seed;
   const int world = cfg.world < 1 ? 1 : cfg.world;
@@ -77,6 +93,15 @@ int Engine::validate() {
       if (!(cfg_.prior_a[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Exponential prior needs scale > 0");
     } else if (cfg_.prior_kind[k] == SABC_PRIOR_LOGNORMAL) {
       if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "LogNormal prior needs sigma > 0");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_GAMMA) {
+      if (!(cfg_.prior_a[k] > 0 && cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Gamma prior needs shape > 0 and scale > 0");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_BETA) {
+      if (!(cfg_.prior_a[k] > 0 && cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Beta prior needs alpha > 0 and beta > 0");
+    } else if (cfg_.prior_kind[k] == SABC_PRIOR_TRUNCNORMAL) {
+      if (!(cfg_.prior_b[k] > 0 && cfg_.prior_d[k] > cfg_.prior_c[k]))
+        return fail(SABC_ERR_BAD_CONFIG, "truncated Normal prior needs sigma > 0 and upper > lower");
+      if (!(m_.prior_k1[k] > 1e-300))
+        return fail(SABC_ERR_BAD_CONFIG, "truncated Normal prior: no probability mass between the bounds");
     } else {
       return fail(SABC_ERR_BAD_CONFIG, "unknown prior kind");
     }

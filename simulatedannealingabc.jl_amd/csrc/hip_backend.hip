@@ -633,6 +633,20 @@ int HipBackend::cdf_apply_host(const double *rho, int64_t m, double *u_out) {
   return rc;
 }
 
+int HipBackend::prior_host(uint64_t pid0, int64_t n, double *theta_out, double *logpdf_out) {
+  if (n <= 0) return 0;
+  double *d_th = nullptr, *d_lp = nullptr;
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  HB_CHECK(hipMalloc((void **)&d_th, (size_t)n * m_.d * sizeof(double)), "hipMalloc");
+  HB_CHECK(hipMalloc((void **)&d_lp, (size_t)n * sizeof(double)), "hipMalloc");
+  int rc = check((hipError_t)launch_prior_op(m_, pid0, n, d_th, d_lp, stream_), "k_prior_op");
+  if (!rc) rc = check(hipMemcpyAsync(theta_out, d_th, (size_t)n * m_.d * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
+  if (!rc) rc = check(hipMemcpyAsync(logpdf_out, d_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
+  if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  (void)hipFree(d_th); (void)hipFree(d_lp);
+  return rc;
+}
+
 int HipBackend::simulate_host(const double *theta, int64_t n, uint64_t pid0, uint64_t iter, double *rho_out) {
   if (n <= 0) return 0;
   double *d_in = nullptr, *d_out = nullptr;

@@ -64,6 +64,7 @@ class HipBackend : public Backend {
   void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
   int cdf_apply_host(const double *rho, int64_t m, double *u_out);
   int simulate_host(const double *theta, int64_t n, uint64_t pid0, uint64_t iter, double *rho_out);
+  int prior_host(uint64_t pid0, int64_t n, double *theta_out, double *logpdf_out);   // sabc_op_prior
   void profile_enable(int level);
   int profile_get(int kernel, double *total_ms, int64_t *launches);
   // host staging for collectives that cannot take device pointers

@@ -14,6 +14,7 @@
 #else
 #define SABC_HD
 #endif
+#include "prior_math.hpp"
 
 namespace sabc {
 namespace hostmath {

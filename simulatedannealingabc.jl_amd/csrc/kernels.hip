@@ -262,7 +262,7 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
 __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
   double lp = 0.0;
   for (int k = 0; k < m.d; ++k) {
-    const double l = prior_logpdf_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k], m.prior_logc[k], th[k]);
+    const double l = prior_logpdf_dim(m, k, th[k]);
     lp = (l > -INFINITY && lp > -INFINITY) ? lp + l : -INFINITY;
   }
   return lp;
@@ -275,8 +275,7 @@ __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const 
   if (li >= pp.n_local) return;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
   for (int k = 0; k < m.d; ++k)
-    pp.pop[(int64_t)k * pp.cap + li] = prior_sample_1d(m.prior_kind[k], m.prior_a[k], m.prior_b[k],
-                                                         stream_block(m.seed, gid, PURPOSE_PRIOR, 0, (uint32_t)k));
+    pp.pop[(int64_t)k * pp.cap + li] = prior_sample_dim(m, k, gid);
 }
 
 // thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor)
@@ -930,6 +929,17 @@ k_cdf_apply_matrix(const CdfPtrs cdf, const int s, const double *__restrict__ rh
     u[(int64_t)j * m + i] = cdf_apply(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], rho[(int64_t)j * m + i]);
 }
 
+// rand(prior) and its log density for particle ids pid0.. (sabc_op_prior)
+__global__ void __launch_bounds__(kBlock)
+k_prior_op(const ModelDesc m, const uint64_t pid0, const int64_t n, double *__restrict__ theta, double *__restrict__ lp) {
+  rng_tables_init();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double th[kMaxPara];
+  for (int k = 0; k < m.d; ++k) { th[k] = prior_sample_dim(m, k, pid0 + (uint64_t)i); theta[(int64_t)k * n + i] = th[k]; }
+  lp[i] = prior_logpdf_rt(m, th);
+}
+
 __global__ void k_philox_debug(uint64_t seed, uint64_t pid, uint32_t purpose, uint64_t iter, uint32_t k,
                                uint32_t *words, double *normals) {
   rng_tables_init();
@@ -1306,6 +1316,12 @@ int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, ui
 #define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out)
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
+  return SABC_LAUNCH_RC();
+}
+
+int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_prior_op, dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, m, pid0, n, theta, lp);
   return SABC_LAUNCH_RC();
 }
 

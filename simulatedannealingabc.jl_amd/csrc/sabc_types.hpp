@@ -14,8 +14,11 @@ struct ModelDesc {
   int32_t model_id, d, s, n_model_params;
   double p[SABC_MAX_MODEL_PARAMS];
   int32_t prior_kind[kMaxPara];
-  double prior_a[kMaxPara], prior_b[kMaxPara];
-  double prior_logc[kMaxPara];   // log sigma | log(b - a) | log theta: the scale constant of logpdf, once on the host
+  double prior_a[kMaxPara], prior_b[kMaxPara], prior_c[kMaxPara], prior_d[kMaxPara];
+  // the normalising constant of logpdf, once on the host: log sigma | log(b - a) | log theta | lgamma(alpha) + alpha log theta
+  // | log B(alpha, beta) | log sigma + log(Phi(hi') - Phi(lo'))
+  double prior_logc[kMaxPara];
+  double prior_k0[kMaxPara], prior_k1[kMaxPara];   // truncated Normal: Phi(lo'), Phi(hi') - Phi(lo') of the standardised bounds
   uint64_t seed;
 };
 

@@ -1,7 +1,7 @@
 """Priors as data.  The reference takes any `Distributions.Distribution` and calls `rand`,
 `logpdf` and `length` on it (SimulatedAnnealingABC.jl:163,174,254,314,318); the device path
-needs the prior as a descriptor, so the supported set is products of univariate Normal and
-Uniform.  Names follow Distributions.jl."""
+needs the prior as a descriptor: products of univariate Normal, Uniform, Exponential, LogNormal, Gamma, Beta and
+truncated Normal.  Names and parametrisations follow Distributions.jl."""
 from __future__ import annotations
 
 from . import _lib
@@ -91,13 +91,77 @@ class LogNormal(Distribution):
         return f"LogNormal(μ={self.μ}, σ={self.σ})"
 
 
+class Gamma(Distribution):
+    """Gamma(α, θ): shape α, scale θ (mean αθ), as in Distributions.jl."""
+
+    def __init__(self, α=1.0, θ=1.0):
+        if not (α > 0 and θ > 0):
+            raise ValueError("Gamma: shape α and scale θ must be positive")
+        self.α, self.θ = float(α), float(θ)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_GAMMA, self.α, self.θ)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"Gamma(α={self.α}, θ={self.θ})"
+
+
+class Beta(Distribution):
+    """Beta(α, β) on (0, 1)."""
+
+    def __init__(self, α=1.0, β=1.0):
+        if not (α > 0 and β > 0):
+            raise ValueError("Beta: α and β must be positive")
+        self.α, self.β = float(α), float(β)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_BETA, self.α, self.β)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"Beta(α={self.α}, β={self.β})"
+
+
+class TruncatedNormal(Distribution):
+    """truncated(Normal(μ, σ), lower, upper) of Distributions.jl."""
+
+    def __init__(self, μ=0.0, σ=1.0, lower=-1.0, upper=1.0):
+        if not (σ > 0 and upper > lower):
+            raise ValueError("TruncatedNormal: σ must be positive and upper must exceed lower")
+        self.μ, self.σ, self.lower, self.upper = float(μ), float(σ), float(lower), float(upper)
+
+    def descriptors(self):
+        return [(_lib.PRIOR_TRUNCNORMAL, self.μ, self.σ, self.lower, self.upper)]
+
+    @property
+    def univariate(self):
+        return True
+
+    def __repr__(self):
+        return f"truncated(Normal(μ={self.μ}, σ={self.σ}), {self.lower}, {self.upper})"
+
+
+def truncated(dist, lower, upper):
+    """`truncated(Normal(μ, σ), lower, upper)` as in Distributions.jl (only Normal is supported)."""
+    if not isinstance(dist, Normal):
+        raise TypeError("only truncated(Normal(...), lower, upper) is available as a device prior")
+    return TruncatedNormal(dist.μ, dist.σ, lower, upper)
+
+
 class Product(Distribution):
     """`product_distribution([...])` of univariate components (test/runtests.jl:87-88)."""
 
     def __init__(self, components):
         self.components = list(components)
         if not self.components or not all(isinstance(c, Distribution) and c.univariate for c in self.components):
-            raise ValueError("product_distribution needs univariate Normal / Uniform / Exponential / LogNormal components")
+            raise ValueError("product_distribution needs univariate components (Normal, Uniform, Exponential, LogNormal, Gamma, Beta, TruncatedNormal)")
         if len(self.components) > _lib.MAX_PARA:
             raise ValueError(f"at most {_lib.MAX_PARA} parameters are supported")
 

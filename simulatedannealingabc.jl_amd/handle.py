@@ -29,8 +29,10 @@ class SabcHandle:
         cfg.n_model_params = len(params)
         for i, p in enumerate(params):
             cfg.model_params[i] = float(p)
-        for k, (kind, a, b) in enumerate(prior.descriptors()):
+        for k, desc in enumerate(prior.descriptors()):
+            kind, a, b, c, d = (tuple(desc) + (0.0, 0.0))[:5]
             cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
+            cfg.prior_c[k], cfg.prior_d[k] = float(c), float(d)
         cfg.algorithm = int(algorithm)
         cfg.rank, cfg.world = int(rank), int(world)
         cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)
@@ -214,6 +216,12 @@ class SabcHandle:
         out = np.empty((self.s, th.shape[1]))
         self._check(self._L.sabc_op_simulate(self._h, _dp(th), th.shape[1], int(pid0), int(it), _dp(out)))
         return out
+
+    def prior(self, pid0, m):
+        """rand(prior) for particle ids pid0.. and the log density of each draw, on the device: (theta [d][m], logpdf [m])."""
+        th, lp = np.empty((self.d, int(m))), np.empty(int(m))
+        self._check(self._L.sabc_op_prior(self._h, int(pid0), int(m), _dp(th), _dp(lp)))
+        return th, lp
 
     # ---- measurement ----
     @property

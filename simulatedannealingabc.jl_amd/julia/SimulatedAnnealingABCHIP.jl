@@ -12,7 +12,7 @@
 # argument list against the prototypes of include/sabc_hip.h, and the enum values used below.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, UnivariateDistribution
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, UnivariateDistribution
 using ProgressMeter: Progress, next!, finish!          # same progress UI as the reference (:290-292,374)
 import Dates
 import Base: show
@@ -37,6 +37,8 @@ struct CConfig
     prior_kind::NTuple{MAX_PARA,Int32}
     prior_a::NTuple{MAX_PARA,Float64}
     prior_b::NTuple{MAX_PARA,Float64}
+    prior_c::NTuple{MAX_PARA,Float64}
+    prior_d::NTuple{MAX_PARA,Float64}
     algorithm::Int32
     rank::Int32
     world::Int32
@@ -150,17 +152,20 @@ function host_callback(m::HostDistance)
     @cfunction($cb, Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int64, UInt64, Ptr{Float64}))
 end
 
-# ---- priors as data: Normal, Uniform and products of those ----
-prior_descriptor(d::Normal) = (Int32(0), d.μ, d.σ)
-prior_descriptor(d::Uniform) = (Int32(1), d.a, d.b)
-prior_descriptor(d::Exponential) = (Int32(2), d.θ, 0.0)
-prior_descriptor(d::LogNormal) = (Int32(3), d.μ, d.σ)
+# ---- priors as data: (kind, a, b, c, d) per dimension, include/sabc_hip.h SABC_PRIOR_* ----
+prior_descriptor(d::Normal) = (Int32(0), d.μ, d.σ, 0.0, 0.0)
+prior_descriptor(d::Uniform) = (Int32(1), d.a, d.b, 0.0, 0.0)
+prior_descriptor(d::Exponential) = (Int32(2), d.θ, 0.0, 0.0, 0.0)
+prior_descriptor(d::LogNormal) = (Int32(3), d.μ, d.σ, 0.0, 0.0)
+prior_descriptor(d::Gamma) = (Int32(4), d.α, d.θ, 0.0, 0.0)
+prior_descriptor(d::Beta) = (Int32(5), d.α, d.β, 0.0, 0.0)
+prior_descriptor(d::Truncated{<:Normal}) = (Int32(6), d.untruncated.μ, d.untruncated.σ, Float64(d.lower), Float64(d.upper))
 prior_descriptors(d::UnivariateDistribution) = [prior_descriptor(d)]
 # product_distribution([...]): Distributions.jl names the vector of marginals `v` (Product, <= 0.25.x) or `dists`
 # (ProductDistribution); neither has an exported accessor, so both spellings are accepted and anything else is refused
 function prior_descriptors(d::Distribution)
     comps = hasproperty(d, :v) ? getproperty(d, :v) : hasproperty(d, :dists) ? getproperty(d, :dists) :
-            error("prior must be Normal, Uniform, Exponential, LogNormal or product_distribution([...]) of those")
+            error("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal) or product_distribution([...]) of those")
     [prior_descriptor(c) for c in comps]
 end
 
@@ -216,10 +221,11 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
                        comm_id=nothing)
     pd = prior_descriptors(prior)
     p = params(f_dist)
-    cfg = Ref(CConfig(1, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
+    cfg = Ref(CConfig(2, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
-                      padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(last.(pd), MAX_PARA, Float64),
+                      padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(getindex.(pd, 3), MAX_PARA, Float64),
+                      padtuple(getindex.(pd, 4), MAX_PARA, Float64), padtuple(getindex.(pd, 5), MAX_PARA, Float64),
                       algorithm == :multi_eps ? 1 : 0, rank, world, 0, v, δ, seed))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sabc_create, libsabc), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))

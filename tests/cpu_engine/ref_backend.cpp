@@ -37,7 +37,8 @@ class RefBackend : public Backend {
     oc_.n_particles = sh.n_global; oc_.n_para = m.d; oc_.n_stats = m.s;
     oc_.model_id = m.model_id; oc_.n_model_params = m.n_model_params;
     for (int i = 0; i < ORC_MAX_MODEL_PARAMS; ++i) oc_.model_params[i] = m.p[i];
-    for (int k = 0; k < ORC_MAX_PARA; ++k) { oc_.prior_kind[k] = m.prior_kind[k]; oc_.prior_a[k] = m.prior_a[k]; oc_.prior_b[k] = m.prior_b[k]; }
+    for (int k = 0; k < ORC_MAX_PARA; ++k) { oc_.prior_kind[k] = m.prior_kind[k]; oc_.prior_a[k] = m.prior_a[k]; oc_.prior_b[k] = m.prior_b[k];
+                                             oc_.prior_c[k] = m.prior_c[k]; oc_.prior_d[k] = m.prior_d[k]; }
     oc_.seed = m.seed;
     return 0;
   }

@@ -154,7 +154,8 @@ def test_hard_coded_enum_values():
                          ("LotkaVolterra", "SABC_MODEL_LV"), ("HostDistance", "SABC_MODEL_HOST")):
         assert int(re.search(r"model_id\(::%s\) = Int32\((\d+)\)" % jl_type, src).group(1)) == models[key]
     for jl_type, key in (("Normal", "SABC_PRIOR_NORMAL"), ("Uniform", "SABC_PRIOR_UNIFORM"), ("Exponential", "SABC_PRIOR_EXPONENTIAL"),
-                         ("LogNormal", "SABC_PRIOR_LOGNORMAL")):
+                         ("LogNormal", "SABC_PRIOR_LOGNORMAL"), ("Gamma", "SABC_PRIOR_GAMMA"), ("Beta", "SABC_PRIOR_BETA"),
+                         (r"Truncated\{<:Normal\}", "SABC_PRIOR_TRUNCNORMAL")):
         assert int(re.search(r"prior_descriptor\(d::%s\) = \(Int32\((\d+)\)" % jl_type, src).group(1)) == priors[key]
     for jl_type, key in (("RandomWalk", "SABC_PROP_RANDOMWALK"), ("DifferentialEvolution", "SABC_PROP_DIFFEVO"),
                          ("StretchMove", "SABC_PROP_STRETCH")):
