@@ -322,43 +322,57 @@ __device__ __forceinline__ void half_swap(double &a, double &b) {
   b = __hiloint2double((int)bhi, (int)blo);
 }
 
+// Lane-index bits as wave masks (bit l of lane_bit(i) = bit i of lane l): compile-time constants.  Every direction /
+// side predicate of the network is an XOR of two of them, so the selects below take their condition from a scalar
+// mask (v_cmp -> s_xor with a constant -> v_cndmask) instead of comparing a materialised 0/1 value with a per-lane 0/1
+// vector (v_cmp -> v_cndmask 0,1 -> v_cmp_eq_u32 -> v_cndmask): 2 VALU instructions and their hazard nops less per
+// element and cross-lane step, and no registers held for the predicates.  The boolean algebra is the one of the plain
+// form ((p < v) == keep_min), so ties behave identically.
+constexpr uint64_t lane_bit(int i) {
+  return i == 0 ? 0xAAAAAAAAAAAAAAAAull : i == 1 ? 0xCCCCCCCCCCCCCCCCull : i == 2 ? 0xF0F0F0F0F0F0F0F0ull
+       : i == 3 ? 0xFF00FF00FF00FF00ull : i == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
+}
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+// lanes that sort DESCENDING in the stage that builds runs of K elements: bit log2(K) - 1 of the lane (none for K = 128)
+constexpr uint64_t descending_lanes(int K) { return K >= 128 ? 0ull : lane_bit(ilog2(K) - 1); }
+
 // One compare-exchange step of the bitonic network.  Written with a compare and selects instead of
 // fmin / fmax: the values are never NaN, and min/max would each be preceded by a canonicalising
 // v_max_f64 x, x (a third of the sort's instructions).  Equal values may be taken from either side.
 template <int K, int J>
-__device__ __forceinline__ void bitonic_step(int lane, double &v0, double &v1) {
-  const bool up = ((2 * lane) & K) == 0;               // K = 128: always ascending
-  if constexpr (J == 1) {
-    const bool swap = (v0 > v1) == up;                 // the lane's own pair is out of order for this direction
+__device__ __forceinline__ void bitonic_step(double &v0, double &v1) {
+  constexpr int kOGT = 2, kOLT = 4;                    // LLVM FCmp predicates of __builtin_amdgcn_fcmp
+  if constexpr (J == 1 || (J >> 1) >= 16) {
+    // the lane holds both elements of a pair: its own (J == 1), or after v_permlane{16,32}_swap (distance 16, 32)
+    if constexpr (J > 1) half_swap<(J >> 1)>(v0, v1);
+    // swap iff (v0 > v1) == ascending; (both lanes of a swapped pair see the same direction: K > J)
+    const bool swap = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_fcmp(v0, v1, kOGT) ^ descending_lanes(K));
     const double a = swap ? v1 : v0, b = swap ? v0 : v1;
     v0 = a; v1 = b;
-  } else if constexpr ((J >> 1) >= 16) {
-    constexpr int dist = J >> 1;
-    half_swap<dist>(v0, v1);
-    const bool swap = (v0 > v1) == up;                 // (both lanes of a pair see the same direction: K > J)
-    const double a = swap ? v1 : v0, b = swap ? v0 : v1;
-    v0 = a; v1 = b;
-    half_swap<dist>(v0, v1);
+    if constexpr (J > 1) half_swap<(J >> 1)>(v0, v1);
   } else {
     constexpr int dist = J >> 1;
     const double p0 = xor_lane<dist>(v0), p1 = xor_lane<dist>(v1);
-    const bool keep_min = ((lane & dist) == 0) == up;
-    // the partner lane evaluates the mirrored test, so the pair {v, p} is preserved (g-and-k)
-    v0 = ((p0 < v0) == keep_min) ? p0 : v0;
-    v1 = ((p1 < v1) == keep_min) ? p1 : v1;
+    // keep_min = ((lane & dist) == 0) == ascending; take the partner's value iff (p < v) == keep_min, i.e. iff
+    // (p < v) XOR bit_dist(lane) XOR descending(lane); the partner evaluates the mirrored test, so the pair {v, p} is preserved
+    constexpr uint64_t m = lane_bit(ilog2(dist)) ^ descending_lanes(K);
+    const bool t0 = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_fcmp(p0, v0, kOLT) ^ m);
+    const bool t1 = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_fcmp(p1, v1, kOLT) ^ m);
+    v0 = t0 ? p0 : v0;
+    v1 = t1 ? p1 : v1;
   }
 }
 
 template <int K, int J>
-__device__ __forceinline__ void bitonic_merge(int lane, double &v0, double &v1) {
-  bitonic_step<K, J>(lane, v0, v1);
-  if constexpr (J > 1) bitonic_merge<K, J / 2>(lane, v0, v1);
+__device__ __forceinline__ void bitonic_merge(double &v0, double &v1) {
+  bitonic_step<K, J>(v0, v1);
+  if constexpr (J > 1) bitonic_merge<K, J / 2>(v0, v1);
 }
 
 template <int K>
-__device__ __forceinline__ void bitonic_sort128(int lane, double &v0, double &v1) {
-  if constexpr (K > 2) bitonic_sort128<K / 2>(lane, v0, v1);
-  bitonic_merge<K, K / 2>(lane, v0, v1);
+__device__ __forceinline__ void bitonic_sort128(double &v0, double &v1) {
+  if constexpr (K > 2) bitonic_sort128<K / 2>(v0, v1);
+  bitonic_merge<K, K / 2>(v0, v1);
 }
 
 template <int S>
@@ -375,7 +389,7 @@ __device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const doubl
   // bitonic sorting network over the 128 values, two per lane (element index = 2*lane + slot):
   // 28 compare-exchange steps, 7 of them inside the lane, 21 with the lane at distance j/2
   double v0 = a, v1 = b;
-  bitonic_sort128<kGkMaxDraws>(lane, v0, v1);
+  bitonic_sort128<kGkMaxDraws>(v0, v1);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index

@@ -657,9 +657,12 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
     if ((i & 15) == 15) cm[i >> 4] = (i - 15 < n) ? run : INFINITY;
   }
   if (stage) {
+    // consecutive lanes take consecutive particles here (not 4 each, as in the scan): the row reads are fully coalesced
+    // and the interleaved writes of one instruction fall into row_len * 512 contiguous bytes
+    const int64_t b0 = (int64_t)blockIdx.x * kScanChunk + threadIdx.x;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t i = base + e;
+      const int64_t i = b0 + (int64_t)e * kBlock;
       if (i < n)
         for (int row = 0; row < row_len; ++row) stage[i * row_len + row] = g[(int64_t)row * cap + i];
     }

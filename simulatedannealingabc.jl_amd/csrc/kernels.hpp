@@ -19,7 +19,10 @@ struct PopPtrs {
 
 // coarse level of the two-level ECDF search: every 2^shift-th knot, kCdfCoarse entries per statistic
 // (padded with +inf), small enough to sit in LDS for the lifetime of a workgroup
-constexpr int kCdfCoarse = 1024;
+#ifndef SABC_CDF_COARSE
+#define SABC_CDF_COARSE 1024
+#endif
+constexpr int kCdfCoarse = SABC_CDF_COARSE;
 
 struct CdfPtrs {
   const double *knots;   // [s][stride]; stride is a multiple of 16 (each table starts on a 128-byte line), +inf behind len

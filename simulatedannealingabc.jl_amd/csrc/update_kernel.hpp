@@ -84,8 +84,11 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
 // K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
 //     + fused block partials.   SimulatedAnnealingABC.jl:308-331
 // ------------------------------------------------------------------------------------------
+#ifndef SABC_UPDATE_MIN_BLOCKS
+#define SABC_UPDATE_MIN_BLOCKS 4
+#endif
 template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(kBlock, 4)
+__global__ void __launch_bounds__(kBlock, SABC_UPDATE_MIN_BLOCKS)
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);

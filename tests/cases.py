@@ -31,6 +31,11 @@ MODELS = {
                                 prior=[("N", 0.0, 1.0), ("L", -0.5, 0.5)], s=1),
     "gauss2_exponential_sd": dict(model=("GaussianIID", dict(n_obs=50, sd=1.0, obs_mean=0.5, obs_m2=1.2)),
                                   prior=[("U", -2.0, 2.0), ("E", 0.7, 0.0)], s=2),
+    # prior families added in round 2: Gamma scale parameter; truncated-Normal mean with a Beta-distributed sd in (0, 1)
+    "gauss2_gamma_sd": dict(model=("GaussianIID", dict(n_obs=40, sd=1.0, obs_mean=0.3, obs_m2=0.9)),
+                            prior=[("N", 0.0, 1.0), ("G", 2.0, 0.5)], s=2),
+    "gauss2_truncnormal_beta": dict(model=("GaussianIID", dict(n_obs=40, sd=1.0, obs_mean=0.4)),
+                                    prior=[("T", 0.0, 1.0, -0.5, 1.5), ("B", 2.0, 2.5)], s=1),
     # BASELINE config 3
     "gauss2d_cfg3": dict(model=("Gaussian2D", dict(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)),
                          prior=[("N", 0.0, 3.0), ("N", 0.0, 3.0)], s=3),
@@ -65,8 +70,9 @@ def oracle_model_params(O, spec):
 def oracle_config(O, name, n, algorithm="single_eps", seed=SEED, v=1.0, delta=0.1):
     spec = MODELS[name]
     mid, params = oracle_model_params(O, spec)
-    kinds = {"N": O.PRIOR_NORMAL, "U": O.PRIOR_UNIFORM, "E": O.PRIOR_EXPONENTIAL, "L": O.PRIOR_LOGNORMAL}
-    prior = [(kinds[k], a, b) for k, a, b in spec["prior"]]
+    kinds = {"N": O.PRIOR_NORMAL, "U": O.PRIOR_UNIFORM, "E": O.PRIOR_EXPONENTIAL, "L": O.PRIOR_LOGNORMAL, "G": O.PRIOR_GAMMA,
+             "B": O.PRIOR_BETA, "T": O.PRIOR_TRUNCNORMAL}
+    prior = [(kinds[p[0]],) + tuple(p[1:]) for p in spec["prior"]]
     alg = O.ALG_MULTI_EPS if algorithm == "multi_eps" else O.ALG_SINGLE_EPS
     return O.make_config(n_particles=n, n_para=len(prior), n_stats=spec["s"], model_id=mid, model_params=params,
                          prior=prior, algorithm=alg, v=v, delta=delta, seed=seed)
@@ -94,8 +100,9 @@ def hip_model_prior(S, name):
     kind, kw = spec["model"]
     model = getattr(S, kind)(**kw)
     make = {"N": lambda a, b: S.Normal(a, b), "U": lambda a, b: S.Uniform(a, b), "E": lambda a, b: S.Exponential(a),
-            "L": lambda a, b: S.LogNormal(a, b)}
-    comps = [make[k](a, b) for k, a, b in spec["prior"]]
+            "L": lambda a, b: S.LogNormal(a, b), "G": lambda a, b: S.Gamma(a, b), "B": lambda a, b: S.Beta(a, b),
+            "T": lambda a, b, lo, hi: S.truncated(S.Normal(a, b), lo, hi)}
+    comps = [make[p[0]](*p[1:]) for p in spec["prior"]]
     prior = comps[0] if len(comps) == 1 else S.product_distribution(comps)
     return model, prior
 

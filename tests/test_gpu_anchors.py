@@ -62,7 +62,7 @@ def test_cfg2_device_follows_the_independent_restatement(S, gpu, prop):
     for k, x, y in zip(marks, dev, ref):
         assert abs(x["acc"] / y["acc"] - 1) < 0.006, (k, x["acc"], y["acc"])             # acceptances per particle
         assert x["res"] == y["res"], (k, x["res"], y["res"])
-        assert abs(x["eps"][0] / y["eps"][0] - 1) < 0.03, (k, x["eps"], y["eps"])
+        assert abs(x["eps"][0] / y["eps"][0] - 1) < (0.10 if k == 25 else 0.03), (k, x["eps"], y["eps"])
         vx, vy = x["theta"][0].var(), y["theta"][0].var()
         assert abs(vx / vy - 1) < (0.07 if k == 25 else 0.025), (k, vx, vy)           # steep at 25: the variance halves in ~10 updates
         assert abs(x["theta"][0].mean() - y["theta"][0].mean()) < 0.0015                 # 0.015 posterior sd
