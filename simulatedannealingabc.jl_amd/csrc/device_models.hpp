@@ -257,6 +257,8 @@ struct Sim<SABC_MODEL_GAUSS2D, D, S> {
   }
 };
 
+#if !defined(__HIPCC_RTC__)   // the wave-cooperative g-and-k simulator has its own kernel (kernels.hip); a run-time compiled
+                              // user simulator never needs it, and older hipRTC compilers lack some of its builtins
 // g-and-k: x = A + B (1 + c tanh(g z / 2)) (1 + z^2)^k z; rho_j = |x_(rank_j) - obs_j|.
 // Wave-cooperative: ONE WAVEFRONT PER PARTICLE.  Lane l draws Philox block l of the particle's
 // SIM stream = normals 2l and 2l+1 = draws 2l and 2l+1 (n_draws <= 128 = 64 lanes x 2); the 128
@@ -398,6 +400,8 @@ __device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const doubl
   }
 }
 
+
+#endif  // !__HIPCC_RTC__
 
 // stochastic Lotka-Volterra, Euler-Maruyama; rho = |mean/sd of prey and predator paths - obs|
 template <int D, int S>

@@ -506,8 +506,10 @@ int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
 
 // one shard: the whole of :124-137 in four launches (kernels.hpp: launch_resample_local)
 int HipBackend::resample_local(double delta, uint64_t iter, int64_t *stats_rows) {
-  if (!stage_dev_)
-    HB_CHECK(hipMalloc((void **)&stage_dev_, (size_t)(sh_.cap > 0 ? sh_.cap : 1) * (size_t)(m_.d + m_.s) * sizeof(double)), "hipMalloc(resample staging)");
+  if (!stage_dev_) {
+    const int64_t doubles = resample_pack_doubles(m_.d + m_.s, sh_.cap > 0 ? sh_.cap : 1);
+    if (doubles > 0) HB_CHECK(hipMalloc((void **)&stage_dev_, (size_t)doubles * sizeof(double)), "hipMalloc(packed resample lines)");
+  }
   if (pending_rows_ >= 0 && flush_reduce()) return -1;      // the partial rows are about to be overwritten
   const int nxt = 1 - cur_;
   prof_begin(SABC_KERNEL_RESAMPLE);

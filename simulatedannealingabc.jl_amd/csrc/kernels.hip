@@ -623,13 +623,27 @@ k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int
 }
 
 // pass 3: inclusive scan inside each chunk + chunk offset
-// stage != nullptr (one shard): the particles' (theta, u) rows are also copied into an interleaved staging array, row_len
-// consecutive doubles per particle, so that a draw of the gather touches ONE line instead of one per row
+// Packed lines (one shard): particle i's running sum AND its (theta, u) row sit together, `pg` particles to a 128-byte
+// line (pg = the largest power of two with pg (1 + row_len) <= 16, so that lines never straddle a scan chunk):
+//   pk[(i / pg) * 16 + (i % pg) * (1 + row_len)] = { cum_i, theta_i..., u_i... },   ge[i / pg] = cum at the line's last particle
+// A draw then costs ONE random line (search the chunk's line ends `ge` -- L2-resident -- then read the line) instead of a
+// line of `cum` plus a line per gathered row.  The running sums are the same numbers, so the drawn index is the same.
+struct PackArgs {
+  double *pk, *ge;       // nullptr: no packing (the sharded path gathers rows by request)
+  int row_len, pg;
+};
+
+__device__ __forceinline__ int pack_group(int row_len) {
+  const int per = 16 / (1 + row_len);
+  return per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;     // 0: a row does not fit a line, the caller falls back
+}
+
+// pass 3: inclusive scan inside each chunk + chunk offset
 __global__ void __launch_bounds__(kBlock)
 k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n,
-             const double *__restrict__ bs, double *__restrict__ cum, double *__restrict__ cm, double *__restrict__ stage,
-             const int row_len) {
+             const double *__restrict__ bs, double *__restrict__ cum, double *__restrict__ cm, const PackArgs pa) {
   __shared__ double sm[kBlock];
+  __shared__ double scum[kScanChunk];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
   double w[4];
   double s = 0.0;
@@ -652,19 +666,31 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
     const int64_t i = base + e;
     run += w[e];
     if (i < n) cum[i] = run;
+    scum[threadIdx.x * 4 + e] = run;
     // mid level of the resample search: cm[g] = cum at the end of 16-element group g (one 128-byte line of `cum`);
     // weights behind n are 0, so `run` is the total there; groups entirely behind n get +inf
     if ((i & 15) == 15) cm[i >> 4] = (i - 15 < n) ? run : INFINITY;
   }
-  if (stage) {
-    // consecutive lanes take consecutive particles here (not 4 each, as in the scan): the row reads are fully coalesced
-    // and the interleaved writes of one instruction fall into row_len * 512 contiguous bytes
-    const int64_t b0 = (int64_t)blockIdx.x * kScanChunk + threadIdx.x;
+  if (pa.pk) {
+    __syncthreads();
+    // consecutive lanes take consecutive particles here (not 4 each, as in the scan): coalesced row reads, and the
+    // writes of one instruction fall into a few contiguous lines
+    const int rl1 = 1 + pa.row_len;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t i = b0 + (int64_t)e * kBlock;
-      if (i < n)
-        for (int row = 0; row < row_len; ++row) stage[i * row_len + row] = g[(int64_t)row * cap + i];
+      const int loc = threadIdx.x + e * kBlock;
+      const int64_t i = (int64_t)blockIdx.x * kScanChunk + loc;
+      const int64_t line = i / pa.pg;
+      const int slot = (int)(i - line * pa.pg);
+      double *dst = pa.pk + line * 16 + slot * rl1;
+      if (i < n) {
+        dst[0] = scum[loc];
+        for (int row = 0; row < pa.row_len; ++row) dst[1 + row] = g[(int64_t)row * cap + i];
+        // the line's end value: its last particle, or the last particle of the population (scum is flat behind n)
+        if (slot == pa.pg - 1 || i == n - 1) pa.ge[line] = scum[loc];
+      } else if (line * pa.pg < n) {
+        dst[0] = INFINITY;            // empty slots of the population's last line never win a search
+      }
     }
   }
 }
@@ -730,16 +756,54 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
     dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
 }
 
-// One shard, staged: the draw reads its (theta, u) row from the interleaved staging array (one line), and -- with D, S
-// known at compile time -- the moment sums of the RESAMPLED population (what k_stats would compute in a pass of its
-// own: Sigma, eps and the history row are taken from the resampled population, :348-353) come out of the same kernel,
-// in the same per-workgroup order.
+// The draw on packed lines: chunk by the offsets `B` (as resample_search), then the first line of the chunk whose end value
+// exceeds t (binary search over the chunk's kScanChunk / pg line ends), then the first slot of that line whose running sum
+// exceeds t.  Returns the drawn index and the address of its packed row.  Same decisions as resample_search on the same
+// numbers: if no running sum of the chunk exceeds t (rounding of the offsets against the sums) the next chunk's first
+// particle is taken, the last particle at the end of the population.
+__device__ __forceinline__ int64_t packed_search(const double t, const double *B, const int64_t nb, const double *__restrict__ ge,
+                                                 const double *__restrict__ pk, const int pg, const int rl1, const int64_t n,
+                                                 const double *&row) {
+  int64_t blo = 0, bhi = nb;
+  while (blo < bhi) {
+    const int64_t mid = blo + ((bhi - blo) >> 1);
+    if (B[mid] > t) bhi = mid; else blo = mid + 1;
+  }
+  const int64_t chunk = blo - 1;
+  const int64_t lines_per_chunk = kScanChunk / pg;
+  const int64_t n_lines = (n + pg - 1) / pg;
+  int64_t lo = chunk * lines_per_chunk, hi = lo + lines_per_chunk;
+  if (hi > n_lines) hi = n_lines;
+  const int64_t end = hi;
+  while (lo < hi) {                        // first line of the chunk with ge > t
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (ge[mid] > t) hi = mid; else lo = mid + 1;
+  }
+  int64_t idx;
+  if (lo < end) {
+    const double *L = pk + lo * 16;
+    int slot = 0;
+    while (slot < pg - 1 && !(L[slot * rl1] > t)) ++slot;      // the line's end exceeds t, so the last slot needs no test
+    idx = lo * pg + slot;
+    if (idx >= n) idx = n - 1;
+  } else {
+    idx = (chunk + 1) * (int64_t)kScanChunk;
+    if (idx >= n) idx = n - 1;
+  }
+  const int64_t line = idx / pg;
+  row = pk + line * 16 + (idx - line * pg) * rl1 + 1;
+  return idx;
+}
+
+// One shard, packed: the draw and its (theta, u) row come from one line, and -- with D, S known at compile time -- the
+// moment sums of the RESAMPLED population (what k_stats would compute in a pass of its own: Sigma, eps and the history
+// row are taken from the resampled population, :348-353) come out of the same kernel, in the same per-workgroup order.
 template <int D, int S>
 __global__ void __launch_bounds__(kBlock)
-k_resample_gather_stats(const uint64_t seed, const double *__restrict__ stage, const int64_t n, const double *__restrict__ cum,
-                        const double *__restrict__ bs, const double *__restrict__ cm, const int64_t nb,
-                        const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst,
-                        const ControlBlock *__restrict__ cb, double *__restrict__ partials) {
+k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, const double *__restrict__ ge, const int pg,
+                        const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
+                        const uint64_t iter, const PopPtrs dst, const ControlBlock *__restrict__ cb,
+                        double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S), RL = D + S;
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
@@ -756,13 +820,14 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ stage, c
     const uint64_t gid = (uint64_t)(dst.gid0 + li);
     const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
     const double t = u52(w.x, w.y) * totals[0];
-    const int64_t idx = resample_search(t, B, nb, cm, cum, n);
+    const double *row;
+    (void)packed_search(t, B, nb, ge, pk, pg, RL + 1, n, row);
     double th[D], u[S], rho[S];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = stage[idx * RL + k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
+    for (int k = 0; k < D; ++k) { th[k] = row[k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      u[j] = stage[idx * RL + D + j];
+      u[j] = row[D + j];
       dst.pop[(int64_t)(D + j) * dst.cap + li] = u[j];
       rho[j] = dst.rho[(int64_t)j * dst.cap + li];                        // rho stays where it is (:131-132)
     }
@@ -773,9 +838,9 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ stage, c
 
 // the same without the sums, d and s at run time (host-callback and source-compiled simulators)
 __global__ void __launch_bounds__(kBlock)
-k_resample_gather_staged(const uint64_t seed, const int row_len, const double *__restrict__ stage, const int64_t n,
-                         const double *__restrict__ cum, const double *__restrict__ bs, const double *__restrict__ cm,
-                         const int64_t nb, const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
+k_resample_gather_packed(const uint64_t seed, const int row_len, const double *__restrict__ pk, const double *__restrict__ ge,
+                         const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb,
+                         const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
   if (in_lds) {
@@ -786,8 +851,9 @@ k_resample_gather_staged(const uint64_t seed, const int row_len, const double *_
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= dst.n_local) return;
   const u32x4 w = stream_block(seed, (uint64_t)(dst.gid0 + li), PURPOSE_RESAMPLE, iter, 0);
-  const int64_t idx = resample_search(u52(w.x, w.y) * totals[0], B, nb, cm, cum, n);
-  for (int row = 0; row < row_len; ++row) dst.pop[(int64_t)row * dst.cap + li] = stage[idx * row_len + row];
+  const double *row;
+  (void)packed_search(u52(w.x, w.y) * totals[0], B, nb, ge, pk, pg, row_len + 1, n, row);
+  for (int r = 0; r < row_len; ++r) dst.pop[(int64_t)r * dst.cap + li] = row[r];
 }
 
 // ---- the sharded resample: requests grouped by owner, served by the owner, scattered by the requester ----
@@ -1171,99 +1237,70 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
   std::memset(&wa, 0, sizeof(wa));
   hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum, cm,
-                     (double *)nullptr, 0);
+  PackArgs none;
+  std::memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum, cm, none);
   return SABC_LAUNCH_RC();
+}
+
+// doubles of the packed-line scratch of launch_resample_local for a shard of n particles: lines of 16 doubles + line ends
+int64_t resample_pack_doubles(int row_len, int64_t n) {
+  const int per = 16 / (1 + row_len);
+  const int pg = per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;
+  if (pg == 0) return 0;
+  const int64_t lines = (n + pg - 1) / pg;
+  return lines * 16 + lines + 16;
 }
 
 // One shard: weights (fused into the first scan pass), scan, staging copy, draw + gather (+ the moment sums of the
 // resampled population when the model's (d, s) is one the kernels are instantiated for): 4 launches.
 // *stats_rows = partial rows written, or -1 when the caller still has to run the stats pass.
 int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const ControlBlock *cb, double delta, uint64_t iter,
-                          double *block_sums, double *cum, double *totals, double *totals_host, double *stage,
+                          double *block_sums, double *cum, double *totals, double *totals_host, double *pack,
                           double *partials, int64_t *stats_rows, hipStream_t stream) {
   const int64_t n = src.n_local, cap = src.cap;
   *stats_rows = -1;
   if (n <= 0) return 0;
   const int rows = m.d + m.s + 1, rl = m.d + m.s;
+  const int per = 16 / (1 + rl);
+  const int pg = per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;
   const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
   double *bs = block_sums, *bq = block_sums + nb, *cm = block_sums + 2 * nb;
   WeightArgs wa;
   std::memset(&wa, 0, sizeof(wa));
   wa.fused = 1; wa.d = m.d; wa.s = m.s; wa.pp = src; wa.cb = cb; wa.n_global = (double)n; wa.delta = delta;
+  PackArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  if (pg > 0 && pack) {
+    const int64_t lines = (n + pg - 1) / pg;
+    pa.pk = pack; pa.ge = pack + lines * 16; pa.row_len = rl; pa.pg = pg;
+  }
   hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, cum, cm,
-                     stage, rl);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, cum, cm, pa);
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
+  if (!pa.pk) {                      // a row does not fit a 128-byte line (d + s > 15): the unpacked gather, sums by the caller
+    hipLaunchKernelGGL(k_resample_gather<true>, grid, block, lds, stream, m.seed, m.d, m.s, (const double *)src.pop, rows, cap, n,
+                       (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst,
+                       (int64_t *)nullptr);
+    return SABC_LAUNCH_RC();
+  }
 #define CALL(M, D, S)                                                                                                    \
   do {                                                                                                                   \
-    hipLaunchKernelGGL((k_resample_gather_stats<D, S>), grid, block, lds, stream, m.seed, (const double *)stage, n,      \
-                       (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst, \
-                       cb, partials);                                                                                    \
+    hipLaunchKernelGGL((k_resample_gather_stats<D, S>), grid, block, lds, stream, m.seed, (const double *)pa.pk,         \
+                       (const double *)pa.ge, pg, n, (const double *)bs, nb, (const double *)totals, iter, dst, cb,      \
+                       partials);                                                                                        \
     *stats_rows = n_blocks(n);                                                                                           \
   } while (0)
   if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
   if (m.model_id == SABC_MODEL_HOST || m.model_id == SABC_MODEL_USER) {
-    hipLaunchKernelGGL(k_resample_gather_staged, grid, block, lds, stream, m.seed, rl, (const double *)stage, n,
-                       (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst);
+    hipLaunchKernelGGL(k_resample_gather_packed, grid, block, lds, stream, m.seed, rl, (const double *)pa.pk,
+                       (const double *)pa.ge, pg, n, (const double *)bs, nb, (const double *)totals, iter, dst);
     return SABC_LAUNCH_RC();
   }
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
-  return SABC_LAUNCH_RC();
-}
-
-int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
-                           const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
-                           hipStream_t stream) {
-  if (dst.n_local <= 0) return 0;
-  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
-  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
-  hipLaunchKernelGGL(k_resample_gather<true>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
-                     m.s, gathered, rows, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst,
-                     (int64_t *)nullptr);
-  return SABC_LAUNCH_RC();
-}
-
-int launch_resample_select(const ModelDesc &m, int64_t cap, int64_t n_global, const double *cum, const double *block_sums,
-                           const double *totals, uint64_t iter, PopPtrs dst, int64_t *idx_out, hipStream_t stream) {
-  if (dst.n_local <= 0) return 0;
-  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
-  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
-  hipLaunchKernelGGL(k_resample_gather<false>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
-                     m.s, (const double *)nullptr, 0, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter,
-                     dst, idx_out);
-  return SABC_LAUNCH_RC();
-}
-
-int launch_bucket_count(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *counts, hipStream_t stream) {
-  if (n_local <= 0) return 0;
-  hipLaunchKernelGGL(k_bucket_count, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, counts);
-  return SABC_LAUNCH_RC();
-}
-
-int launch_bucket_scatter(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *cursor, double *req,
-                          int64_t *slot, hipStream_t stream) {
-  if (n_local <= 0) return 0;
-  hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, cursor,
-                     req, slot);
-  return SABC_LAUNCH_RC();
-}
-
-int launch_resample_serve(const double *req, int64_t m, int row_len, PopPtrs src, double *rows_out, hipStream_t stream) {
-  if (m <= 0) return 0;
-  hipLaunchKernelGGL(k_resample_serve, dim3((unsigned)n_blocks(m * row_len)), dim3(kBlock), 0, stream, req, m, row_len, src,
-                     rows_out);
-  return SABC_LAUNCH_RC();
-}
-
-int launch_resample_scatter(const double *rows_in, const int64_t *slot, int64_t n_local, int row_len, PopPtrs dst,
-                            hipStream_t stream) {
-  if (n_local <= 0) return 0;
-  hipLaunchKernelGGL(k_resample_scatter, dim3((unsigned)n_blocks(n_local * row_len)), dim3(kBlock), 0, stream, rows_in, slot,
-                     n_local, row_len, dst);
   return SABC_LAUNCH_RC();
 }
 

@@ -86,12 +86,14 @@ inline int64_t weight_scan_doubles(int64_t n_global) {
 // totals[0] = sum w, totals[1] = sum w^2                               :129,134
 int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
                        double *cum, double *totals, double *totals_host, hipStream_t stream);
-// K5 on one shard in four launches: weights fused into the first scan pass, interleaved (theta, u) staging written by the
-// last, draw + gather from the staging array with the moment sums of the resampled population fused in (when (d, s) is an
-// instantiated combination; *stats_rows = -1 otherwise: the caller runs the stats pass).  stage: n * (d + s) doubles.
+// K5 on one shard in four launches: weights fused into the first scan pass; the last pass also packs every particle's
+// running sum together with its (theta, u) row, 4 / 2 / 1 particles to a 128-byte line; draw + gather read ONE random line
+// per draw, with the moment sums of the resampled population fused in (when (d, s) is an instantiated combination;
+// *stats_rows = -1 otherwise: the caller runs the stats pass).  pack: resample_pack_doubles(d + s, n) doubles of scratch.
 int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const ControlBlock *cb, double delta, uint64_t iter,
-                          double *block_sums, double *cum, double *totals, double *totals_host, double *stage,
+                          double *block_sums, double *cum, double *totals, double *totals_host, double *pack,
                           double *partials, int64_t *stats_rows, hipStream_t stream);
+int64_t resample_pack_doubles(int row_len, int64_t n);
 // K5c: n_local categorical draws by inverse CDF + gather of theta and u (not rho)   :129-132
 int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
                            const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,

@@ -55,6 +55,7 @@ def main():
     d = len(MODELS[a.case]["prior"])
     alg = S._lib.ALG_MULTI_EPS if a.alg == "multi_eps" else S._lib.ALG_SINGLE_EPS
     h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
+    transport = "none"
     if world > 1:
         transport = install_collectives(h, device, alltoallv=bool(a.alltoallv))
         assert transport in ("rccl", "hooks-nccl", "hooks-gloo"), transport
@@ -72,7 +73,7 @@ def main():
                  rho=np.concatenate([p[3] for p in parts], 1), eps=h.eps, eps_hist=e, u_hist=uh, rho_hist=rh,
                  counters=np.array([h.counters[k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]),
                  sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]),
-                 comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]))
+                 comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]), transport=np.array(transport))
     dist.barrier()
     h.close()
     dist.destroy_process_group()
