@@ -1304,6 +1304,58 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
   return SABC_LAUNCH_RC();
 }
 
+int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
+                           const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
+                           hipStream_t stream) {
+  if (dst.n_local <= 0) return 0;
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
+  hipLaunchKernelGGL(k_resample_gather<true>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
+                     m.s, gathered, rows, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst,
+                     (int64_t *)nullptr);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_select(const ModelDesc &m, int64_t cap, int64_t n_global, const double *cum, const double *block_sums,
+                           const double *totals, uint64_t iter, PopPtrs dst, int64_t *idx_out, hipStream_t stream) {
+  if (dst.n_local <= 0) return 0;
+  const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
+  const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
+  hipLaunchKernelGGL(k_resample_gather<false>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
+                     m.s, (const double *)nullptr, 0, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter,
+                     dst, idx_out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_bucket_count(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *counts, hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_bucket_count, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, counts);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_bucket_scatter(const int64_t *idx, int64_t n_local, int64_t cap, unsigned long long *cursor, double *req,
+                          int64_t *slot, hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_bucket_scatter, dim3((unsigned)n_blocks(n_local)), dim3(kBlock), 0, stream, idx, n_local, cap, cursor,
+                     req, slot);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_serve(const double *req, int64_t m, int row_len, PopPtrs src, double *rows_out, hipStream_t stream) {
+  if (m <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_serve, dim3((unsigned)n_blocks(m * row_len)), dim3(kBlock), 0, stream, req, m, row_len, src,
+                     rows_out);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_resample_scatter(const double *rows_in, const int64_t *slot, int64_t n_local, int row_len, PopPtrs dst,
+                            hipStream_t stream) {
+  if (n_local <= 0) return 0;
+  hipLaunchKernelGGL(k_resample_scatter, dim3((unsigned)n_blocks(n_local * row_len)), dim3(kBlock), 0, stream, rows_in, slot,
+                     n_local, row_len, dst);
+  return SABC_LAUNCH_RC();
+}
+
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream) {
   hipLaunchKernelGGL(k_cdf_meta, dim3(1), dim3(64), 0, stream, sorted, n, meta);
   hipLaunchKernelGGL(k_cdf_fill, dim3((unsigned)n_blocks(n > 0 ? n : 1)), dim3(kBlock), 0, stream, sorted, n, meta, knots);
