@@ -624,19 +624,18 @@ k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int
 
 // pass 3: inclusive scan inside each chunk + chunk offset
 // Packed lines (one shard): particle i's running sum AND its (theta, u) row sit together, `pg` particles to a 128-byte
-// line (pg = the largest power of two with pg (1 + row_len) <= 16, so that lines never straddle a scan chunk):
-//   pk[(i / pg) * 16 + (i % pg) * (1 + row_len)] = { cum_i, theta_i..., u_i... },   ge[i / pg] = cum at the line's last particle
-// A draw then costs ONE random line (search the chunk's line ends `ge` -- L2-resident -- then read the line) instead of a
-// line of `cum` plus a line per gathered row.  The running sums are the same numbers, so the drawn index is the same.
+// line (pg = 4, 2 or 1: the largest power of two with pg (1 + row_len) <= 16, so that a line never straddles a scan chunk
+// and every particle's slot starts on a 16 / pg-double boundary):
+//   pk[(i / pg) * 16 + (i % pg) * (16 / pg)] = { cum_i, theta_i..., u_i... }
+//   ge[i / pg]  = cum at the line's last particle                      (kScanChunk / pg per chunk)
+//   gc[i / pg / 16] = ge of every 16th line                            (kScanChunk / pg / 16 per chunk: <= 64 doubles)
+// A draw then costs THREE dependent line fetches (a line of gc, a line of ge, the packed line) instead of ~10 (binary
+// search through `cm` and `cum`, one line per gathered row).  The running sums are the same numbers, so the drawn index
+// is the same.
 struct PackArgs {
-  double *pk, *ge;       // nullptr: no packing (the sharded path gathers rows by request)
+  double *pk, *ge, *gc;  // pk == nullptr: no packing (the sharded path gathers rows by request)
   int row_len, pg;
 };
-
-__device__ __forceinline__ int pack_group(int row_len) {
-  const int per = 16 / (1 + row_len);
-  return per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;     // 0: a row does not fit a line, the caller falls back
-}
 
 // pass 3: inclusive scan inside each chunk + chunk offset
 __global__ void __launch_bounds__(kBlock)
@@ -661,36 +660,42 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
   }
   __syncthreads();
   double run = bs[blockIdx.x] + sm[threadIdx.x];
+  const bool packed = pa.pk != nullptr;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t i = base + e;
     run += w[e];
+    if (packed) { scum[threadIdx.x * 4 + e] = run; continue; }       // the packed gather reads neither cum nor cm
     if (i < n) cum[i] = run;
-    scum[threadIdx.x * 4 + e] = run;
     // mid level of the resample search: cm[g] = cum at the end of 16-element group g (one 128-byte line of `cum`);
     // weights behind n are 0, so `run` is the total there; groups entirely behind n get +inf
     if ((i & 15) == 15) cm[i >> 4] = (i - 15 < n) ? run : INFINITY;
   }
-  if (pa.pk) {
-    __syncthreads();
-    // consecutive lanes take consecutive particles here (not 4 each, as in the scan): coalesced row reads, and the
-    // writes of one instruction fall into a few contiguous lines
-    const int rl1 = 1 + pa.row_len;
+  if (!packed) return;
+  __syncthreads();
+  // consecutive lanes take consecutive particles here (not 4 each, as in the scan): coalesced row reads, and the pg lanes
+  // of a line write its 128 bytes with 16-byte stores
+  const int stride = 16 / pa.pg;
+  const int64_t n_lines = (n + pa.pg - 1) / pa.pg;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int loc = threadIdx.x + e * kBlock;
-      const int64_t i = (int64_t)blockIdx.x * kScanChunk + loc;
-      const int64_t line = i / pa.pg;
-      const int slot = (int)(i - line * pa.pg);
-      double *dst = pa.pk + line * 16 + slot * rl1;
-      if (i < n) {
-        dst[0] = scum[loc];
-        for (int row = 0; row < pa.row_len; ++row) dst[1 + row] = g[(int64_t)row * cap + i];
-        // the line's end value: its last particle, or the last particle of the population (scum is flat behind n)
-        if (slot == pa.pg - 1 || i == n - 1) pa.ge[line] = scum[loc];
-      } else if (line * pa.pg < n) {
-        dst[0] = INFINITY;            // empty slots of the population's last line never win a search
-      }
+  for (int e = 0; e < 4; ++e) {
+    const int loc = threadIdx.x + e * kBlock;
+    const int64_t i = (int64_t)blockIdx.x * kScanChunk + loc;
+    const int64_t line = i / pa.pg;
+    if (line >= n_lines) continue;
+    const int slot = (int)(i - line * pa.pg);
+    double v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = 0.0;
+    v[0] = i < n ? scum[loc] : INFINITY;                             // empty slots of the last line never win a search
+    if (i < n)
+      for (int row = 0; row < pa.row_len; ++row) v[1 + row] = g[(int64_t)row * cap + i];
+    double2 *dst = reinterpret_cast<double2 *>(pa.pk + line * 16 + slot * stride);
+    for (int q = 0; 2 * q < stride; ++q) dst[q] = make_double2(v[2 * q], v[2 * q + 1]);
+    // the line's end value: its last particle, or the last particle of the population (scum is flat behind n)
+    if (i < n && (slot == pa.pg - 1 || i == n - 1)) {
+      pa.ge[line] = scum[loc];
+      if ((line & 15) == 15 || i == n - 1) pa.gc[line >> 4] = scum[loc];
     }
   }
 }
@@ -757,13 +762,14 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
 }
 
 // The draw on packed lines: chunk by the offsets `B` (as resample_search), then the first line of the chunk whose end value
-// exceeds t (binary search over the chunk's kScanChunk / pg line ends), then the first slot of that line whose running sum
-// exceeds t.  Returns the drawn index and the address of its packed row.  Same decisions as resample_search on the same
-// numbers: if no running sum of the chunk exceeds t (rounding of the offsets against the sums) the next chunk's first
-// particle is taken, the last particle at the end of the population.
-__device__ __forceinline__ int64_t packed_search(const double t, const double *B, const int64_t nb, const double *__restrict__ ge,
-                                                 const double *__restrict__ pk, const int pg, const int rl1, const int64_t n,
-                                                 const double *&row) {
+// exceeds t -- by the chunk's coarse ends gc (every 16th line; one or a few 128-byte lines) and the 16 line ends behind the
+// one found (one line of ge) --, then the first slot of that line whose running sum exceeds t.  Returns the drawn index and
+// the address of its packed row.  Same decisions as resample_search on the same numbers: if no running sum of the chunk
+// exceeds t (rounding of the offsets against the sums) the next chunk's first particle is taken, the last particle at the
+// end of the population.
+__device__ __forceinline__ int64_t packed_search(const double t, const double *B, const int64_t nb, const double *__restrict__ gc,
+                                                 const double *__restrict__ ge, const double *__restrict__ pk, const int pg,
+                                                 const int64_t n, const double *&row) {
   int64_t blo = 0, bhi = nb;
   while (blo < bhi) {
     const int64_t mid = blo + ((bhi - blo) >> 1);
@@ -772,18 +778,29 @@ __device__ __forceinline__ int64_t packed_search(const double t, const double *B
   const int64_t chunk = blo - 1;
   const int64_t lines_per_chunk = kScanChunk / pg;
   const int64_t n_lines = (n + pg - 1) / pg;
-  int64_t lo = chunk * lines_per_chunk, hi = lo + lines_per_chunk;
-  if (hi > n_lines) hi = n_lines;
-  const int64_t end = hi;
-  while (lo < hi) {                        // first line of the chunk with ge > t
-    const int64_t mid = lo + ((hi - lo) >> 1);
-    if (ge[mid] > t) hi = mid; else lo = mid + 1;
+  const int64_t l0 = chunk * lines_per_chunk;
+  int64_t end = l0 + lines_per_chunk;
+  if (end > n_lines) end = n_lines;
+  // coarse: first 16-line group of the chunk whose end exceeds t (the chunk's last group may be partial: its end is the
+  // population's last particle)
+  int64_t glo = l0 >> 4, ghi = (end + 15) >> 4;
+  const int64_t gend = ghi;
+  while (glo < ghi) {
+    const int64_t mid = glo + ((ghi - glo) >> 1);
+    if (gc[mid] > t) ghi = mid; else glo = mid + 1;
   }
   int64_t idx;
-  if (lo < end) {
+  if (glo < gend) {
+    int64_t lo = glo << 4, hi = lo + 16;
+    if (hi > end) hi = end;
+    while (lo < hi - 1) {                  // the group's end exceeds t, so its last line needs no test
+      const int64_t mid = lo + ((hi - 1 - lo) >> 1);
+      if (ge[mid] > t) hi = mid + 1; else lo = mid + 1;
+    }
+    const int stride = 16 / pg;
     const double *L = pk + lo * 16;
     int slot = 0;
-    while (slot < pg - 1 && !(L[slot * rl1] > t)) ++slot;      // the line's end exceeds t, so the last slot needs no test
+    while (slot < pg - 1 && !(L[slot * stride] > t)) ++slot;       // likewise the line's last slot
     idx = lo * pg + slot;
     if (idx >= n) idx = n - 1;
   } else {
@@ -791,7 +808,7 @@ __device__ __forceinline__ int64_t packed_search(const double t, const double *B
     if (idx >= n) idx = n - 1;
   }
   const int64_t line = idx / pg;
-  row = pk + line * 16 + (idx - line * pg) * rl1 + 1;
+  row = pk + line * 16 + (idx - line * pg) * (16 / pg) + 1;
   return idx;
 }
 
@@ -800,11 +817,11 @@ __device__ __forceinline__ int64_t packed_search(const double t, const double *B
 // row are taken from the resampled population, :348-353) come out of the same kernel, in the same per-workgroup order.
 template <int D, int S>
 __global__ void __launch_bounds__(kBlock)
-k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, const double *__restrict__ ge, const int pg,
-                        const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
+k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, const double *__restrict__ ge,
+                        const double *__restrict__ gc, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
                         const uint64_t iter, const PopPtrs dst, const ControlBlock *__restrict__ cb,
                         double *__restrict__ partials) {
-  constexpr int NP = n_partials(D, S), RL = D + S;
+  constexpr int NP = n_partials(D, S);
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
   if (in_lds) {
@@ -821,7 +838,7 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
     const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
     const double t = u52(w.x, w.y) * totals[0];
     const double *row;
-    (void)packed_search(t, B, nb, ge, pk, pg, RL + 1, n, row);
+    (void)packed_search(t, B, nb, gc, ge, pk, pg, n, row);
     double th[D], u[S], rho[S];
 #pragma unroll
     for (int k = 0; k < D; ++k) { th[k] = row[k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
@@ -839,7 +856,7 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
 // the same without the sums, d and s at run time (host-callback and source-compiled simulators)
 __global__ void __launch_bounds__(kBlock)
 k_resample_gather_packed(const uint64_t seed, const int row_len, const double *__restrict__ pk, const double *__restrict__ ge,
-                         const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb,
+                         const double *__restrict__ gc, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb,
                          const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
@@ -852,7 +869,7 @@ k_resample_gather_packed(const uint64_t seed, const int row_len, const double *_
   if (li >= dst.n_local) return;
   const u32x4 w = stream_block(seed, (uint64_t)(dst.gid0 + li), PURPOSE_RESAMPLE, iter, 0);
   const double *row;
-  (void)packed_search(u52(w.x, w.y) * totals[0], B, nb, ge, pk, pg, row_len + 1, n, row);
+  (void)packed_search(u52(w.x, w.y) * totals[0], B, nb, gc, ge, pk, pg, n, row);
   for (int r = 0; r < row_len; ++r) dst.pop[(int64_t)r * dst.cap + li] = row[r];
 }
 
@@ -1249,7 +1266,7 @@ int64_t resample_pack_doubles(int row_len, int64_t n) {
   const int pg = per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;
   if (pg == 0) return 0;
   const int64_t lines = (n + pg - 1) / pg;
-  return lines * 16 + lines + 16;
+  return lines * 16 + lines + (lines + 15) / 16 + 32;
 }
 
 // One shard: weights (fused into the first scan pass), scan, staging copy, draw + gather (+ the moment sums of the
@@ -1273,7 +1290,7 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
   std::memset(&pa, 0, sizeof(pa));
   if (pg > 0 && pack) {
     const int64_t lines = (n + pg - 1) / pg;
-    pa.pk = pack; pa.ge = pack + lines * 16; pa.row_len = rl; pa.pg = pg;
+    pa.pk = pack; pa.ge = pack + lines * 16; pa.gc = pa.ge + lines + 8; pa.row_len = rl; pa.pg = pg;
   }
   hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
@@ -1289,14 +1306,15 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
 #define CALL(M, D, S)                                                                                                    \
   do {                                                                                                                   \
     hipLaunchKernelGGL((k_resample_gather_stats<D, S>), grid, block, lds, stream, m.seed, (const double *)pa.pk,         \
-                       (const double *)pa.ge, pg, n, (const double *)bs, nb, (const double *)totals, iter, dst, cb,      \
-                       partials);                                                                                        \
+                       (const double *)pa.ge, (const double *)pa.gc, pg, n, (const double *)bs, nb,                      \
+                       (const double *)totals, iter, dst, cb, partials);                                                 \
     *stats_rows = n_blocks(n);                                                                                           \
   } while (0)
   if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
   if (m.model_id == SABC_MODEL_HOST || m.model_id == SABC_MODEL_USER) {
     hipLaunchKernelGGL(k_resample_gather_packed, grid, block, lds, stream, m.seed, rl, (const double *)pa.pk,
-                       (const double *)pa.ge, pg, n, (const double *)bs, nb, (const double *)totals, iter, dst);
+                       (const double *)pa.ge, (const double *)pa.gc, pg, n, (const double *)bs, nb, (const double *)totals, iter,
+                       dst);
     return SABC_LAUNCH_RC();
   }
   SABC_DISPATCH_MODEL(m, CALL);
