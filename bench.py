@@ -85,15 +85,17 @@ def _load_traffic(workload_n):
 
 
 def load_sq_summary(workload_n, config="cfg2"):
-    """VALU busy fraction / effective clock of the update kernel from the committed SQ counter pass (tools/pmc_sq.sh)."""
-    if config != "cfg2" or int(workload_n) != 1_000_000:
+    """VALU busy fraction / effective clock of the update kernel from the committed SQ counter passes (tools/pmc_sq.sh)."""
+    if int(workload_n) != 1_000_000:
         return {}
     try:
         import csv
-        rows = {r["name"]: float(r["value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_pmc_sq_cfg2.csv")))}
+        name = f"r02_pmc_sq_{config}.csv"
+        rows = {r["name"]: float(r["value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name)))}
         return {"pmc_valu_busy_fraction": rows["valu_busy_fraction"], "pmc_effective_clock_ghz": rows["effective_clock_ghz"],
                 "pmc_cycles_per_valu_instruction": rows["cycles_per_valu_instruction"],
-                "pmc_note": "rocprofv3 --pmc SQ_* pass of the same command (profiles/r01_pmc_sq_cfg2.csv): share of the SQ busy "
+                "pmc_wave_cycles_parked": rows["wave_cycles_parked_waitcnt_barrier"],
+                "pmc_note": f"rocprofv3 --pmc SQ_* passes of the same command (profiles/{name}): share of the SQ busy "
                             "cycles in which a SIMD's VALU executes"}
     except Exception:
         return {}

@@ -26,6 +26,15 @@ namespace sabc {
 // ------------------------------------------------------------------------------------------
 constexpr int kGkD = 4, kGkS = 4;
 constexpr int kGkPerBlock = (kBlock / 64) * kGkParticlesPerWave;
+// k_update_gk: every wave takes kGkReps groups of 16 particles in turn and the workgroup writes ONE partial row for all of
+// them.  Measured at n = 1e6 (tools/exp_ab2.sh, three runs each): 1 group 663 us, 2 groups 786 us, 4 groups 812 us -- the
+// loop around the phases costs the register allocator 240 more bytes of scratch and 16 more SGPR reloads per particle,
+// far more than the 12 us the shorter partial-row matrix saves in k_reduce_partials + k_control.  So: one group.
+#ifndef SABC_GK_REPS
+#define SABC_GK_REPS 1
+#endif
+constexpr int kGkReps = SABC_GK_REPS;
+constexpr int kGkUpdatePerBlock = kGkPerBlock * kGkReps;
 
 // per-wave staging of what phase 1 (propose + simulate) hands to phase 2 (ECDF) and 3 (accept)
 struct GkStage {
@@ -50,7 +59,10 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   __shared__ double red[kBlock / 64][NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   GkStage &st = stage[wave];
-  const int64_t t0 = (int64_t)blockIdx.x * kGkPerBlock + wave * PW;
+  if (lane < NP) red[wave][lane] = 0.0;
+  for (int rep = 0; rep < kGkReps; ++rep) {
+  const int64_t t0 = (int64_t)blockIdx.x * kGkUpdatePerBlock + (wave * kGkReps + rep) * PW;
+  if (t0 >= act_n) break;                  // uniform over the wave
   // the wave owns particles t0 .. t0+PW-1; in the scalar phases (1a, 3) lane i < PW handles particle t0+i
   const int64_t t_mine = t0 + lane;
   const bool mine = lane < PW && t_mine < act_n;
@@ -184,14 +196,18 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
     }
     moment_terms<D, S>(cb->pivot, accepted, th, u, rho, term);
   }
-  // sum the moment terms over the wave's 16 particle lanes (lanes >= 16 hold zeros), then over the 4 waves
+  // sum the moment terms over the wave's 16 particle lanes (lanes >= 16 hold zeros) into the wave's running row, ...
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     double v = term[q];
 #pragma unroll
     for (int off = PW / 2; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) red[wave][q] = v;
+    if (lane == 0) red[wave][q] += v;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();         // the staging arrays are reused by the next group
+  }
+  // ... then over the 4 waves
   __syncthreads();
   if (threadIdx.x < NP) {
     const int q = threadIdx.x;
@@ -1096,7 +1112,8 @@ static int module_launch(hipFunction_t f, unsigned grid, unsigned block, hipStre
     }                                                                                             \
   } while (0)
 
-inline unsigned gk_blocks(int64_t n) { return (unsigned)((n + kGkPerBlock - 1) / kGkPerBlock); }
+inline unsigned gk_blocks(int64_t n) { return (unsigned)((n + kGkPerBlock - 1) / kGkPerBlock); }                       // k_simulate_gk
+inline unsigned gk_update_blocks(int64_t n) { return (unsigned)((n + kGkUpdatePerBlock - 1) / kGkUpdatePerBlock); }   // k_update_gk
 
 int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream, const RtcKernels *rtc) {
   if (pp.n_local <= 0) return 0;
@@ -1125,8 +1142,8 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 // workgroups (= partial rows) of one k_update launch over act_n particles
 int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   if (act_n <= 0) return 0;
-  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_blocks(act_n)   // 64 particles per workgroup (wave per particle)
-                                     : n_blocks(act_n);            // 256 particles per workgroup
+  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_update_blocks(act_n)   // 256 particles per workgroup (wave per particle, 4 groups of 16 per wave)
+                                     : n_blocks(act_n);                   // 256 particles per workgroup
 }
 
 // ev0 / ev1 (optional): timing events attached to the dispatch packet itself (hipExtLaunchKernel), so that

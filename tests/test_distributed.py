@@ -94,6 +94,52 @@ def test_cpu_engine_resample_without_alltoallv_is_the_same_run(S, tmp_path):
     assert a["comm_bytes"][1] < b["comm_bytes"][1]
 
 
+def test_cpu_engine_failed_collective_restores_the_state(S):
+    """Error contract of sabc_update on the product's host engine (engine.cpp over the oracle-backed Backend): a collective
+    that fails in the middle of the loop leaves counters, eps and histories as they were at entry and the handle refuses
+    further updates until sabc_set_population has restored the particles."""
+    import ctypes as C
+    from tests import cpu_engine
+    from tests.cases import SEED, hip_model_prior, hip_proposal
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    h = cpu_engine.handle_class()(n_particles=400, model=model, prior=prior, seed=SEED, rank=0, world=2)
+    state = {"allreduce_calls": 0, "fail_at": None}
+
+    # a loop-back transport: this process plays both shards' collectives with its own data (enough to drive the engine)
+    def allreduce(ctx, buf, count, stream):
+        state["allreduce_calls"] += 1
+        if state["fail_at"] is not None and state["allreduce_calls"] >= state["fail_at"]:
+            return -1
+        a = np.ctypeslib.as_array((C.c_double * count).from_address(buf))
+        a *= 2.0                                            # two identical shards
+        return 0
+
+    def allgather(ctx, send, recv, count, stream):
+        a = np.ctypeslib.as_array((C.c_double * count).from_address(send))
+        out = np.ctypeslib.as_array((C.c_double * (2 * count)).from_address(recv))
+        out[:count] = a
+        out[count:] = a
+        return 0
+    h.set_collectives(allreduce, allgather, False)
+    h.initialize(400)
+    h.update(n_simulation=3 * 400, proposal=hip_proposal(S, "rw", 1))
+    before = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.history], [a.copy() for a in h.get_population()])
+    state.update(allreduce_calls=0, fail_at=5)              # the RandomWalk entry takes two reductions: fails in the third update
+    with pytest.raises(S.SABCError, match="allreduce"):
+        h.update(n_simulation=6 * 400, proposal=hip_proposal(S, "rw", 1))
+    assert dict(h.counters) == before[0]
+    np.testing.assert_array_equal(h.eps, before[1])
+    for a, b in zip(h.history, before[2]):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(S.SABCError, match="half-updated"):
+        h.update(n_simulation=400, proposal=hip_proposal(S, "rw", 1))
+    state.update(fail_at=None)
+    h.set_population(*before[3])                            # what a wrapper does from the result's own arrays
+    h.update(n_simulation=2 * 400, proposal=hip_proposal(S, "rw", 1))
+    assert h.counters["n_population_updates"] == before[0]["n_population_updates"] + 2
+    h.close()
+
+
 @pytest.mark.parametrize("prop,d,case", [("de", 1, "gauss1_cfg2"), ("stretch", 2, "gauss2_meansd")])
 def test_cpu_engine_comm_bytes_per_update(S, tmp_path, prop, d, case):
     """What crosses between shards per population update, counted by the engine (sabc_comm_bytes): DE / Stretch gather

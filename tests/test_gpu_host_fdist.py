@@ -110,6 +110,40 @@ def test_exception_in_f_dist_propagates(S, gpu):
         S.sabc(f_dist, S.Normal(0, 1), n_particles=100, n_simulation=1000)
 
 
+def test_failed_update_leaves_the_state_untouched(S, gpu):
+    """The reference works on copies and leaves `population_state` untouched when `update_population!` throws
+    (SimulatedAnnealingABC.jl:264-267, :387-397).  Here the particles are updated in place on the device, so after a
+    failure inside the loop the library puts counters, eps and histories back, and refuses further updates on the raw
+    handle until the particles have been restored -- which `update_population_` does from the result's own arrays."""
+    armed = {"on": False, "calls": 0}
+    rng = np.random.default_rng(3)
+
+    def f_dist(θ):
+        armed["calls"] += 1
+        if armed["on"] and armed["calls"] > 250:
+            raise ZeroDivisionError("simulator blew up")
+        return abs(0.3 - np.mean(rng.normal(θ, 1.0, 20)))
+    prior = S.Normal(0, 1)
+    res = S.sabc(f_dist, prior, n_particles=100, n_simulation=400, proposal=S.RandomWalk(n_para=1), seed=5)
+    h = res._handle
+    before = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.history], res.population.copy(), res.u.copy())
+    armed.update(on=True, calls=0)
+    with pytest.raises(ZeroDivisionError, match="blew up"):
+        S.update_population_(res, f_dist, prior, n_simulation=600, proposal=S.RandomWalk(n_para=1))
+    assert dict(h.counters) == before[0]
+    np.testing.assert_array_equal(h.eps, before[1])
+    for a, b in zip(h.history, before[2]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(res.population, before[3])          # the result object was not refreshed
+    assert res.state.n_population_updates == before[0]["n_population_updates"]
+    with pytest.raises(S.SABCError, match="half-updated"):              # the raw handle: SABC_ERR_STATE until restored
+        h.update(n_simulation=100, proposal=S.RandomWalk(n_para=1))
+    armed.update(on=False)
+    S.update_population_(res, f_dist, prior, n_simulation=200, proposal=S.RandomWalk(n_para=1))   # restores, then updates
+    assert res.state.n_population_updates == before[0]["n_population_updates"] + 2
+    assert res.state.n_simulation == before[0]["n_simulation"] + 200
+
+
 def test_negative_distance_from_host_simulator(S, gpu):
     with pytest.raises(S.SABCError, match="Negative distances"):       # SimulatedAnnealingABC.jl:185
         S.sabc(lambda θ: θ, S.Normal(0, 1), n_particles=100, n_simulation=1000)
