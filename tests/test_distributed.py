@@ -253,3 +253,60 @@ def test_nccl_hooks_single_rank(S, gpu):
         assert torch.equal(x, torch.arange(8, dtype=torch.float64, device="cuda")) and torch.equal(x, y)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 200_001), ("gauss2_2stats", "multi_eps", "de", 60_000),
+                                              ("gauss2d_cfg3", "single_eps", "stretch", 40_000)])
+def test_device_collectives_in_flight_two_shards_one_gpu(S, gpu, tmp_path, case, alg, prop, n):
+    """Two shards in one process on the one MI355X, one host thread and one stream each, collectives as device-side copies
+    in stream order with NO host wait on the stream (tests/loopback_collectives.py): the engine's pipeline -- two updates
+    queued ahead, guarded no-op steps behind a fired resample test, partner gathers and the resample exchange on device
+    pointers -- runs with collectives in flight, as it will over RCCL.  Must equal the CPU engine with the same sharding."""
+    import threading
+    import torch
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+    from tests.loopback_collectives import Loopback
+    world, k = 2, 12
+    lb = Loopback(world)
+    d = len(MODELS[case]["prior"])
+    out, err = [None] * world, [None] * world
+
+    def shard(rank):
+        try:
+            torch.cuda.set_device(0)
+            model, prior = hip_model_prior(S, case)
+            h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=world,
+                             algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
+            ar, ag, a2a = lb.hooks(rank)
+            h.set_collectives(ar, ag, True)                 # device buffers: the hooks get device pointers + the stream
+            h.set_alltoallv(a2a)
+            h.comm_selftest()
+            h.initialize((k + 1) * n)
+            syncs0 = h.host_syncs
+            h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=n // 4)
+            th, u, rho = h.get_population()
+            out[rank] = dict(theta=th, u=u, rho=rho, eps=h.eps, counters=h.counters, offset=h.local_offset,
+                             syncs=h.host_syncs - syncs0, comm=h.comm_bytes)
+            h.close()
+        except BaseException as e:                          # a failing shard must not leave the other at a barrier
+            err[rank] = e
+            lb.barrier.abort()
+
+    threads = [threading.Thread(target=shard, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(e is None for e in err), err
+    assert all(o is not None for o in out)
+    ref = launch(world, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    tol = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}[prop]
+    theta = np.concatenate([out[r]["theta"] for r in range(world)], 1)
+    c = out[0]["counters"]
+    assert [c[q] for q in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")] == list(ref["counters"])
+    assert c["n_resampling"] >= 3 and out[0]["counters"] == out[1]["counters"]
+    np.testing.assert_allclose(theta, ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(out[0]["eps"], ref["eps"], rtol=tol)
+    np.testing.assert_array_equal(out[0]["eps"], out[1]["eps"])          # every shard computed the same control step
