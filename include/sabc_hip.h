@@ -213,6 +213,8 @@ SABC_API double sabc_last_ess(const sabc_handle *h);
 SABC_API int sabc_op_build_cdf(int32_t device, const double *x, int64_t n, double *knots_out, int64_t *len_out);
 SABC_API int sabc_op_cdf_eval(int32_t device, const double *knots, int64_t len, const double *q, int64_t m,
                               double *out);
+/* the ascending sort behind build_cdf (cdf_estimators.jl:33 `sort(x)`): the library's own radix sort, any doubles */
+SABC_API int sabc_op_sort(int32_t device, const double *x, int64_t n, double *out);
 /* update_epsilon_single_eps / update_epsilon_multi_eps: SimulatedAnnealingABC.jl:92-117 (host code of the engine) */
 SABC_API int sabc_op_eps_single(double ubar, double v, double *eps_out);
 SABC_API int sabc_op_eps_multi(const double *ubar, int32_t s, double v, double *eps_out);

@@ -11,7 +11,7 @@ from .api import (SABCresult, SABCstate, initialization, is_logging, load_result
 from .distributions import (Beta, Exponential, Gamma, LogNormal, Normal, Product, TruncatedNormal, Uniform,  # noqa: F401
                             product_distribution, truncated)
 from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
-                     op_normal_pairs, op_philox, op_rng_peak)
+                     op_normal_pairs, op_philox, op_rng_peak, op_sort)
 from .models import DeviceDistance, DeviceSource, GandK, Gaussian2D, GaussianIID, HostDistance, LotkaVolterra  # noqa: F401
 from .proposals import DifferentialEvolution, Proposal, RandomWalk, StretchMove  # noqa: F401
 
@@ -20,6 +20,6 @@ __all__ = [
     "RandomWalk", "DifferentialEvolution", "StretchMove", "Proposal",
     "Normal", "Uniform", "Exponential", "LogNormal", "Gamma", "Beta", "TruncatedNormal", "truncated", "Product", "product_distribution",
     "DeviceDistance", "DeviceSource", "HostDistance", "GaussianIID", "Gaussian2D", "GandK", "LotkaVolterra",
-    "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox", "op_normal_pairs", "op_rng_peak",
+    "SabcHandle", "op_build_cdf", "op_cdf_eval", "op_eps_single", "op_eps_multi", "op_philox", "op_normal_pairs", "op_rng_peak", "op_sort",
     "build", "lib", "is_logging",
 ]

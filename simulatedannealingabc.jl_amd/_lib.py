@@ -152,6 +152,7 @@ def bind(L, strict=True):
         "sabc_get_proposal_sigma": ([vp, dp], C.c_int),
         "sabc_last_ess": ([vp], C.c_double),
         "sabc_op_build_cdf": ([C.c_int32, dp, C.c_int64, dp, ip64], C.c_int),
+        "sabc_op_sort": ([C.c_int32, dp, C.c_int64, dp], C.c_int),
         "sabc_op_cdf_eval": ([C.c_int32, dp, C.c_int64, dp, C.c_int64, dp], C.c_int),
         "sabc_op_eps_single": ([C.c_double, C.c_double, dp], C.c_int),
         "sabc_op_eps_multi": ([dp, C.c_int32, C.c_double, dp], C.c_int),

@@ -480,6 +480,27 @@ int sabc_op_build_cdf(int32_t device, const double *x, int64_t n, double *knots_
   return 0;
 }
 
+int sabc_op_sort(int32_t device, const double *x, int64_t n, double *out) {
+  std::string why;
+  int rc = usable_device(device, why);
+  if (rc) { g_err = why; return rc; }
+  if (n <= 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return SABC_ERR_HIP; }
+  double *a = nullptr, *b = nullptr;
+  void *tmp = nullptr;
+  size_t bytes = 0;
+  hipError_t e = hipMalloc((void **)&a, (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc((void **)&b, (size_t)n * 8);
+  if (e == hipSuccess) e = (hipError_t)sort_f64(a, b, n, nullptr, &bytes, nullptr);
+  if (e == hipSuccess) e = hipMalloc(&tmp, bytes ? bytes : 16);
+  if (e == hipSuccess) e = hipMemcpy(a, x, (size_t)n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = (hipError_t)sort_f64(a, b, n, tmp, &bytes, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, b, (size_t)n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(tmp);
+  if (e != hipSuccess) { g_err = hipGetErrorString(e); return SABC_ERR_HIP; }
+  return 0;
+}
+
 int sabc_op_cdf_eval(int32_t device, const double *knots, int64_t len, const double *q, int64_t m, double *out) {
   std::string why;
   int rc = usable_device(device, why);

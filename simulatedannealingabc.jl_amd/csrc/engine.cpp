@@ -170,6 +170,9 @@ int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool noti
   c.hist_capacity = hist_capacity_;
   c.notify_seq = notify ? ++notify_seq_ : 0;
   c.resample_threshold = threshold;
+  // update steps of the device-coded simulators report the change of sum(rho); stats passes (and the host-callback
+  // mode, whose sums come from a stats pass) the sum itself
+  c.rho_is_delta = ((mode & CTRL_ACCUMULATE) && !host_mode_) ? 1 : 0;
   if (seq_out) *seq_out = c.notify_seq;
   if (be_->control(c)) return fail(SABC_ERR_HIP, "control kernel failed");
   return 0;
@@ -480,6 +483,12 @@ int Engine::update_loop(const sabc_update_args &a) {
     if ((rc = control(CTRL_PIVOT, &a, a.v))) return rc;                     // centre the moment sums first
     if ((rc = stats_reduce())) return rc;
     if ((rc = control(CTRL_PROPOSAL, &a, a.v))) return rc;
+  }
+  if (n_pop > 0 && a.proposal_kind != SABC_PROP_RANDOMWALK && !host_mode_) {
+    // the update steps only report the CHANGE of sum(rho): start the running sum from the population as it stands (the
+    // caller may have replaced it with sabc_set_population since the last call)
+    if ((rc = stats_reduce())) return rc;
+    if ((rc = control(0, &a, a.v))) return rc;
   }
   if (n_pop > 0 && a.proposal_kind != SABC_PROP_RANDOMWALK) {
     const int64_t need = a.proposal_kind == SABC_PROP_DIFFEVO ? 2 : 1;

@@ -60,7 +60,8 @@ enum : int32_t {
 };
 
 struct ControlArgs {
-  int32_t mode, d, s, algorithm, prop_kind, reserved;
+  int32_t mode, d, s, algorithm, prop_kind;
+  int32_t rho_is_delta;                  // the rho block of the sums holds the CHANGE of sum(rho) (an update step), not the sum
   double n_global, v, prop_p0;
   int64_t hist_capacity;
   int64_t notify_seq;                    // != 0: post (n_accept, error, halted, seq) to the host mailbox
@@ -80,7 +81,7 @@ constexpr int kMailboxRing = 8;          // slot = seq % kMailboxRing; the host 
 // Layout of the fused per-update sums ("partials"): one row of `np` doubles.
 //   [0]                n_accept
 //   [1, 1+s)           sum_i u_ij
-//   [1+s, 1+2s)        sum_i rho_ij
+//   [1+s, 1+2s)        sum_i rho_ij  (stats passes)  |  sum over accepted i of rho'_ij - rho_ij  (update steps)
 //   [1+2s, 1+2s+d)     sum_i (theta_ik - pivot_k)
 //   [.., +d(d+1)/2)    sum_i (theta_ik - pivot_k)(theta_il - pivot_l), l <= k, row-major lower
 inline constexpr int n_partials(int d, int s) { return 1 + 2 * s + d + d * (d + 1) / 2; }

@@ -105,14 +105,14 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
   if (t < act_n) {
     const int64_t li = act_lo + t;
     const uint64_t gid = (uint64_t)(pp.gid0 + li);
-    double th[D], u[S], rho[S];
+    // rho is NOT read here: an update step reports the CHANGE of sum(rho) (rho' - rho of the accepted particles, read where
+    // they are overwritten); the control step adds it to the running sum (ControlArgs::rho_is_delta).  8 s n bytes less
+    // read per launch: the old distance of a particle that is not accepted is never needed.
+    double th[D], u[S], drho[S];
 #pragma unroll
     for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
-      rho[j] = pp.rho[(int64_t)j * pp.cap + li];
-    }
+    for (int j = 0; j < S; ++j) { u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li]; drho[j] = 0.0; }
 
     // ---- proposal (:311) ----
     double thp[D];
@@ -186,12 +186,13 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
       for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        u[j] = up[j]; rho[j] = rp[j];
+        u[j] = up[j];
+        drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
         pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
         pp.rho[(int64_t)j * pp.cap + li] = rp[j];
       }
     }
-    moment_terms<D, S>(cb->pivot, accepted, th, u, rho, acc);
+    moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
   }
   block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
 }

@@ -248,6 +248,16 @@ def op_build_cdf(x, device=0):
     return out[: ln.value].copy()
 
 
+def op_sort(x, device=0):
+    """Ascending sort on the device (the library's own radix sort; what build_cdf uses)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    rc = _lib.lib().sabc_op_sort(device, _dp(x), len(x), _dp(out))
+    if rc:
+        raise SABCError(rc, _lib.global_error())
+    return out
+
+
 def op_cdf_eval(knots, q, device=0):
     k = np.ascontiguousarray(knots, dtype=np.float64)
     qq = np.atleast_1d(np.ascontiguousarray(q, dtype=np.float64))

@@ -110,6 +110,7 @@ class RefBackend : public Backend {
   }
   static uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
+  // rho = the particle's distances (stats pass) or their change on acceptance (update step: ControlArgs::rho_is_delta)
   void moments(bool acc, const double *th, const double *u, const double *rho, double *row) const {
     const int d = m_.d, s = m_.s;
     row[0] += acc ? 1.0 : 0.0;
@@ -184,11 +185,12 @@ class RefBackend : public Backend {
         uint32_t wa[4];
         orc_stream_block(m_.seed, gid, ORC_PURPOSE_ACCEPT, c.iter, 0, wa);
         const bool accepted = std::log(orc_u52(wa[0], wa[1])) < log_accept;
+        double drho[ORC_MAX_STATS] = {0};
         if (accepted) {
           for (int k = 0; k < d; ++k) { th[k] = thp[k]; pop[(size_t)k * cap + li] = thp[k]; }
-          for (int j = 0; j < s; ++j) { u[j] = up[j]; rho[j] = rp[j]; pop[(size_t)(d + j) * cap + li] = up[j]; rho_[(size_t)j * cap + li] = rp[j]; }
+          for (int j = 0; j < s; ++j) { u[j] = up[j]; drho[j] = rp[j] - rho[j]; pop[(size_t)(d + j) * cap + li] = up[j]; rho_[(size_t)j * cap + li] = rp[j]; }
         }
-        moments(accepted, th, u, rho, row);
+        moments(accepted, th, u, drho, row);
       }
     }
     *rows_out = rows;

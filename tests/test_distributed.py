@@ -155,7 +155,7 @@ def test_cpu_engine_comm_bytes_per_update(S, tmp_path, prop, d, case):
     np_ = 1 + 2 * s + d + d * (d + 1) // 2
     per_update = 2 * world * d * hcap * 8 + np_ * 8
     assert got["counters"][2] == 1
-    assert int(got["comm_bytes"][1]) == k * per_update
+    assert int(got["comm_bytes"][1]) == k * per_update + np_ * 8       # + the sums of the population at entry
     assert per_update * 2 <= (2 * world * d * cap * 8 + np_ * 8) + np_ * 8 + 2 * world * d * 8   # >= 2x below the round-1 volume
 
 

@@ -26,7 +26,7 @@ def test_cfg2_counters_and_invariants(cfg2):
     ubar, e = cfg2.u.mean(), st.ϵ[0]
     assert abs(e * e + e ** 1.5 - ubar * ubar) < 1e-9 * ubar * ubar                          # :93, v = 1
     assert st.u_history[-1][0] == pytest.approx(ubar, rel=1e-12)
-    assert st.ρ_history[-1][0] == pytest.approx(cfg2.ρ.mean(), rel=1e-12)
+    assert st.ρ_history[-1][0] == pytest.approx(cfg2.ρ.mean(), rel=1e-10)      # a running sum: += the change per update
 
 
 def test_cfg2_ecdf_table(cfg2):

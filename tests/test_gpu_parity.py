@@ -67,6 +67,27 @@ def test_cdf_estimator_on_device(S, O, gpu, data):
     np.testing.assert_allclose(S.op_cdf_eval(kn, qq), O.cdf_apply(kn, qq), rtol=1e-14, atol=1e-16)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 255, 256, 257, 1023, 1024, 1025, 4097, 1_000_003])
+def test_radix_sort_on_device(S, gpu, n):
+    """The hand-written LSD radix sort behind build_cdf (csrc/sort.hip) on arbitrary doubles: negatives, signed zeros,
+    infinities, denormals, heavy ties, every tile-boundary size."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)
+    k = max(n // 7, 1)
+    x[rng.integers(0, n, k)] = rng.choice([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, 5e-324, -5e-324, 1.5, 1.5, 1.5], k)
+    got = S.op_sort(x)
+    want = np.sort(x)
+    np.testing.assert_array_equal(got, want)                       # (-0.0 == 0.0 compares equal: their mutual order is free)
+    assert np.all(np.signbit(got[got < 0])) and not np.any(np.signbit(got[got > 0]))
+    # signed zeros: all -0.0 before all +0.0 (the key order), nothing lost
+    z = got[got == 0]
+    assert np.array_equal(np.signbit(z), np.sort(np.signbit(z))[::-1]) and len(z) == np.sum(x == 0)
+    # heavy ties and an already sorted / reversed input
+    t = rng.integers(0, 3, n).astype(float)
+    np.testing.assert_array_equal(S.op_sort(t), np.sort(t))
+    np.testing.assert_array_equal(S.op_sort(want[::-1].copy()), want)
+
+
 def test_cdf_estimator_errors(S, gpu):
     with pytest.raises(S.SABCError) as e:
         S.op_build_cdf([0.0, 0.0, 0.0])
