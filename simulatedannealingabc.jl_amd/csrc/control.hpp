@@ -16,10 +16,11 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
   if ((a.mode & CTRL_GUARDED) && cb.halt) return false;
   if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
   const int d = a.d, s = a.s;
-  for (int q = 0; q < n_partials(d, s); ++q) {
-    const bool delta = a.rho_is_delta && q >= 1 + s && q < 1 + 2 * s;            // running sum(rho) += its change
-    cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
-  }
+  if (!(a.mode & CTRL_KEEP_SUMS))
+    for (int q = 0; q < n_partials(d, s); ++q) {
+      const bool delta = a.rho_is_delta && q >= 1 + s && q < 1 + 2 * s;          // running sum(rho) += its change
+      cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
+    }
   const double n = a.n_global;
   const double *S = &cb.sums[1 + 2 * s], *Q = &cb.sums[1 + 2 * s + d];
 

@@ -548,7 +548,7 @@ int Engine::update_loop(const sabc_update_args &a) {
     ++next_confirm;
   }
   if (last_checkpoint != n_pop) {                                           // :378-382
-    if ((rc = control(CTRL_HISTORY, &a, a.v))) return rc;
+    if ((rc = control(CTRL_HISTORY | CTRL_KEEP_SUMS, &a, a.v))) return rc;
   }
   if ((rc = sync_control())) return rc;
   if ((rc = drain_history())) return rc;

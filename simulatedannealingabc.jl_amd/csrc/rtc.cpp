@@ -6,6 +6,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sabc_hip.h"
@@ -58,6 +60,15 @@ HiprtcApi *hiprtc_api() {
 
 void anchor() {}
 
+// compiled code objects of this process, keyed by (source, d, s): a second handle with the same simulator (every
+// sabc() call makes one) loads the module without paying the ~2 s of compilation again
+struct CachedModule {
+  std::vector<char> code;
+  std::string lowered[6];
+};
+std::mutex g_cache_mutex;
+std::map<std::string, CachedModule> g_cache;
+
 }  // namespace
 
 std::string rtc_default_csrc_dir() {
@@ -107,6 +118,26 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   std::snprintf(name[4], sizeof(name[4]), "sabc::k_simulate_batch<%d, %d, %d>", SABC_MODEL_USER, d, s);
   std::snprintf(name[5], sizeof(name[5]), "sabc::k_stats<%d, %d>", d, s);
 
+  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + "\n" + user_source;
+  if (out) {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto hit = g_cache.find(cache_key);
+    if (hit != g_cache.end()) {
+      RtcKernels k;
+      k.d = d; k.s = s;
+      if (hipModuleLoadData(&k.module, hit->second.code.data()) != hipSuccess) { *log = "hipModuleLoadData of the cached simulator failed"; return -1; }
+      hipFunction_t *slots[6] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats};
+      for (int i = 0; i < 6; ++i)
+        if (hipModuleGetFunction(slots[i], k.module, hit->second.lowered[i].c_str()) != hipSuccess) {
+          *log = std::string("kernel not found in the cached module: ") + name[i];
+          rtc_release(&k);
+          return -1;
+        }
+      if (code_size) *code_size = hit->second.code.size();
+      *out = k;
+      return 0;
+    }
+  }
   void *prog = nullptr;
   if (api->CreateProgram(&prog, src.c_str(), "sabc_user_simulator.hip", 0, nullptr, nullptr)) { *log = "hiprtcCreateProgram failed"; return -1; }
   for (int i = 0; i < 6; ++i) api->AddNameExpression(prog, name[i]);
@@ -148,6 +179,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
     return -1;
   }
   hipFunction_t *slots[6] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats};
+  CachedModule entry;
   for (int i = 0; i < 6; ++i) {
     const char *lowered = nullptr;
     if (api->GetLoweredName(prog, name[i], &lowered) || !lowered ||
@@ -157,8 +189,14 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       rtc_release(&k);
       return -1;
     }
+    entry.lowered[i] = lowered;
   }
   api->DestroyProgram(&prog);
+  entry.code = std::move(code);
+  {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    g_cache.emplace(cache_key, std::move(entry));
+  }
   *out = k;
   return 0;
 }

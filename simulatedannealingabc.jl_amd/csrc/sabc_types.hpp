@@ -56,7 +56,9 @@ enum : int32_t {
   CTRL_HISTORY = 16,      // append (eps, mean u, mean rho)               (:367-372)
   CTRL_CHECK = 32,        // n_accept >= threshold ? set halt and stop here  (:340)
   CTRL_CLEAR_HALT = 64,   // after the host-driven resample
-  CTRL_GUARDED = 128      // no-op while halt is set (a step that was queued ahead of the decision)
+  CTRL_GUARDED = 128,     // no-op while halt is set (a step that was queued ahead of the decision)
+  CTRL_KEEP_SUMS = 256    // no reduction preceded this step: work on ControlBlock::sums as they stand (the staging buffer
+                          // still holds the LAST step's sums -- for an update step the change of sum(rho), not the sum)
 };
 
 struct ControlArgs {

@@ -1,8 +1,9 @@
 // sort.hip -- ascending sort of one distance column (cdf_estimators.jl:33 `sort(x)`), once per statistic at
 // initialization: a hand-written least-significant-digit radix sort for gfx950 (8 bits per pass, 8 passes over the
-// order-preserving 64-bit image of a double).  Per pass three launches:
+// order-preserving 64-bit image of a double).  Per pass four launches:
 //   k_radix_hist    every workgroup counts the digits of its tile of 1024 keys (LDS atomics) -> hist[digit][tile]
-//   k_radix_scan    exclusive prefix over hist in (digit, tile) order: where each tile's keys of each digit go
+//   k_radix_rowsum, k_radix_rowscan   exclusive prefix over hist in (digit, tile) order: where each tile's keys of each
+//                   digit go (one workgroup per digit, coalesced)
 //   k_radix_scatter every workgroup ranks its keys STABLY (wave-level match by ballots, waves and quarter-tiles in order)
 //                   and writes them to their places
 // The first pass reads doubles and maps them to keys, the last maps back.  The result of a sort is unique, so nothing here
@@ -53,25 +54,52 @@ k_radix_hist(const void *__restrict__ src, const int64_t n, const int shift, con
   hist[(int64_t)threadIdx.x * n_tiles + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// exclusive prefix sum of `len` counters in place (one workgroup of 1024: thread t owns a contiguous run)
-__global__ void __launch_bounds__(1024)
-k_radix_scan(uint64_t *__restrict__ hist, const int64_t len) {
-  __shared__ uint64_t part[2][1024];
-  const int t = threadIdx.x;
-  const int64_t per = (len + 1023) / 1024;
-  const int64_t lo = (int64_t)t * per, hi = (lo + per < len) ? lo + per : len;
+// Exclusive prefix over hist in (digit, tile) order, in two launches of 256 workgroups (one per digit, coalesced row
+// accesses): the row totals, then every row scanned in place on top of the total of the rows before it.
+__global__ void __launch_bounds__(kSortBlock)
+k_radix_rowsum(const uint64_t *__restrict__ hist, const int64_t n_tiles, uint64_t *__restrict__ totals) {
+  __shared__ uint64_t sm[kSortBlock / 64];
+  const uint64_t *row = hist + (int64_t)blockIdx.x * n_tiles;
   uint64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += hist[i];
-  part[0][t] = s;
+  for (int64_t i = threadIdx.x; i < n_tiles; i += kSortBlock) s += row[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
-  int cur = 0;
-  for (int off = 1; off < 1024; off <<= 1) {
-    part[1 - cur][t] = t >= off ? part[cur][t] + part[cur][t - off] : part[cur][t];
-    cur = 1 - cur;
+  if (threadIdx.x == 0) totals[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void __launch_bounds__(kSortBlock)
+k_radix_rowscan(uint64_t *__restrict__ hist, const int64_t n_tiles, const uint64_t *__restrict__ totals) {
+  __shared__ uint64_t part[2][kSortBlock];
+  __shared__ uint64_t carry;
+  const int t = threadIdx.x;
+  // where this digit starts: the totals of the digits before it (tree sum over the 256 totals, masked)
+  part[0][t] = t < (int)blockIdx.x ? totals[t] : 0;
+  __syncthreads();
+  for (int off = kSortBlock / 2; off > 0; off >>= 1) {
+    if (t < off) part[0][t] += part[0][t + off];
     __syncthreads();
   }
-  uint64_t run = t > 0 ? part[cur][t - 1] : 0;
-  for (int64_t i = lo; i < hi; ++i) { const uint64_t v = hist[i]; hist[i] = run; run += v; }
+  if (t == 0) carry = part[0][0];
+  __syncthreads();
+  uint64_t *row = hist + (int64_t)blockIdx.x * n_tiles;
+  for (int64_t base = 0; base < n_tiles; base += kSortBlock) {     // 256 counters per trip: inclusive scan in LDS
+    const int64_t i = base + t;
+    const uint64_t v = i < n_tiles ? row[i] : 0;
+    part[0][t] = v;
+    __syncthreads();
+    int cur = 0;
+    for (int off = 1; off < kSortBlock; off <<= 1) {
+      part[1 - cur][t] = t >= off ? part[cur][t] + part[cur][t - off] : part[cur][t];
+      cur = 1 - cur;
+      __syncthreads();
+    }
+    if (i < n_tiles) row[i] = carry + part[cur][t] - v;            // exclusive
+    __syncthreads();
+    if (t == kSortBlock - 1) carry += part[cur][t];
+    __syncthreads();
+  }
 }
 
 template <bool FIRST, bool LAST>
@@ -127,7 +155,7 @@ k_radix_scatter(const void *__restrict__ src, void *__restrict__ dst, const int6
 // ascending sort of n doubles.  tmp == nullptr: *tmp_bytes receives the scratch size (digit counters + one key buffer).
 int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream) {
   const int64_t n_tiles = n > 0 ? (n + kSortTile - 1) / kSortTile : 1;
-  const size_t hist_bytes = (size_t)kRadix * (size_t)n_tiles * sizeof(uint64_t);
+  const size_t hist_bytes = ((size_t)kRadix * (size_t)n_tiles + kRadix) * sizeof(uint64_t);   // counters + row totals
   const size_t need = hist_bytes + (size_t)(n > 0 ? n : 1) * sizeof(uint64_t);
   if (!tmp) { *tmp_bytes = need; return 0; }
   if (*tmp_bytes < need) return (int)hipErrorInvalidValue;
@@ -141,7 +169,9 @@ int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_by
     const int shift = 8 * pass;
     if (pass == 0) hipLaunchKernelGGL(k_radix_hist<true>, grid, block, 0, stream, src, n, shift, n_tiles, hist);
     else hipLaunchKernelGGL(k_radix_hist<false>, grid, block, 0, stream, src, n, shift, n_tiles, hist);
-    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, stream, hist, (int64_t)kRadix * n_tiles);
+    uint64_t *totals = hist + (size_t)kRadix * (size_t)n_tiles;
+    hipLaunchKernelGGL(k_radix_rowsum, dim3(kRadix), block, 0, stream, (const uint64_t *)hist, n_tiles, totals);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(kRadix), block, 0, stream, hist, n_tiles, (const uint64_t *)totals);
     if (pass == 0) hipLaunchKernelGGL((k_radix_scatter<true, false>), grid, block, 0, stream, src, dst, n, shift, n_tiles, (const uint64_t *)hist);
     else if (pass == 7) hipLaunchKernelGGL((k_radix_scatter<false, true>), grid, block, 0, stream, src, dst, n, shift, n_tiles, (const uint64_t *)hist);
     else hipLaunchKernelGGL((k_radix_scatter<false, false>), grid, block, 0, stream, src, dst, n, shift, n_tiles, (const uint64_t *)hist);

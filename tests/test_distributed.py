@@ -94,6 +94,32 @@ def test_cpu_engine_resample_without_alltoallv_is_the_same_run(S, tmp_path):
     assert a["comm_bytes"][1] < b["comm_bytes"][1]
 
 
+@pytest.mark.parametrize("prop", ["rw", "de", "stretch"])
+def test_cpu_engine_histories_match_the_oracle(S, O, prop):
+    """The host engine's history rows (eps, mean u, mean rho -- the last from a RUNNING sum that update steps only report
+    changes to) against the oracle's, with a checkpoint cadence that leaves a final push (:378-382) and resamples firing."""
+    from tests import cpu_engine
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal, oracle_config, oracle_proposal
+    case, n, k, cph = "gauss2_meansd", 600, 10, 3
+    d = len(MODELS[case]["prior"])
+    model, prior = hip_model_prior(S, case)
+    h = cpu_engine.handle_class()(n_particles=n, model=model, prior=prior, seed=SEED)
+    h.initialize((k + 1) * n)
+    h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=n // 2, checkpoint_history=cph)
+    run = O.OracleRun(oracle_config(O, case, n, seed=SEED))
+    run.initialize((k + 1) * n)
+    run.update(O.make_update_args(n_simulation=k * n, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=n // 2,
+                                  checkpoint_history=cph))
+    assert h.counters == run.counters and run.counters["n_resampling"] >= 3
+    e, u, r = h.history
+    oe, ou, orr = run.history
+    assert len(e) == 1 + k // cph + 1                               # initial row, every third update, the final push
+    np.testing.assert_allclose(e, oe, rtol=1e-10)
+    np.testing.assert_allclose(u, ou, rtol=1e-10)
+    np.testing.assert_allclose(r, orr, rtol=1e-10)
+    h.close()
+
+
 def test_cpu_engine_failed_collective_restores_the_state(S):
     """Error contract of sabc_update on the product's host engine (engine.cpp over the oracle-backed Backend): a collective
     that fails in the middle of the loop leaves counters, eps and histories as they were at entry and the handle refuses
