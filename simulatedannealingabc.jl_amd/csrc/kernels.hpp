@@ -118,7 +118,7 @@ int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, doub
 // compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
 int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
                           hipStream_t stream);
-// ascending sort of n doubles (rocPRIM radix sort); query tmp size with tmp == nullptr
+// ascending sort of n doubles (sort.hip: LSD radix sort, 8 passes of 8 bits); query tmp size with tmp == nullptr
 int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream);
 // host-simulator mode (SABC_MODEL_HOST): the per-particle body cut at f_dist
 int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
