@@ -673,9 +673,26 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
   }
   sm[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {             // exclusive scan of 256 thread totals, fixed order
+  // Exclusive scan of the 256 thread totals in the FIXED sequential order 0, 1, 2, ... (part of the summation order the
+  // oracle shares).  One lane walking the LDS array paid a dependent LDS round trip per element (~12 us of the kernel);
+  // here the first wave holds the totals in registers (4 per lane) and the running sum visits them in the same order
+  // through v_readlane: the same 256 additions, in registers.
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const double a[4] = {sm[4 * lane], sm[4 * lane + 1], sm[4 * lane + 2], sm[4 * lane + 3]};
+    double ex[4] = {0.0, 0.0, 0.0, 0.0};
     double run = 0.0;
-    for (int k = 0; k < kBlock; ++k) { const double v = sm[k]; sm[k] = run; run += v; }
+    for (int l = 0; l < 64; ++l) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[e]), l),
+                                          __builtin_amdgcn_readlane(__double2loint(a[e]), l));
+        if (lane == l) ex[e] = run;
+        run += b;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[4 * lane + e] = ex[e];
   }
   __syncthreads();
   double run = bs[blockIdx.x] + sm[threadIdx.x];

@@ -185,6 +185,22 @@ def test_cpu_engine_comm_bytes_per_update(S, tmp_path, prop, d, case):
     assert per_update * 2 <= (2 * world * d * cap * 8 + np_ * 8) + np_ * 8 + 2 * world * d * 8   # >= 2x below the round-1 volume
 
 
+@pytest.mark.parametrize("world,n", [(3, 1000), (2, 1001), (8, 1003)])
+def test_cpu_engine_partner_gather_geometry(S, tmp_path, world, n):
+    """Ragged shards and odd half batches: every partner index a DifferentialEvolution / StretchMove proposal can draw
+    lands on a particle of the inactive half of some shard (the gathered blocks hold only those halves, ceil(cap / 2)
+    doubles per row and shard).  A run with partners read from the wrong place drifts out of the prior's support or
+    stops annealing; this one behaves like the evenly sharded run, and twice the same."""
+    kw = dict(engine="cpu", backend="gloo", case="gauss2_meansd", prop="de", n=n, updates=10, resample=n // 2)
+    a = launch(world, str(tmp_path / "a.npz"), **kw)
+    b = launch(world, str(tmp_path / "b.npz"), **kw)
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    even = launch(2, str(tmp_path / "e.npz"), **dict(kw, n=1000))
+    assert abs(a["counters"][1] / n / (even["counters"][1] / 1000) - 1) < 0.06          # acceptances per particle
+    assert abs(a["eps"][0] / even["eps"][0] - 1) < 0.25 and abs(int(a["counters"][2]) - int(even["counters"][2])) <= 1
+    assert np.all(a["theta"][1] >= 0) and np.all(a["theta"][1] <= 1)                    # second parameter: Uniform(0, 1) prior
+
+
 @pytest.mark.parametrize("prop", ["de", "stretch"])
 def test_cpu_engine_sharded_partner_proposals(S, O, tmp_path, prop):
     """Partners are drawn from the inactive halves of ALL shards (exact global semantics); the run is
@@ -202,7 +218,9 @@ def test_cpu_engine_sharded_partner_proposals(S, O, tmp_path, prop):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 20001), ("gauss2_2stats", "multi_eps", "de", 10000),
-                                              ("gauss2d_cfg3", "single_eps", "stretch", 10000)])
+                                              ("gauss2d_cfg3", "single_eps", "stretch", 10000),
+                                              ("gauss2_2stats", "single_eps", "de", 10003),      # ragged last shard, odd halves
+                                              ("gauss1_cfg2", "single_eps", "stretch", 9999)])
 def test_hip_two_shards_on_one_gpu(S, gpu, tmp_path, case, alg, prop, n):
     """libsabc_hip.so with world = 2 (gloo hooks, both ranks on this GPU) against the CPU engine with the
     same sharding, and for RandomWalk against its own single-process run."""
