@@ -30,7 +30,7 @@ HipBackend::~HipBackend() {
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_, stage_dev_};
+  double *dev[] = {pop_[0], pop_[1], rho_, knots_, coarse_, mid_, partials_, hist_dev_, sums_stage_, gather_, cum_, block_sums_, totals_dev_, col_a_, col_b_, pack_dev_};
   for (double *p : dev)
     if (p) (void)hipFree(p);
   for (double *p : scratch_)
@@ -506,15 +506,15 @@ int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
 
 // one shard: the whole of :124-137 in four launches (kernels.hpp: launch_resample_local)
 int HipBackend::resample_local(double delta, uint64_t iter, int64_t *stats_rows) {
-  if (!stage_dev_) {
+  if (!pack_dev_) {
     const int64_t doubles = resample_pack_doubles(m_.d + m_.s, sh_.cap > 0 ? sh_.cap : 1);
-    if (doubles > 0) HB_CHECK(hipMalloc((void **)&stage_dev_, (size_t)doubles * sizeof(double)), "hipMalloc(packed resample lines)");
+    if (doubles > 0) HB_CHECK(hipMalloc((void **)&pack_dev_, (size_t)doubles * sizeof(double)), "hipMalloc(packed resample lines)");
   }
   if (pending_rows_ >= 0 && flush_reduce()) return -1;      // the partial rows are about to be overwritten
   const int nxt = 1 - cur_;
   prof_begin(SABC_KERNEL_RESAMPLE);
   HB_LAUNCH(launch_resample_local(m_, pop_ptrs(cur_), pop_ptrs(nxt), cb_dev_, delta, iter, block_sums_, cum_, totals_dev_, totals_host_dev_,
-                                  stage_dev_, partials_, stats_rows, stream_), "resample kernels");
+                                  pack_dev_, partials_, stats_rows, stream_), "resample kernels");
   prof_end(SABC_KERNEL_RESAMPLE);
   cur_ = nxt;
   return 0;

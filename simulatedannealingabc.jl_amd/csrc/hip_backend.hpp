@@ -110,7 +110,7 @@ class HipBackend : public Backend {
   unsigned long long *bucket_host_ = nullptr;             // pinned staging of the same
   double *cum_ = nullptr, *block_sums_ = nullptr, *totals_dev_ = nullptr;
   double *totals_host_ = nullptr, *totals_host_dev_ = nullptr;   // pinned + mapped: k_scan_offsets posts (sum w, sum w^2) there
-  double *stage_dev_ = nullptr;                                  // one shard: interleaved (theta, u) copy the gather reads
+  double *pack_dev_ = nullptr;                                   // one shard: packed resample lines (kernels.hpp: launch_resample_local)
   double *col_a_ = nullptr, *col_b_ = nullptr;
   void *sort_tmp_ = nullptr;
   size_t sort_tmp_bytes_ = 0;

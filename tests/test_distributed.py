@@ -117,6 +117,14 @@ def test_cpu_engine_histories_match_the_oracle(S, O, prop):
     np.testing.assert_allclose(e, oe, rtol=1e-10)
     np.testing.assert_allclose(u, ou, rtol=1e-10)
     np.testing.assert_allclose(r, orr, rtol=1e-10)
+    # ... and the particles themselves: on one shard the engine's half batches are the reference's (:300-301), so the whole
+    # state must be the oracle's for every proposal (the sharded RandomWalk runs are tied to this one by
+    # test_cpu_engine_sharded_randomwalk_equals_single_shard)
+    th, u, rho = h.get_population()
+    np.testing.assert_allclose(th, run.theta, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(u, run.u, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(rho, run.rho, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(h.eps, run.eps, rtol=1e-10)
     h.close()
 
 
