@@ -174,6 +174,7 @@ def main():
                     help="nccl (= RCCL) is the product path; gloo lets several ranks share one GPU to rehearse the N > 1 code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
+    ap.add_argument("--time-every-launch", action="store_true", help="HIP events on every k_update launch instead of every second one")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=100, help="population updates of the CPU baseline sample (~15 s on 16 cores)")
     ap.add_argument("--allow-hooks", action="store_true",
@@ -257,7 +258,7 @@ def main():
 
     if W > 0:
         h.update(n_simulation=W * n, proposal=proposal)
-    h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else 1))
+    h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else (3 if args.time_every_launch else 1)))
     barrier()
     syncs0 = h.host_syncs
     comm0 = h.comm_bytes
@@ -281,11 +282,10 @@ def main():
 
     if rank == 0:
         bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
-        # launches that ran: K (RandomWalk: one per update) or 2K; launches beyond that were queued ahead of a
-        # resample decision that fired and returned at once (their ~2 us are in kern_ms but they did no work)
+        # launches of the update kernel in the timed region: K (RandomWalk: one per update) or 2K; every second one carries
+        # timing events (sabc_profile_enable level 1), `launches` of them came back
         real_launches = K if args.proposal == "randomwalk" else 2 * K
-        aborted = max(launches - real_launches, 0)
-        avg_launch_s = (kern_ms / real_launches) * 1e-3 if launches else float("nan")
+        avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
         sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
         valu = None
@@ -329,7 +329,7 @@ def main():
                 "traffic": load_traffic(n, args.config) if world == 1 else None,   # measured for a 1e6-particle launch
                 "kernel": f"k_update<{type(model).__name__},{d},{s},{args.proposal}>",
                 "avg_launch_us": avg_launch_s * 1e6 if launches else None,
-                "launches": real_launches, "aborted_launches": aborted,
+                "launches": real_launches, "timed_launches": launches,
                 "algorithmic_bytes_per_sim": bytes_per_sim,
                 "note": f"not HBM-bound by construction: {normals_per_sim} f64 normals ({normals_per_sim // 2} Philox4x32-10 "
                         f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; the binding resource is VALU issue "
@@ -342,7 +342,7 @@ def main():
             # bytes landing in one shard's receive buffers per population update (allreduce of the fused sums; DE / Stretch:
             # two allgathers of the inactive halves; on resamples the weight row and the rows the shard drew)
             "comm_bytes_per_step": comm_bytes / K,
-            "kernel_time_frac": (kern_ms * 1e-3) / dt if launches else None,
+            "kernel_time_frac": (avg_launch_s * real_launches) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": c["n_resampling"] - resampling0,
             "host_syncs_in_timed_region": syncs,

@@ -243,7 +243,9 @@ SABC_API int sabc_op_rng_peak(int32_t device, int64_t n_lanes, int32_t pairs_per
 enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
        SABC_KERNEL_COUNT = 4 };
 /* HIP-event timing of kernels on the library's stream, accumulated since enable.
-   level 0 off, 1 = SABC_KERNEL_UPDATE only (each event is a marker packet the queue drains), 2 = all */
+   level 0 off, 1 = every second launch of SABC_KERNEL_UPDATE (the events ride on the kernel's dispatch packet and cost
+   ~4 us of queue time each: sampling halves what the measurement adds), 2 = every kernel, 3 = every launch of
+   SABC_KERNEL_UPDATE.  sabc_profile_get returns the time and the number of the launches that were timed. */
 SABC_API int sabc_profile_enable(sabc_handle *h, int32_t level);
 SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
 /* how many times update()/initialize() had to wait for the device so far (run-ahead windows) */

@@ -479,8 +479,10 @@ int Engine::update_loop(const sabc_update_args &a) {
   if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
 
   if (a.proposal_kind == SABC_PROP_RANDOMWALK) {                            // update_proposal!, :284
-    if ((rc = stats_reduce())) return rc;
-    if ((rc = control(CTRL_PIVOT, &a, a.v))) return rc;                     // centre the moment sums first
+    if (population_replaced_) {                                             // the pivot of the last call may be far off
+      if ((rc = stats_reduce())) return rc;
+      if ((rc = control(CTRL_PIVOT, &a, a.v))) return rc;                   // centre the moment sums first
+    }
     if ((rc = stats_reduce())) return rc;
     if ((rc = control(CTRL_PROPOSAL, &a, a.v))) return rc;
   }
@@ -552,6 +554,7 @@ int Engine::update_loop(const sabc_update_args &a) {
   }
   if ((rc = sync_control())) return rc;
   if ((rc = drain_history())) return rc;
+  population_replaced_ = false;                                             // the pivot now follows the population
   n_simulation_ += n_updates;                                               // :391
   n_population_updates_ += n_pop;                                           // :394
   return 0;

@@ -121,7 +121,7 @@ class Engine {
   void set_cdf_len(int stat, int64_t len) { cdf_len_[stat] = len; }
   const double *sigma() const { return cb_.sigma; }
   bool initialized() const { return initialized_; }
-  void mark_initialized() { initialized_ = true; }
+  void mark_initialized() { initialized_ = true; population_replaced_ = true; }   // sabc_set_population
   void set_collectives(Collectives *c) { coll_ = c; }
   // how often update() had to wait for the device (one per run-ahead window), for measurement
   int64_t host_syncs() const { return host_syncs_; }
@@ -157,6 +157,7 @@ class Engine {
   Collectives *coll_;
   std::string err_;
   bool initialized_ = false;
+  bool population_replaced_ = true;                 // the particles may lie anywhere relative to ControlBlock::pivot
 
   int np_ = 0, eps_len_ = 1;
   bool host_mode_ = false;                          // f_dist is a host callback (SABC_MODEL_HOST)

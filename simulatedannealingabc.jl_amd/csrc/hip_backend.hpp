@@ -125,6 +125,7 @@ class HipBackend : public Backend {
   RtcKernels rtc_;                                        // SABC_MODEL_USER: kernels compiled from the user's source
   const RtcKernels *rtc() const { return rtc_.module ? &rtc_ : nullptr; }
   int prof_ = 0, prof_open_ = -1;
+  unsigned prof_tick_ = 0;
   struct EvPair { hipEvent_t a, b; };
   std::vector<EvPair> ev_[SABC_KERNEL_COUNT];
   std::vector<EvPair> ev_pool_;

@@ -43,7 +43,10 @@ constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 // one workgroup per 256 particles and dynamic workgroup scheduling stay)
 // partial-row matrices up to this many doubles are summed inside the control kernel (one launch,
 // one CU); larger ones by the np-workgroup reduction first
-constexpr int64_t kFuseReduceMaxDoubles = 8192;   // measured at n = 1e6 (19.5 k doubles): 271 us/update unfused, 277 fused
+#ifndef SABC_FUSE_REDUCE_MAX
+#define SABC_FUSE_REDUCE_MAX 8192
+#endif
+constexpr int64_t kFuseReduceMaxDoubles = SABC_FUSE_REDUCE_MAX;   // measured at n = 1e6 (19.5 k doubles): 271 us/update unfused, 277 fused
 
 inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 
