@@ -44,9 +44,11 @@ constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 // partial-row matrices up to this many doubles are summed inside the control kernel (one launch,
 // one CU); larger ones by the np-workgroup reduction first
 #ifndef SABC_FUSE_REDUCE_MAX
-#define SABC_FUSE_REDUCE_MAX 8192
+#define SABC_FUSE_REDUCE_MAX 32768
 #endif
-constexpr int64_t kFuseReduceMaxDoubles = SABC_FUSE_REDUCE_MAX;   // measured at n = 1e6 (19.5 k doubles): 271 us/update unfused, 277 fused
+// (round 2, same-box A/B at n = 1e6 = 19.5 k doubles, four runs each: step minus update kernel 31.2 us with the two
+// launches, 30.2 us fused; round 1 had measured the fused form 6 us slower, before the control step worked on an LDS copy)
+constexpr int64_t kFuseReduceMaxDoubles = SABC_FUSE_REDUCE_MAX;
 
 inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 
