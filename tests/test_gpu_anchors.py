@@ -119,3 +119,49 @@ def test_two_philox_keys_agree_within_monte_carlo_error(S, gpu):
         assert abs(x["theta"][0].mean() - y["theta"][0].mean()) < 0.0005
         assert not np.array_equal(x["theta"], y["theta"])
     assert stats.ks_2samp(a[-1]["theta"][0][::20], b[-1]["theta"][0][::20]).statistic < 0.012
+
+
+SIM_POINTS = {
+    "gk_cfg4": (M.cfg4, [(3.0, 1.0, 2.0, 0.5), (1.0, 4.0, 0.5, 0.1), (6.0, 0.5, 5.0, 1.2)]),
+    "lv_cfg5": (M.cfg5, [(1.0, 0.02, 0.8), (0.4, 0.05, 1.5), (1.8, 0.01, 0.3)]),
+    "gauss2d_cfg3": (M.cfg3, [(1.2, -0.7), (0.0, 0.0), (-2.0, 3.0)]),
+    "gauss1_cfg2": (M.cfg2, [(1.6,), (0.0,), (-3.0,)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SIM_POINTS))
+def test_device_simulators_against_their_definitions(S, gpu, case):
+    """Every device-coded simulator (through the C-ABI operator sabc_op_simulate) against a NumPy simulation written from
+    the model's definition -- np.sort for the order statistics of the g-and-k model (the device sorts 128 values across a
+    wavefront), the Euler-Maruyama step as one writes it down, sample moments by their formulas: at a fixed theta the
+    distances must have the same distribution (two-sample Kolmogorov-Smirnov per statistic, 20 000 simulations each)."""
+    make, points = SIM_POINTS[case]
+    ref = make()
+    model, prior = hip_model_prior(S, case)
+    h = S.SabcHandle(n_particles=256, model=model, prior=prior, seed=SEED)
+    rng = np.random.default_rng(5)
+    m = 20_000
+    for theta in points:
+        th = np.tile(np.array(theta, dtype=float)[:, None], (1, m))
+        got = h.simulate(th, pid0=1000, it=7).T
+        want = ref["sim_pointwise" if "sim_pointwise" in ref else "sim"](np.tile(np.array(theta, dtype=float), (m, 1)), rng)
+        for j in range(got.shape[1]):
+            ks = stats.ks_2samp(got[:, j], want[:, j]).statistic
+            assert ks < 0.02, (case, theta, j, ks)                 # 5 % critical value at m = 20 000: 0.0136
+    h.close()
+
+
+@pytest.mark.parametrize("case,make,d,n_np", [("gk_cfg4", M.cfg4, 4, 100_000), ("lv_cfg5", M.cfg5, 3, 50_000)])
+def test_cfg4_cfg5_device_follows_the_independent_restatement(S, gpu, case, make, d, n_np):
+    """BASELINE configs[3] and [4] (g-and-k, Lotka-Volterra) through the whole loop at n = 1e6 against the NumPy restatement."""
+    marks = (20, 60)
+    dev = device_trajectory(S, case, "single_eps", "rw", d, marks, SEED)
+    ref = numpy_trajectory(make(), "single_eps", "rw", marks, seed=4, n=n_np)
+    for k, x, y in zip(marks, dev, ref):
+        assert abs(x["acc"] / y["acc"] - 1) < 0.015, (k, x["acc"], y["acc"])
+        assert abs(x["res"] - y["res"]) <= 1
+        assert abs(x["eps"][0] / y["eps"][0] - 1) < 0.05, (k, x["eps"], y["eps"])
+        np.testing.assert_allclose(x["ubar"], y["ubar"], rtol=0.04)
+        sx, sy = x["theta"].std(1), y["theta"].std(1)
+        np.testing.assert_allclose(sx, sy, rtol=0.03)
+        assert np.all(np.abs(x["theta"].mean(1) - y["theta"].mean(1)) < 0.04 * sy)

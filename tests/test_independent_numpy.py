@@ -104,6 +104,52 @@ def test_cfg3_sufficient_statistic_shortcut_is_the_same_distribution():
         assert stats.ks_2samp(a[:, j], b[:, j]).statistic < 0.012, j
 
 
+SIM_POINTS = {
+    "gk_cfg4": (M.cfg4, [(3.0, 1.0, 2.0, 0.5), (1.0, 4.0, 0.5, 0.1), (6.0, 0.5, 5.0, 1.2)]),
+    "lv_cfg5": (M.cfg5, [(1.0, 0.02, 0.8), (0.4, 0.05, 1.5), (1.8, 0.01, 0.3)]),
+    "gauss2d_cfg3": (M.cfg3, [(1.2, -0.7), (0.0, 0.0), (-2.0, 3.0)]),
+    "gauss1_cfg2": (M.cfg2, [(1.6,), (0.0,), (-3.0,)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SIM_POINTS))
+def test_oracle_simulators_against_their_definitions(O, case):
+    """Each simulator of the oracle (the device's are compared with it draw by draw) against a NumPy simulation written
+    from the model's definition in DESIGN.md -- order statistics by np.sort, the Euler-Maruyama step as one writes it
+    down, sample moments by their formulas: the distances at a fixed theta must have the same distribution (two-sample
+    Kolmogorov-Smirnov per statistic)."""
+    from scipy import stats
+    from tests.cases import oracle_config
+    make, points = SIM_POINTS[case]
+    model = make()
+    rng = np.random.default_rng(17)
+    m = 4000
+    cfg = oracle_config(O, case, 100, seed=99)
+    for theta in points:
+        got = np.array([O.simulate(cfg, np.array(theta, dtype=float), pid, 3) for pid in range(m)])
+        want = model["sim_pointwise" if "sim_pointwise" in model else "sim"](np.tile(np.array(theta, dtype=float), (m, 1)), rng)
+        for j in range(got.shape[1]):
+            ks = stats.ks_2samp(got[:, j], want[:, j]).statistic
+            assert ks < 0.045, (case, theta, j, ks)               # 5 % critical value at m = 4000: 0.030
+
+
+@pytest.mark.parametrize("case,make,d,marks", [("gk_cfg4", M.cfg4, 4, (20, 60)), ("lv_cfg5", M.cfg5, 3, (20, 60))])
+def test_cfg4_cfg5_trajectory_oracle_vs_independent_numpy(O, case, make, d, marks):
+    """The two heavy simulators through the whole loop (uniform box priors: proposals leave the support and are not
+    simulated, :314)."""
+    global N
+    a = oracle_trajectory(O, case, "single_eps", "rw", d, marks, seed=31)
+    b = numpy_trajectory(make(), "single_eps", "rw", marks, seed=32)
+    for k, x, y in zip(marks, a, b):
+        assert abs(x["acc"] / y["acc"] - 1) < 0.03, (k, x["acc"], y["acc"])
+        assert abs(x["res"] - y["res"]) <= 1
+        assert abs(x["eps"][0] / y["eps"][0] - 1) < 0.10, (k, x["eps"], y["eps"])
+        np.testing.assert_allclose(x["ubar"], y["ubar"], rtol=0.08)
+        sx, sy = x["theta"].std(1), y["theta"].std(1)
+        np.testing.assert_allclose(sx, sy, rtol=0.06)
+        assert np.all(np.abs(x["theta"].mean(1) - y["theta"].mean(1)) < 0.08 * sy)
+
+
 def test_operators_oracle_vs_independent_numpy(O):
     """ECDF (np.interp), both epsilon schedules (brentq): value-level agreement with the oracle's operators."""
     rng = np.random.default_rng(5)
