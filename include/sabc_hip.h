@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SABC_ABI_VERSION 2      /* 2: sabc_config gained prior_c / prior_d (Gamma, Beta, truncated Normal priors) */
+#define SABC_ABI_VERSION 3      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal) */
 #define SABC_MAX_PARA 8
 #define SABC_MAX_STATS 8
 #define SABC_MAX_MODEL_PARAMS 32
@@ -92,6 +92,10 @@ typedef struct {
                                      Gamma: scale theta | Beta: beta */
   double  prior_c[SABC_MAX_PARA]; /* truncated Normal: lower bound (others: unused) */
   double  prior_d[SABC_MAX_PARA]; /* truncated Normal: upper bound (others: unused) */
+  int32_t prior_joint;            /* 0: product of the univariate families above | 1: MvNormal(mu, Sigma) over all n_para
+                                     dimensions: mu = prior_a[0..d), Sigma = L L' with L = prior_chol */
+  int32_t reserved2;
+  double  prior_chol[SABC_MAX_PARA * SABC_MAX_PARA];   /* prior_joint = 1: lower Cholesky factor of Sigma, row-major d x d */
   int32_t algorithm;              /* SABC_ALG_* */
   int32_t rank;                   /* this process' shard (0 when world == 1) */
   int32_t world;                  /* number of shards (GPUs) */

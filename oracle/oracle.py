@@ -50,6 +50,9 @@ class Config(C.Structure):
         ("prior_b", C.c_double * MAX_PARA),
         ("prior_c", C.c_double * MAX_PARA),
         ("prior_d", C.c_double * MAX_PARA),
+        ("prior_joint", C.c_int32),
+        ("_pad2", C.c_int32),
+        ("prior_chol", C.c_double * (MAX_PARA * MAX_PARA)),
         ("algorithm", C.c_int32),
         ("_pad", C.c_int32),
         ("v", C.c_double),
@@ -166,7 +169,7 @@ def host_simulator(fn, d, s):
 
 
 def make_config(*, n_particles, n_para, n_stats, model_id, model_params, prior, algorithm=ALG_SINGLE_EPS,
-                v=1.0, delta=0.1, seed=20241220, host_fn=None) -> Config:
+                v=1.0, delta=0.1, seed=20241220, host_fn=None, prior_chol=None) -> Config:
     """prior: list of (kind, a, b) or (kind, a, b, c, d) per dimension."""
     cfg = Config()
     cfg.n_particles, cfg.n_para, cfg.n_stats = int(n_particles), int(n_para), int(n_stats)
@@ -179,6 +182,12 @@ def make_config(*, n_particles, n_para, n_stats, model_id, model_params, prior, 
         cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
         cfg.prior_c[k], cfg.prior_d[k] = float(c), float(d)
     cfg.algorithm, cfg.v, cfg.delta, cfg.seed = int(algorithm), float(v), float(delta), int(seed)
+    if prior_chol is not None:      # MvNormal(mu = the a's of `prior`, Sigma = L L'), L lower triangular d x d
+        L = np.asarray(prior_chol, dtype=np.float64).reshape(n_para, n_para)
+        cfg.prior_joint = 1
+        for k in range(n_para):
+            for l in range(n_para):
+                cfg.prior_chol[k * n_para + l] = float(L[k, l]) if l <= k else 0.0
     if host_fn is not None:
         cfg.host_fn = host_fn      # keep a reference to the CFUNCTYPE object alive in the caller
     return cfg

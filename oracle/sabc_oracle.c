@@ -194,6 +194,17 @@ static double gamma_sample(uint64_t seed, uint64_t pid, uint32_t base, double sh
 }
 
 void orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta) {
+  if (cfg->prior_joint) {               /* MvNormal(mu, L L'): mu + L z, z_k = first normal of block k (rand(MvNormal), :174) */
+    const int d = cfg->n_para;
+    double z[ORC_MAX_PARA];
+    for (int k = 0; k < d; ++k) { double zz[2]; orc_normal_pair(cfg->seed, pid, ORC_PURPOSE_PRIOR, 0, (uint32_t)k, zz); z[k] = zz[0]; }
+    for (int k = 0; k < d; ++k) {
+      double x = cfg->prior_a[k];
+      for (int l = 0; l <= k; ++l) x += cfg->prior_chol[k * d + l] * z[l];
+      theta[k] = x;
+    }
+    return;
+  }
   for (int k = 0; k < cfg->n_para; ++k) {
     const int kind = cfg->prior_kind[k];
     if (kind == ORC_PRIOR_GAMMA) { theta[k] = cfg->prior_b[k] * gamma_sample(cfg->seed, pid, (uint32_t)k, cfg->prior_a[k]); continue; }
@@ -225,6 +236,18 @@ void orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta) {
 }
 
 double orc_prior_logpdf(const orc_config *cfg, const double *theta) {
+  if (cfg->prior_joint) {               /* logpdf(MvNormal(mu, L L'), x) = -1/2 |L^-1 (x - mu)|^2 - d/2 log 2 pi - sum log L_kk */
+    const int d = cfg->n_para;
+    double y[ORC_MAX_PARA], q = 0.0, logdet = 0.0;
+    for (int k = 0; k < d; ++k) {
+      double r = theta[k] - cfg->prior_a[k];
+      for (int l = 0; l < k; ++l) r -= cfg->prior_chol[k * d + l] * y[l];
+      y[k] = r / cfg->prior_chol[k * d + k];
+      q += y[k] * y[k];
+      logdet += log(cfg->prior_chol[k * d + k]);
+    }
+    return -0.5 * q - (0.5 * d * ORC_LOG2PI + logdet);
+  }
   double lp = 0.0;
   for (int k = 0; k < cfg->n_para; ++k) {
     double x = theta[k];

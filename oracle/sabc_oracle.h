@@ -73,6 +73,9 @@ typedef struct {
   double  prior_b[ORC_MAX_PARA];  /* Normal: sigma | Uniform: upper | Gamma: scale | Beta: beta */
   double  prior_c[ORC_MAX_PARA];  /* truncated Normal: lower */
   double  prior_d[ORC_MAX_PARA];  /* truncated Normal: upper */
+  int32_t prior_joint;            /* 1: MvNormal(prior_a, L L') with L = prior_chol (row-major d x d lower) */
+  int32_t _pad2;
+  double  prior_chol[ORC_MAX_PARA * ORC_MAX_PARA];
   int32_t algorithm;
   int32_t _pad;
   double  v;                      /* used by initialization for eps_0 */

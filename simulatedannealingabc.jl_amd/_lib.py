@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
@@ -45,6 +45,7 @@ class Config(C.Structure):
         ("model_params", C.c_double * MAX_MODEL_PARAMS),
         ("prior_kind", C.c_int32 * MAX_PARA), ("prior_a", C.c_double * MAX_PARA), ("prior_b", C.c_double * MAX_PARA),
         ("prior_c", C.c_double * MAX_PARA), ("prior_d", C.c_double * MAX_PARA),
+        ("prior_joint", C.c_int32), ("reserved2", C.c_int32), ("prior_chol", C.c_double * (MAX_PARA * MAX_PARA)),
         ("algorithm", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("reserved", C.c_int32),
         ("v", C.c_double), ("delta", C.c_double), ("seed", C.c_uint64),
     ]

@@ -150,7 +150,10 @@ def as_host_distance(f_dist, prior, args=(), kwargs=None):
             _lib.PRIOR_EXPONENTIAL: lambda a, b, c, d: rng.exponential(a), _lib.PRIOR_LOGNORMAL: lambda a, b, c, d: rng.lognormal(a, b),
             _lib.PRIOR_GAMMA: lambda a, b, c, d: rng.gamma(a, b), _lib.PRIOR_BETA: lambda a, b, c, d: rng.beta(a, b),
             _lib.PRIOR_TRUNCNORMAL: truncnorm}
-    θ = np.array([draw[desc[0]](*(tuple(desc[1:]) + (0.0, 0.0))[:4]) for desc in prior.descriptors()])
+    if getattr(prior, "chol", None) is not None:          # MvNormal
+        θ = prior.μ + prior.chol @ rng.standard_normal(len(prior))
+    else:
+        θ = np.array([draw[desc[0]](*(tuple(desc[1:]) + (0.0, 0.0))[:4]) for desc in prior.descriptors()])
     probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
     hd = HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
                       univariate=prior.univariate, args=args, kwargs=kwargs)
@@ -246,7 +249,8 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
     if f_dist is not res._model or prior is not res._prior:
         if type(f_dist) is not type(res._model) or list(f_dist.params) != list(res._model.params) or \
-                prior.descriptors() != res._prior.descriptors():
+                prior.descriptors() != res._prior.descriptors() or \
+                not np.array_equal(np.asarray(getattr(prior, "chol", 0.0)), np.asarray(getattr(res._prior, "chol", 0.0))):
             raise ValueError("f_dist / prior differ from the ones this SABCresult was initialised with")
     h = res._handle
     if proposal is None:

@@ -92,8 +92,35 @@ __device__ __forceinline__ double prior_sample_dim(const ModelDesc &m, int k, ui
   return a + (b - a) * ua;
 }
 
+// MvNormal(mu, L L'): logpdf = -1/2 |L^-1 (x - mu)|^2 - (d/2 log 2 pi + sum log L_kk) by forward substitution;
+// rand = mu + L z with z_k the first normal of block k of the PRIOR stream (a diagonal L gives the product of Normals)
+__device__ __forceinline__ double mvnormal_logpdf(const ModelDesc &m, int d, const double *th) {
+  double y[kMaxPara], q = 0.0;
+  for (int k = 0; k < d; ++k) {
+    double r = th[k] - m.prior_a[k];
+    for (int l = 0; l < k; ++l) r -= m.prior_L[k * d + l] * y[l];
+    y[k] = r / m.prior_L[k * d + k];
+    q += y[k] * y[k];
+  }
+  return -0.5 * q - m.prior_joint_logc;
+}
+
+__device__ __forceinline__ void mvnormal_sample(const ModelDesc &m, int d, uint64_t pid, double *th) {
+  double z[kMaxPara];
+  for (int k = 0; k < d; ++k) {
+    double z1;
+    box_muller(stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k), z[k], z1);
+  }
+  for (int k = 0; k < d; ++k) {
+    double x = m.prior_a[k];
+    for (int l = 0; l <= k; ++l) x += m.prior_L[k * d + l] * z[l];
+    th[k] = x;
+  }
+}
+
 template <int D>
 __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double *th) {
+  if (D > 1 && m.prior_joint) return mvnormal_logpdf(m, D, th);
   double lp = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -106,6 +133,7 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
 // rand(prior) at :174
 template <int D>
 __device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
+  if (D > 1 && m.prior_joint) { mvnormal_sample(m, D, pid, th); return; }
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = prior_sample_dim(m, k, pid);
 }

@@ -41,6 +41,15 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
       m_.prior_logc[k] = scale > 0 ? std::log(scale) : 0.0;
     }
   }
+  m_.prior_joint = cfg.prior_joint;
+  m_.prior_joint_logc = 0.5 * (double)cfg.n_para * 1.8378770664093454835606594728112;   // d/2 log(2 pi)
+  for (int i = 0; i < kMaxPara * kMaxPara; ++i) m_.prior_L[i] = 0.0;
+  if (cfg.prior_joint == 1 && cfg.n_para >= 1 && cfg.n_para <= kMaxPara)
+    for (int k = 0; k < cfg.n_para; ++k) {
+      for (int l = 0; l <= k; ++l) m_.prior_L[k * cfg.n_para + l] = cfg.prior_chol[k * cfg.n_para + l];
+      const double lkk = cfg.prior_chol[k * cfg.n_para + k];
+      m_.prior_joint_logc += lkk > 0 ? std::log(lkk) : 0.0;
+    }
   m_.seed = cfg.seed;
   const int world = cfg.world < 1 ? 1 : cfg.world;
   sh_ = make_shard(cfg.n_particles, cfg.rank, world);
@@ -84,7 +93,12 @@ int Engine::validate() {
       ok = false;
   }
   if (!ok) return fail(SABC_ERR_BAD_CONFIG, "unknown model id or model parameters inconsistent with n_para / n_stats");
-  for (int k = 0; k < d; ++k) {
+  if (cfg_.prior_joint != 0 && cfg_.prior_joint != 1) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
+  if (cfg_.prior_joint == 1) {
+    for (int k = 0; k < d; ++k)
+      if (!(cfg_.prior_chol[k * d + k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "MvNormal prior needs a Cholesky factor with a positive diagonal");
+  }
+  for (int k = 0; k < d && cfg_.prior_joint == 0; ++k) {
     if (cfg_.prior_kind[k] == SABC_PRIOR_NORMAL) {
       if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Normal prior needs sigma > 0");
     } else if (cfg_.prior_kind[k] == SABC_PRIOR_UNIFORM) {

@@ -277,6 +277,7 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
 // maxima); these kernels are host-bound by construction, so they are written for generality.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
+  if (m.prior_joint) return mvnormal_logpdf(m, m.d, th);
   double lp = 0.0;
   for (int k = 0; k < m.d; ++k) {
     const double l = prior_logpdf_dim(m, k, th[k]);
@@ -291,6 +292,12 @@ __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const 
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= pp.n_local) return;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
+  if (m.prior_joint) {
+    double th[kMaxPara];
+    mvnormal_sample(m, m.d, gid, th);
+    for (int k = 0; k < m.d; ++k) pp.pop[(int64_t)k * pp.cap + li] = th[k];
+    return;
+  }
   for (int k = 0; k < m.d; ++k)
     pp.pop[(int64_t)k * pp.cap + li] = prior_sample_dim(m, k, gid);
 }
@@ -1058,7 +1065,10 @@ k_prior_op(const ModelDesc m, const uint64_t pid0, const int64_t n, double *__re
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double th[kMaxPara];
-  for (int k = 0; k < m.d; ++k) { th[k] = prior_sample_dim(m, k, pid0 + (uint64_t)i); theta[(int64_t)k * n + i] = th[k]; }
+  if (m.prior_joint) mvnormal_sample(m, m.d, pid0 + (uint64_t)i, th);
+  else
+    for (int k = 0; k < m.d; ++k) th[k] = prior_sample_dim(m, k, pid0 + (uint64_t)i);
+  for (int k = 0; k < m.d; ++k) theta[(int64_t)k * n + i] = th[k];
   lp[i] = prior_logpdf_rt(m, th);
 }
 

@@ -19,6 +19,10 @@ struct ModelDesc {
   // | log B(alpha, beta) | log sigma + log(Phi(hi') - Phi(lo'))
   double prior_logc[kMaxPara];
   double prior_k0[kMaxPara], prior_k1[kMaxPara];   // truncated Normal: Phi(lo'), Phi(hi') - Phi(lo') of the standardised bounds
+  // prior_joint = 1: MvNormal(prior_a, L L'), L row-major d x d lower; logc = d/2 log(2 pi) + sum log L_kk
+  int32_t prior_joint, prior_pad;
+  double prior_L[kMaxPara * kMaxPara];
+  double prior_joint_logc;
   uint64_t seed;
 };
 

@@ -172,5 +172,30 @@ class Product(Distribution):
         return "Product(" + ", ".join(map(repr, self.components)) + ")"
 
 
+class MvNormal(Distribution):
+    """MvNormal(μ, Σ) of Distributions.jl: a joint Gaussian prior over all parameters (Σ symmetric positive definite)."""
+
+    def __init__(self, μ, Σ):
+        import numpy as np
+        self.μ = np.atleast_1d(np.asarray(μ, dtype=np.float64))
+        self.Σ = np.atleast_2d(np.asarray(Σ, dtype=np.float64))
+        d = len(self.μ)
+        if self.Σ.shape != (d, d) or not np.allclose(self.Σ, self.Σ.T):
+            raise ValueError("MvNormal: Σ must be a symmetric d × d matrix")
+        if d > _lib.MAX_PARA:
+            raise ValueError(f"at most {_lib.MAX_PARA} parameters are supported")
+        try:
+            self.chol = np.linalg.cholesky(self.Σ)
+        except np.linalg.LinAlgError as e:
+            raise ValueError("MvNormal: Σ must be positive definite") from e
+
+    def descriptors(self):
+        # per dimension (Normal, μ_k, marginal σ_k): the library reads μ from here and Σ's factor from `chol`
+        return [(_lib.PRIOR_NORMAL, float(m), float(self.Σ[k, k]) ** 0.5) for k, m in enumerate(self.μ)]
+
+    def __repr__(self):
+        return f"MvNormal(μ={self.μ.tolist()}, Σ={self.Σ.tolist()})"
+
+
 def product_distribution(components):
     return Product(components)

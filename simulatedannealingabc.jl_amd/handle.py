@@ -33,6 +33,13 @@ class SabcHandle:
             kind, a, b, c, d = (tuple(desc) + (0.0, 0.0))[:5]
             cfg.prior_kind[k], cfg.prior_a[k], cfg.prior_b[k] = int(kind), float(a), float(b)
             cfg.prior_c[k], cfg.prior_d[k] = float(c), float(d)
+        L = getattr(prior, "chol", None)          # MvNormal: lower Cholesky factor of Sigma
+        if L is not None:
+            d = len(prior)
+            cfg.prior_joint = 1
+            for k in range(d):
+                for l in range(k + 1):
+                    cfg.prior_chol[k * d + l] = float(L[k, l])
         cfg.algorithm = int(algorithm)
         cfg.rank, cfg.world = int(rank), int(world)
         cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)

@@ -12,7 +12,8 @@
 # argument list against the prototypes of include/sabc_hip.h, and the enum values used below.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, UnivariateDistribution
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, MvNormal, UnivariateDistribution
+using LinearAlgebra: cholesky, Symmetric
 using ProgressMeter: Progress, next!, finish!          # same progress UI as the reference (:290-292,374)
 import Dates
 import Base: show
@@ -23,6 +24,7 @@ export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
 const libsabc = get(ENV, "SABC_HIP_LIB", joinpath(@__DIR__, "..", "libsabc_hip.so"))
 
 const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
+const MAX_PARA2 = MAX_PARA * MAX_PARA      # the row-major Cholesky factor of an MvNormal prior
 
 # ---- C structs (must match include/sabc_hip.h field for field) ----
 struct CConfig
@@ -39,6 +41,9 @@ struct CConfig
     prior_b::NTuple{MAX_PARA,Float64}
     prior_c::NTuple{MAX_PARA,Float64}
     prior_d::NTuple{MAX_PARA,Float64}
+    prior_joint::Int32
+    reserved2::Int32
+    prior_chol::NTuple{MAX_PARA2,Float64}
     algorithm::Int32
     rank::Int32
     world::Int32
@@ -161,11 +166,19 @@ prior_descriptor(d::Gamma) = (Int32(4), d.α, d.θ, 0.0, 0.0)
 prior_descriptor(d::Beta) = (Int32(5), d.α, d.β, 0.0, 0.0)
 prior_descriptor(d::Truncated{<:Normal}) = (Int32(6), d.untruncated.μ, d.untruncated.σ, Float64(d.lower), Float64(d.upper))
 prior_descriptors(d::UnivariateDistribution) = [prior_descriptor(d)]
+# MvNormal(mu, Sigma): mu travels in the per-dimension descriptors, the lower Cholesky factor of Sigma in prior_chol
+prior_descriptors(d::MvNormal) = [(Int32(0), d.μ[k], sqrt(d.Σ[k, k]), 0.0, 0.0) for k in 1:length(d)]
+prior_chol(d::Distribution) = (Int32(0), Float64[])
+function prior_chol(d::MvNormal)
+    n = length(d)
+    L = cholesky(Symmetric(Matrix(d.Σ))).L
+    (Int32(1), Float64[l <= k ? L[k, l] : 0.0 for k in 1:n for l in 1:n])        # row-major n x n
+end
 # product_distribution([...]): Distributions.jl names the vector of marginals `v` (Product, <= 0.25.x) or `dists`
 # (ProductDistribution); neither has an exported accessor, so both spellings are accepted and anything else is refused
 function prior_descriptors(d::Distribution)
     comps = hasproperty(d, :v) ? getproperty(d, :v) : hasproperty(d, :dists) ? getproperty(d, :dists) :
-            error("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal) or product_distribution([...]) of those")
+            error("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal), product_distribution([...]) of those, or MvNormal")
     [prior_descriptor(c) for c in comps]
 end
 
@@ -220,12 +233,14 @@ end
 function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v, δ, seed, device=0, rank=0, world=1,
                        comm_id=nothing)
     pd = prior_descriptors(prior)
+    joint, chol = prior_chol(prior)
     p = params(f_dist)
-    cfg = Ref(CConfig(2, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
+    cfg = Ref(CConfig(3, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
                       padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(getindex.(pd, 3), MAX_PARA, Float64),
                       padtuple(getindex.(pd, 4), MAX_PARA, Float64), padtuple(getindex.(pd, 5), MAX_PARA, Float64),
+                      joint, Int32(0), padtuple(chol, MAX_PARA2, Float64),
                       algorithm == :multi_eps ? 1 : 0, rank, world, 0, v, δ, seed))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sabc_create, libsabc), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))

@@ -36,6 +36,9 @@ MODELS = {
                             prior=[("N", 0.0, 1.0), ("G", 2.0, 0.5)], s=2),
     "gauss2_truncnormal_beta": dict(model=("GaussianIID", dict(n_obs=40, sd=1.0, obs_mean=0.4)),
                                     prior=[("T", 0.0, 1.0, -0.5, 1.5), ("B", 2.0, 2.5)], s=1),
+    # joint Gaussian prior (MvNormal(mu, Sigma)): correlated mean components of the 2-D model; 3 dimensions over LV's rates
+    "gauss2d_mvnormal": dict(model=("Gaussian2D", dict(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)),
+                             prior=[("N", 0.5, 2.0), ("N", -0.5, 1.5)], cov=[[4.0, -1.8], [-1.8, 2.25]], s=3),
     # BASELINE config 3
     "gauss2d_cfg3": dict(model=("Gaussian2D", dict(n_obs=50, r=0.6, obs_mean=(1.2, -0.7), obs_varsum=2.1, obs_cov=0.55)),
                          prior=[("N", 0.0, 3.0), ("N", 0.0, 3.0)], s=3),
@@ -74,8 +77,9 @@ def oracle_config(O, name, n, algorithm="single_eps", seed=SEED, v=1.0, delta=0.
              "B": O.PRIOR_BETA, "T": O.PRIOR_TRUNCNORMAL}
     prior = [(kinds[p[0]],) + tuple(p[1:]) for p in spec["prior"]]
     alg = O.ALG_MULTI_EPS if algorithm == "multi_eps" else O.ALG_SINGLE_EPS
+    chol = np.linalg.cholesky(np.asarray(spec["cov"], dtype=np.float64)) if "cov" in spec else None
     return O.make_config(n_particles=n, n_para=len(prior), n_stats=spec["s"], model_id=mid, model_params=params,
-                         prior=prior, algorithm=alg, v=v, delta=delta, seed=seed)
+                         prior=prior, algorithm=alg, v=v, delta=delta, seed=seed, prior_chol=chol)
 
 
 def oracle_proposal(O, prop, d):
@@ -102,6 +106,8 @@ def hip_model_prior(S, name):
     make = {"N": lambda a, b: S.Normal(a, b), "U": lambda a, b: S.Uniform(a, b), "E": lambda a, b: S.Exponential(a),
             "L": lambda a, b: S.LogNormal(a, b), "G": lambda a, b: S.Gamma(a, b), "B": lambda a, b: S.Beta(a, b),
             "T": lambda a, b, lo, hi: S.truncated(S.Normal(a, b), lo, hi)}
+    if "cov" in spec:
+        return model, S.MvNormal([p[1] for p in spec["prior"]], spec["cov"])
     comps = [make[p[0]](*p[1:]) for p in spec["prior"]]
     prior = comps[0] if len(comps) == 1 else S.product_distribution(comps)
     return model, prior

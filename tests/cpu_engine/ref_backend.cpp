@@ -39,6 +39,9 @@ class RefBackend : public Backend {
     for (int i = 0; i < ORC_MAX_MODEL_PARAMS; ++i) oc_.model_params[i] = m.p[i];
     for (int k = 0; k < ORC_MAX_PARA; ++k) { oc_.prior_kind[k] = m.prior_kind[k]; oc_.prior_a[k] = m.prior_a[k]; oc_.prior_b[k] = m.prior_b[k];
                                              oc_.prior_c[k] = m.prior_c[k]; oc_.prior_d[k] = m.prior_d[k]; }
+    oc_.prior_joint = m.prior_joint;
+    for (int k = 0; k < m.d; ++k)
+      for (int l = 0; l < m.d; ++l) oc_.prior_chol[k * m.d + l] = m.prior_L[k * m.d + l];
     oc_.seed = m.seed;
     return 0;
   }

@@ -26,7 +26,9 @@ def jl_source():
 
 def jl_consts(src):
     m = re.search(r"const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = (\d+), (\d+), (\d+)", src)
-    return dict(MAX_PARA=int(m.group(1)), MAX_STATS=int(m.group(2)), MAX_MODEL_PARAMS=int(m.group(3)))
+    assert re.search(r"const MAX_PARA2 = MAX_PARA \* MAX_PARA\b", src)
+    return dict(MAX_PARA=int(m.group(1)), MAX_STATS=int(m.group(2)), MAX_MODEL_PARAMS=int(m.group(3)),
+                MAX_PARA2=int(m.group(1)) ** 2)
 
 
 def jl_struct_layout(src, name):

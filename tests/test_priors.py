@@ -76,8 +76,70 @@ def test_device_prior_against_scipy_and_oracle(S, O, gpu, name):
     np.testing.assert_allclose(x[:4000], ref, rtol=1e-9, atol=1e-300)
 
 
+MU3 = np.array([0.5, -1.0, 2.0])
+A3 = np.array([[1.5, 0.0, 0.0], [-0.7, 0.9, 0.0], [0.3, 0.4, 0.5]])
+SIGMA3 = A3 @ A3.T
+
+
+def mv_oracle_cfg(O, mu, sigma):
+    d = len(mu)
+    return O.make_config(n_particles=100, n_para=d, n_stats=1, model_id=O.MODEL_GAUSS_IID, model_params=[10, 1.0, 0.0, 0.0],
+                         prior=[(O.PRIOR_NORMAL, float(mu[k]), float(np.sqrt(sigma[k, k]))) for k in range(d)], seed=SEED,
+                         prior_chol=np.linalg.cholesky(sigma))
+
+
+def check_mvnormal_draws(x, lp, mu, sigma):
+    """x: d x M draws, lp their log densities: scipy's multivariate_normal for the density, the whitened draws
+    L^-1 (x - mu) against N(0, 1) per coordinate and their cross moments for the sampler."""
+    dist = stats.multivariate_normal(mu, sigma)
+    np.testing.assert_allclose(lp, dist.logpdf(x.T), rtol=1e-11, atol=1e-11)
+    z = np.linalg.solve(np.linalg.cholesky(sigma), x - mu[:, None])
+    for k in range(len(mu)):
+        assert stats.kstest(z[k], stats.norm.cdf).pvalue > 1e-3
+    m = x.shape[1]
+    np.testing.assert_allclose(np.cov(x), sigma, atol=6 * np.abs(sigma).max() * np.sqrt(2.0 / m))
+    np.testing.assert_allclose(x.mean(axis=1), mu, atol=5 * np.sqrt(np.diag(sigma) / m).max())
+
+
+def test_oracle_mvnormal_against_scipy(O):
+    cfg = mv_oracle_cfg(O, MU3, SIGMA3)
+    x = np.array([O.prior_sample(cfg, pid) for pid in range(M)]).T
+    lp = np.array([O.prior_logpdf(cfg, x[:, i]) for i in range(M)])
+    check_mvnormal_draws(x, lp, MU3, SIGMA3)
+    # a diagonal Sigma is the product of Normals, draw for draw
+    diag = np.diag([1.3 ** 2, 0.4 ** 2, 2.0 ** 2])
+    cj = mv_oracle_cfg(O, MU3, diag)
+    cp = O.make_config(n_particles=100, n_para=3, n_stats=1, model_id=O.MODEL_GAUSS_IID, model_params=[10, 1.0, 0.0, 0.0],
+                       prior=[(O.PRIOR_NORMAL, MU3[0], 1.3), (O.PRIOR_NORMAL, MU3[1], 0.4), (O.PRIOR_NORMAL, MU3[2], 2.0)], seed=SEED)
+    for pid in range(200):
+        a, b = O.prior_sample(cj, pid), O.prior_sample(cp, pid)
+        np.testing.assert_allclose(a, b, rtol=1e-15)
+        assert O.prior_logpdf(cj, a) == pytest.approx(O.prior_logpdf(cp, b), rel=1e-13)
+
+
+def test_mvnormal_rejects_bad_covariances(S):
+    with pytest.raises(ValueError):
+        S.MvNormal([0.0, 0.0], [[1.0, 2.0], [2.0, 1.0]])          # not positive definite
+    with pytest.raises(ValueError):
+        S.MvNormal([0.0, 0.0], [[1.0, 0.5], [0.1, 1.0]])          # not symmetric
+    with pytest.raises(ValueError):
+        S.MvNormal([0.0, 0.0, 0.0], [[1.0, 0.0], [0.0, 1.0]])     # wrong shape
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,alg,prop", [("gauss2_gamma_sd", "single_eps", "rw"), ("gauss2_truncnormal_beta", "multi_eps", "de")])
+def test_device_mvnormal_against_scipy_and_oracle(S, O, gpu):
+    h = S.SabcHandle(n_particles=256, model=S.LotkaVolterra(n_steps=8), prior=S.MvNormal(MU3, SIGMA3), seed=SEED)
+    th, lp = h.prior(0, M)
+    h.close()
+    check_mvnormal_draws(th, lp, MU3, SIGMA3)
+    cfg = mv_oracle_cfg(O, MU3, SIGMA3)
+    ref = np.array([O.prior_sample(cfg, pid) for pid in range(4000)]).T
+    np.testing.assert_allclose(th[:, :4000], ref, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,alg,prop", [("gauss2_gamma_sd", "single_eps", "rw"), ("gauss2_truncnormal_beta", "multi_eps", "de"),
+                                           ("gauss2d_mvnormal", "multi_eps", "rw"), ("gauss2d_mvnormal", "single_eps", "stretch")])
 def test_trajectory_parity_with_the_new_priors(S, O, gpu, case, alg, prop):
     from tests.cases import MODELS, hip_model_prior, hip_proposal, oracle_run
     n, k = 3000, 8
@@ -88,6 +150,6 @@ def test_trajectory_parity_with_the_new_priors(S, O, gpu, case, alg, prop):
     run = oracle_run(O, case, n, (k + 1) * n, alg, prop, resample=n // 2)
     c = run.counters
     assert (res.state.n_accept, res.state.n_resampling) == (c["n_accept"], c["n_resampling"])
-    tol = {"rw": 1e-9, "de": 1e-6}[prop]
+    tol = {"rw": 1e-9, "de": 1e-6, "stretch": 1e-6}[prop]
     np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol * 1e-2)
     np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
