@@ -178,8 +178,10 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
     ap.add_argument("--cpu-updates", type=int, default=100, help="population updates of the CPU baseline sample (~15 s on 16 cores)")
     ap.add_argument("--allow-hooks", action="store_true",
-                    help="with --dist-backend nccl: keep going when RCCL could not be bound inside the library and the "
-                         "collectives fell back to the torch.distributed hooks (default: exit non-zero)")
+                    help="accepted for round-1 command lines; falling back to hooks-nccl no longer stops the run (see --strict-transport)")
+    ap.add_argument("--strict-transport", action="store_true",
+                    help="exit 3 also when RCCL could not be bound inside the library and the collectives fell back to "
+                         "torch.distributed's RCCL on device pointers ('hooks-nccl': same wires, Python in the per-update path)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="--gpus N > 1 without a launcher: deadline for the ranks (s)")
     args = ap.parse_args()
 
@@ -238,14 +240,19 @@ def main():
     if world > 1:
         from sabc_amd.dist import install_collectives
         transport = install_collectives(h, device)
-        if args.dist_backend == "nccl" and transport != "rccl" and not args.allow_hooks:
-            # every rank takes the same branch (install_collectives agrees on the transport across ranks)
+        # every rank takes the same branch (install_collectives agrees on the transport across ranks)
+        # (--dist-backend gloo is an explicit request for the host-staged rehearsal transport and says so in the line)
+        degraded = args.dist_backend == "nccl" and transport != "rccl"
+        if degraded and args.strict_transport:
             print(f"[bench] rank {rank}: RCCL could not be bound inside the library, the collectives fell back to "
-                  f"'{transport}' (Python in the per-update path): not measuring that silently; --allow-hooks overrides",
-                  file=sys.stderr, flush=True)
+                  f"'{transport}': --strict-transport refuses to measure that", file=sys.stderr, flush=True)
             h.close()
             dist.destroy_process_group()
             raise SystemExit(3)
+        if degraded:
+            print(f"[bench] WARNING rank {rank}: RCCL could not be bound inside the library; measuring over '{transport}' "
+                  "(torch.distributed on device pointers, a Python callback per collective): the line says so in "
+                  "config.collectives and transport_degraded", file=sys.stderr, flush=True)
     t_init0 = time.perf_counter()
     h.initialize(n)
     torch.cuda.synchronize()
@@ -323,6 +330,9 @@ def main():
                 "n_particles": n, "proposal": args.proposal, "algorithm": args.algorithm,
                 "particles_per_gpu": h.n_local, "seed": SEED, "collectives": transport,
             },
+            # True: the library's own RCCL binding failed and torch.distributed's RCCL carried the collectives (device
+            # pointers, same wires, one Python callback per collective) -- a measured but pessimistic number
+            "transport_degraded": bool(world > 1 and args.dist_backend == "nccl" and transport != "rccl"),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
