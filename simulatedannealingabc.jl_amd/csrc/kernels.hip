@@ -810,56 +810,97 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
 // the address of its packed row.  Same decisions as resample_search on the same numbers: if no running sum of the chunk
 // exceeds t (rounding of the offsets against the sums) the next chunk's first particle is taken, the last particle at the
 // end of the population.
+// Every level is ONE round trip: the 16 doubles of a 128-byte line are fetched by eight independent 16-byte loads and the
+// position is the COUNT of entries that do not exceed t (the running sums are non-decreasing, so the count is the
+// binary search's answer); a dependent chain of ~11 divergent loads per draw became 3 (the kernel is bound by that
+// chain's latency, not by bytes or issue).  L receives the packed line of the drawn particle, `slot` its slot.
+__device__ __forceinline__ void load_line(const double *__restrict__ p, double (&L)[16]) {
+  const double2 *q = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const double2 v = q[k]; L[2 * k] = v.x; L[2 * k + 1] = v.y; }
+}
+
+template <int PG>
 __device__ __forceinline__ int64_t packed_search(const double t, const double *B, const int64_t nb, const double *__restrict__ gc,
-                                                 const double *__restrict__ ge, const double *__restrict__ pk, const int pg,
-                                                 const int64_t n, const double *&row) {
+                                                 const double *__restrict__ ge, const double *__restrict__ pk,
+                                                 const int64_t n, double (&L)[16], int &slot) {
+  constexpr int kStride = 16 / PG;
+  constexpr int64_t kLinesPerChunk = kScanChunk / PG;
+  constexpr int kGroupsOfChunk = (int)(kLinesPerChunk / 16);      // 16, 32 or 64 entries of gc per chunk
   int64_t blo = 0, bhi = nb;
   while (blo < bhi) {
     const int64_t mid = blo + ((bhi - blo) >> 1);
     if (B[mid] > t) bhi = mid; else blo = mid + 1;
   }
   const int64_t chunk = blo - 1;
-  const int64_t lines_per_chunk = kScanChunk / pg;
-  const int64_t n_lines = (n + pg - 1) / pg;
-  const int64_t l0 = chunk * lines_per_chunk;
-  int64_t end = l0 + lines_per_chunk;
+  const int64_t n_lines = (n + PG - 1) / PG;
+  const int64_t l0 = chunk * kLinesPerChunk;
+  int64_t end = l0 + kLinesPerChunk;
   if (end > n_lines) end = n_lines;
   // coarse: first 16-line group of the chunk whose end exceeds t (the chunk's last group may be partial: its end is the
-  // population's last particle)
-  int64_t glo = l0 >> 4, ghi = (end + 15) >> 4;
-  const int64_t gend = ghi;
-  while (glo < ghi) {
-    const int64_t mid = glo + ((ghi - glo) >> 1);
-    if (gc[mid] > t) ghi = mid; else glo = mid + 1;
+  // population's last particle).  More than 16 groups per chunk: halve by the last entry of the lower half first.
+  const int64_t gend = (end + 15) >> 4;
+  int64_t gbase = l0 >> 4;
+  int nwin = kGroupsOfChunk / 16;
+  while (nwin > 1) {
+    const int half = nwin >> 1;
+    const int64_t probe = gbase + 16 * half - 1;
+    if (probe < gend && !(gc[probe] > t)) { gbase += 16 * half; nwin -= half; } else nwin = half;
   }
+  load_line(gc + gbase, L);
+  int cnt = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) cnt += (gbase + q < gend && !(L[q] > t)) ? 1 : 0;
+  const int64_t glo = gbase + cnt;
   int64_t idx;
   if (glo < gend) {
-    int64_t lo = glo << 4, hi = lo + 16;
+    const int64_t lo = glo << 4;
+    int64_t hi = lo + 16;
     if (hi > end) hi = end;
-    while (lo < hi - 1) {                  // the group's end exceeds t, so its last line needs no test
-      const int64_t mid = lo + ((hi - 1 - lo) >> 1);
-      if (ge[mid] > t) hi = mid + 1; else lo = mid + 1;
-    }
-    const int stride = 16 / pg;
-    const double *L = pk + lo * 16;
-    int slot = 0;
-    while (slot < pg - 1 && !(L[slot * stride] > t)) ++slot;       // likewise the line's last slot
-    idx = lo * pg + slot;
-    if (idx >= n) idx = n - 1;
+    load_line(ge + lo, L);
+    int lc = 0;
+#pragma unroll
+    for (int q = 0; q < 15; ++q) lc += (lo + q < hi - 1 && !(L[q] > t)) ? 1 : 0;   // the group's end exceeds t: its last line needs no test
+    const int64_t line = lo + lc;
+    load_line(pk + line * 16, L);
+    slot = 0;
+#pragma unroll
+    for (int q = 0; q < PG - 1; ++q) slot += !(L[q * kStride] > t) ? 1 : 0;          // likewise the line's last slot
+    idx = line * PG + slot;
+    if (idx >= n) { idx = n - 1; slot = (int)(idx - line * PG); }                     // (the last line; its empty slots hold +inf)
   } else {
     idx = (chunk + 1) * (int64_t)kScanChunk;
     if (idx >= n) idx = n - 1;
+    const int64_t line = idx / PG;
+    slot = (int)(idx - line * PG);
+    load_line(pk + line * 16, L);
   }
-  const int64_t line = idx / pg;
-  row = pk + line * 16 + (idx - line * pg) * (16 / pg) + 1;
   return idx;
+}
+
+// value `k` of the row in slot `slot` of the packed line L (k and PG at compile time: a select chain, no indexed registers)
+template <int PG>
+__device__ __forceinline__ double line_value(const double (&L)[16], const int slot, const int k) {
+  constexpr int kStride = 16 / PG;
+  double v = L[1 + k];
+#pragma unroll
+  for (int q = 1; q < PG; ++q) {
+    int hit = slot == q;
+    asm volatile("" : "+v"(hit));     // opaque: related conditions would be folded into an INDEXED read of a scratch copy of L
+    v = hit ? L[q * kStride + 1 + k] : v;
+  }
+  return v;
+}
+
+constexpr int packed_per_line(int row_len) {
+  return 16 / (1 + row_len) >= 4 ? 4 : 16 / (1 + row_len) >= 2 ? 2 : 1;
 }
 
 // One shard, packed: the draw and its (theta, u) row come from one line, and -- with D, S known at compile time -- the
 // moment sums of the RESAMPLED population (what k_stats would compute in a pass of its own: Sigma, eps and the history
 // row are taken from the resampled population, :348-353) come out of the same kernel, in the same per-workgroup order.
 template <int D, int S>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, 4)     // up to 128 VGPRs: a 16-double line is live across the search
 k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, const double *__restrict__ ge,
                         const double *__restrict__ gc, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
                         const uint64_t iter, const PopPtrs dst, const ControlBlock *__restrict__ cb,
@@ -880,14 +921,16 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
     const uint64_t gid = (uint64_t)(dst.gid0 + li);
     const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
     const double t = u52(w.x, w.y) * totals[0];
-    const double *row;
-    (void)packed_search(t, B, nb, gc, ge, pk, pg, n, row);
+    constexpr int PG = packed_per_line(D + S);
+    double L[16];
+    int slot;
+    (void)packed_search<PG>(t, B, nb, gc, ge, pk, n, L, slot);
     double th[D], u[S], rho[S];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = row[k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
+    for (int k = 0; k < D; ++k) { th[k] = line_value<PG>(L, slot, k); dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      u[j] = row[D + j];
+      u[j] = line_value<PG>(L, slot, D + j);
       dst.pop[(int64_t)(D + j) * dst.cap + li] = u[j];
       rho[j] = dst.rho[(int64_t)j * dst.cap + li];                        // rho stays where it is (:131-132)
     }
@@ -911,8 +954,14 @@ k_resample_gather_packed(const uint64_t seed, const int row_len, const double *_
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= dst.n_local) return;
   const u32x4 w = stream_block(seed, (uint64_t)(dst.gid0 + li), PURPOSE_RESAMPLE, iter, 0);
-  const double *row;
-  (void)packed_search(u52(w.x, w.y) * totals[0], B, nb, gc, ge, pk, pg, n, row);
+  const double t = u52(w.x, w.y) * totals[0];
+  double L[16];
+  int slot;
+  const int64_t idx = pg == 4 ? packed_search<4>(t, B, nb, gc, ge, pk, n, L, slot)
+                    : pg == 2 ? packed_search<2>(t, B, nb, gc, ge, pk, n, L, slot)
+                              : packed_search<1>(t, B, nb, gc, ge, pk, n, L, slot);
+  const int64_t line = idx / pg;
+  const double *row = pk + line * 16 + (idx - line * pg) * (16 / pg) + 1;      // the line just fetched: L1 hits
   for (int r = 0; r < row_len; ++r) dst.pop[(int64_t)r * dst.cap + li] = row[r];
 }
 
@@ -1173,7 +1222,7 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   if (act_n <= 0) return 0;
   return m.model_id == SABC_MODEL_GK ? (int64_t)gk_update_blocks(act_n)   // 256 particles per workgroup (wave per particle, 4 groups of 16 per wave)
-                                     : n_blocks(act_n);                   // 256 particles per workgroup
+                                     : (act_n + kUpdateBlock - 1) / kUpdateBlock;   // one thread per particle
 }
 
 // ev0 / ev1 (optional): timing events attached to the dispatch packet itself (hipExtLaunchKernel), so that
@@ -1188,11 +1237,11 @@ int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream, hipEvent_t ev0,
                   hipEvent_t ev1, const RtcKernels *rtc) {
   if (act_n <= 0) return 0;
-  const dim3 grid((unsigned)update_rows(m, act_n)), block(kBlock);
+  const dim3 grid((unsigned)update_rows(m, act_n)), block(m.model_id == SABC_MODEL_GK ? kBlock : kUpdateBlock);
   double *out = partials + row0 * n_partials(m.d, m.s);
   if (m.model_id == SABC_MODEL_USER) {
     if (!rtc || c.prop_kind < 0 || c.prop_kind > 2 || !rtc->update[c.prop_kind]) return (int)hipErrorInvalidValue;
-    return module_launch(rtc->update[c.prop_kind], grid.x, kBlock, stream, ev0, ev1, m, c, cb, pp, cdf, pv, act_lo, act_n, out);
+    return module_launch(rtc->update[c.prop_kind], grid.x, kUpdateBlock, stream, ev0, ev1, m, c, cb, pp, cdf, pv, act_lo, act_n, out);
   }
   if (m.model_id == SABC_MODEL_GK) {
     const dim3 g((unsigned)update_rows(m, act_n));
@@ -1308,12 +1357,16 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
 }
 
 // doubles of the packed-line scratch of launch_resample_local for a shard of n particles: lines of 16 doubles + line ends
+static inline int64_t pack_ge_doubles(int64_t lines) { return ((lines + 8 + 15) / 16) * 16; }
+
 int64_t resample_pack_doubles(int row_len, int64_t n) {
   const int per = 16 / (1 + row_len);
   const int pg = per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;
   if (pg == 0) return 0;
   const int64_t lines = (n + pg - 1) / pg;
-  return lines * 16 + lines + (lines + 15) / 16 + 32;
+  const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
+  // packed lines | line ends (a multiple of 16, so that gc starts a line) | coarse ends: whole 16-entry windows are read
+  return lines * 16 + pack_ge_doubles(lines) + nb * (kScanChunk / pg / 16) + 32;
 }
 
 // One shard: weights (fused into the first scan pass), scan, staging copy, draw + gather (+ the moment sums of the
@@ -1337,7 +1390,7 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
   std::memset(&pa, 0, sizeof(pa));
   if (pg > 0 && pack) {
     const int64_t lines = (n + pg - 1) / pg;
-    pa.pk = pack; pa.ge = pack + lines * 16; pa.gc = pa.ge + lines + 8; pa.row_len = rl; pa.pg = pg;
+    pa.pk = pack; pa.ge = pack + lines * 16; pa.gc = pa.ge + pack_ge_doubles(lines); pa.row_len = rl; pa.pg = pg;
   }
   hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);

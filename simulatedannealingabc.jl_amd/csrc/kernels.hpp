@@ -38,6 +38,12 @@ struct CdfPtrs {
 inline int64_t cdf_mid_stride(int64_t stride) { return ((2 * stride + 2 * kCdfCoarse) >> 4) + 2; }
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64
+// threads per workgroup of k_update (thread-per-particle form): the grid's tail -- the last workgroups of every CU run
+// with idle neighbours -- shrinks with the workgroup, the per-workgroup LDS tables and partial rows grow in number
+#ifndef SABC_UPDATE_BLOCK
+#define SABC_UPDATE_BLOCK 256
+#endif
+constexpr int kUpdateBlock = SABC_UPDATE_BLOCK;
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 // (a grid-stride variant of k_update with <= 1024 workgroups cost 20 more VGPRs and 11 % of its speed:
 // one workgroup per 256 particles and dynamic workgroup scheduling stay)

@@ -12,9 +12,10 @@ namespace sabc {
 // ------------------------------------------------------------------------------------------
 // block reduction of NP per-lane values: wave shuffles, then LDS across the 4 wavefronts
 // ------------------------------------------------------------------------------------------
-template <int NP>
+template <int NP, int BLOCK = kBlock>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], double *__restrict__ out) {
-  __shared__ double sm[kBlock / 64][NP];
+  constexpr int NW = BLOCK / 64;
+  __shared__ double sm[NW][NP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // step-major order: the NP shuffles of one step are independent and go out back to back (one LDS round trip per
   // step instead of one per step AND column -- 6 instead of 6 NP dependent trips at the end of every wave's life)
@@ -36,7 +37,10 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], doub
   __syncthreads();
   if (threadIdx.x < NP) {
     const int c = threadIdx.x;
-    out[c] = ((sm[0][c] + sm[1][c]) + sm[2][c]) + sm[3][c];
+    double a = sm[0][c];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) a += sm[w][c];
+    out[c] = a;
   }
 }
 
@@ -88,20 +92,20 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
 #define SABC_UPDATE_MIN_BLOCKS 4
 #endif
 template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(kBlock, SABC_UPDATE_MIN_BLOCKS)
+__global__ void __launch_bounds__(kUpdateBlock, SABC_UPDATE_MIN_BLOCKS)
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   rng_tables_load();
   __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
-  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kBlock) (&cidx[0][0])[i] = cdf.coarse[i];
+  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kUpdateBlock) (&cidx[0][0])[i] = cdf.coarse[i];
   __syncthreads();                         // publishes both the generator tables and the index
   double acc[NP];
 #pragma unroll
   for (int q = 0; q < NP; ++q) acc[q] = 0.0;
 
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * kUpdateBlock + threadIdx.x;
   if (t < act_n) {
     const int64_t li = act_lo + t;
     const uint64_t gid = (uint64_t)(pp.gid0 + li);
@@ -194,7 +198,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
     }
     moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
   }
-  block_reduce_store<NP>(acc, partials + (int64_t)blockIdx.x * NP);
+  block_reduce_store<NP, kUpdateBlock>(acc, partials + (int64_t)blockIdx.x * NP);
 }
 
 // moment sums of the shard as it stands (after a resample, or at update_population! entry :284)

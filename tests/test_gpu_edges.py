@@ -4,7 +4,7 @@ the host-simulator mode, and simulators that return zeros."""
 import numpy as np
 import pytest
 
-from tests.cases import SEED, hip_model_prior, hip_proposal, oracle_proposal, oracle_run
+from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal, oracle_proposal, oracle_run
 
 pytestmark = pytest.mark.gpu
 
@@ -105,3 +105,20 @@ def test_resample_disabled_and_every_update(S, O, gpu):
         assert res.state.n_resampling == run.counters["n_resampling"] == expect
         assert res.state.n_accept == run.counters["n_accept"]
         np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["gauss1_2stats", "gauss2d_cfg3", "lv_cfg5", "gk_cfg4"])
+def test_resample_draws_at_ragged_sizes(S, O, gpu, name):
+    """The one-shard resample searches packed 128-byte lines (4, 2 or 1 particles per line, 16 lines per group, 1024 particles
+    per chunk): population sizes that end in the middle of a line, a group and a chunk, one short of and one past a chunk,
+    against the oracle's draws (the initialization ends with a resample, :124-137)."""
+    model, prior = hip_model_prior(S, name)
+    d = len(MODELS[name]["prior"])
+    for n in (70, 1023, 1025, 2 * 1024 + 16 * 4 + 3, 33_003):
+        res = S.sabc(model, prior, n_particles=n, n_simulation=n, proposal=hip_proposal(S, "rw", d), seed=SEED)
+        run = oracle_run(O, name, n, n, prop="rw")
+        assert res.state.n_resampling == run.counters["n_resampling"] == 1
+        θ = res.population.T if d > 1 else res.population[None, :]
+        # a draw that picked a neighbouring particle would differ in the first digits
+        np.testing.assert_allclose(θ, run.theta, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(np.atleast_2d(res.u.T), run.u, rtol=1e-9, atol=1e-9)
