@@ -405,29 +405,49 @@ __device__ __forceinline__ void bitonic_sort128(double &v0, double &v1) {
   bitonic_merge<K, K / 2>(v0, v1);
 }
 
+// The quantile function is INCREASING in z when B > 0, k >= 0 and 0 <= c <= 0.83: d/dz of z (1 + c tanh(g z / 2)) (1 + z^2)^k
+// is (1 + z^2)^k [(1 + c t)(1 + 2 k z^2 / (1 + z^2)) + c w sech^2 w] with w = g z / 2, t = tanh w, and
+// tanh a + a sech^2 a <= 1.1997, so the bracket is >= 1 - 1.1997 c > 0 for every g.  Then the order statistics of the
+// simulated data are the quantile function OF the order statistics of the normals: sort(x)[r] = Q(sort(z)[r]) -- the
+// 128 normals are sorted and Q is evaluated at the S wanted ranks only (by the caller, for 16 particles x 4 ranks in one
+// pass over the lanes) instead of 128 times per particle.  Outside that region the data themselves are sorted, as the
+// reference does (the oracle always does).  Rounding can order two normals closer than ~1e-14 differently from their
+// images; the order statistic then differs in its last digits only.
+__device__ __forceinline__ bool gk_increasing(const double *th, double c) {
+  return th[1] > 0.0 && th[3] >= 0.0 && c >= 0.0 && c <= 0.83;
+}
+
+// |Q(z) - obs| for an order statistic z of the normals (+inf: a rank behind n_draws)
+__device__ __forceinline__ double gk_rho_of_normal(const double *th, double c, double z, double obs) {
+  const double x = z < INFINITY ? gk_quantile(th, c, z) : INFINITY;
+  return finite_or_big(fabs(x - obs));
+}
+
+// out[j]: gk_increasing(th, c) ? the normal of rank j (the caller applies gk_rho_of_normal) : rho_j itself.
+// All 64 lanes must call this with the same (th, pid, iter).
 template <int S>
-__device__ __forceinline__ void gk_simulate_wave(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
-                                                 double *rho) {
+__device__ __forceinline__ void gk_simulate_wave_ranks(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
+                                                       double *out) {
   const int lane = threadIdx.x & 63;
   const int n_draws = (int)m.p[0];
   const double c = m.p[1];
+  const bool inc = gk_increasing(th, c);                // uniform over the wave
   double z0, z1;
   box_muller(stream_block(m.seed, pid, PURPOSE_SIM, iter, (uint32_t)lane), z0, z1);
+  if (!inc) { z0 = gk_quantile(th, c, z0); z1 = gk_quantile(th, c, z1); }
   const int i0 = 2 * lane, i1 = 2 * lane + 1;
-  const double a = i0 < n_draws ? gk_quantile(th, c, z0) : INFINITY;
-  const double b = i1 < n_draws ? gk_quantile(th, c, z1) : INFINITY;
   // bitonic sorting network over the 128 values, two per lane (element index = 2*lane + slot):
   // 28 compare-exchange steps, 7 of them inside the lane, 21 with the lane at distance j/2
-  double v0 = a, v1 = b;
+  double v0 = i0 < n_draws ? z0 : INFINITY, v1 = i1 < n_draws ? z1 : INFINITY;
   bitonic_sort128<kGkMaxDraws>(v0, v1);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
     const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
     const double lo = __shfl(v0, want >> 1, 64), hi = __shfl(v1, want >> 1, 64);
-    rho[j] = finite_or_big(fabs(((want & 1) ? hi : lo) - m.p[2 + S + j]));
+    const double v = (want & 1) ? hi : lo;
+    out[j] = inc ? v : finite_or_big(fabs(v - m.p[2 + S + j]));
   }
 }
-
 
 #endif  // !__HIPCC_RTC__
 

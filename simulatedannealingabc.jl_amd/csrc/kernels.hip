@@ -131,7 +131,8 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
     double thp[D], rp[S];
 #pragma unroll
     for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
-    gk_simulate_wave<S>(m, thp, (uint64_t)(pp.gid0 + act_lo + t0 + it), c.iter, rp);
+    // the wanted order statistics of the normals where the quantile function is increasing (phase 2 maps them), else rho
+    gk_simulate_wave_ranks<S>(m, thp, (uint64_t)(pp.gid0 + act_lo + t0 + it), c.iter, rp);
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < S; ++j) st.rp[it][j] = rp[j];
@@ -140,16 +141,26 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase 2: all 16 x 4 ECDF lookups of the wave at once, one per lane (:316)
+  // ---- phase 2: the 16 x 4 (particle, statistic) pairs of the wave at once, one per lane: quantile function of the
+  // order statistic of the normals -> distance (device_models.hpp: gk_increasing), then the ECDF lookup (:316)
   {
     const int it = lane >> 2, j = lane & 3;
     double upv = 0.0;
     if (t0 + it < act_n && st.lpp[it] > -INFINITY) {
       int64_t len = cdf.len[0];
+      double obs = m.p[2 + S];
 #pragma unroll
       for (int q = 1; q < S; ++q)
-        if (j == q) len = cdf.len[q];
-      upv = cdf_apply_mid(cdf.knots + (int64_t)j * cdf.stride, len, cdf.mid + (int64_t)j * cdf.mid_stride, st.rp[it][j]);
+        if (j == q) { len = cdf.len[q]; obs = m.p[2 + S + q]; }
+      double thp[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
+      double r = st.rp[it][j];
+      if (gk_increasing(thp, m.p[1])) {
+        r = gk_rho_of_normal(thp, m.p[1], r, obs);
+        st.rp[it][j] = r;
+      }
+      upv = cdf_apply_mid(cdf.knots + (int64_t)j * cdf.stride, len, cdf.mid + (int64_t)j * cdf.mid_stride, r);
     }
     st.up[it][j] = upv;
   }
@@ -251,10 +262,26 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
     double th[D], rho[S];
 #pragma unroll
     for (int k = 0; k < D; ++k) th[k] = sth[wave][it][k];
-    gk_simulate_wave<S>(m, th, pid0 + (uint64_t)(i0 + it), iter, rho);
+    gk_simulate_wave_ranks<S>(m, th, pid0 + (uint64_t)(i0 + it), iter, rho);
     if (lane == 0) {
 #pragma unroll
       for (int j = 0; j < S; ++j) srho[wave][it][j] = rho[j];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {   // order statistics of the normals -> distances, the 16 x 4 pairs of the wave at once (gk_increasing)
+    static_assert(PW * S == 64, "one (particle, statistic) pair per lane");
+    const int it = lane >> 2, j = lane & 3;
+    if (i0 + it < n) {
+      double th[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) th[k] = sth[wave][it][k];
+      double obs = m.p[2 + S];
+#pragma unroll
+      for (int q = 1; q < S; ++q)
+        if (j == q) obs = m.p[2 + S + q];
+      if (gk_increasing(th, m.p[1])) srho[wave][it][j] = gk_rho_of_normal(th, m.p[1], srho[wave][it][j], obs);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -512,15 +539,20 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
   const int g = threadIdx.x / np, c = threadIdx.x - g * np;
   double v = 0.0;
   if (g < G) {
-    int64_t r = g;
-    for (; r + 7 * (int64_t)G < rows; r += 8 * (int64_t)G) {   // 8 loads in flight per lane; the additions stay in row order
-      double x[8];
+    // all of a lane's rows in ONE round trip where they fit (20 at n = 1e6: 3906 rows over 204 row groups), masked so that
+    // there is no tail of dependent single loads (each a trip to the L2: 3-4 of them were ~3 us of this kernel); the
+    // additions stay in row order, a masked slot adds +0
+    constexpr int kInFlight = 24;
+    for (int64_t r0 = g; r0 < rows; r0 += (int64_t)kInFlight * G) {
+      double x[kInFlight];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = partials[(r + (int64_t)e * G) * np + c];
+      for (int e = 0; e < kInFlight; ++e) {
+        const int64_t r = r0 + (int64_t)e * G;
+        x[e] = r < rows ? partials[r * np + c] : 0.0;
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v += x[e];
+      for (int e = 0; e < kInFlight; ++e) v += x[e];
     }
-    for (; r < rows; r += G) v += partials[r * np + c];
   }
   sm[threadIdx.x] = v;
   __syncthreads();

@@ -45,6 +45,10 @@ MODELS = {
     # BASELINE config 4
     "gk_cfg4": dict(model=("GandK", dict(n_draws=128, c=0.8, ranks=(16, 48, 80, 112), obs=(1.9, 2.7, 3.6, 6.4))),
                     prior=[("U", 0.0, 10.0)] * 4, s=4),
+    # the same with c = 0.9: above 0.83 the quantile function need not be increasing, so the device sorts the data
+    # themselves (below it sorts the normals and maps the wanted ranks: device_models.hpp, gk_increasing)
+    "gk_c09": dict(model=("GandK", dict(n_draws=100, c=0.9, ranks=(10, 40, 60, 95), obs=(1.5, 2.8, 3.4, 7.0))),
+                   prior=[("U", 0.0, 10.0)] * 4, s=4),
     # BASELINE config 5
     "lv_cfg5": dict(model=("LotkaVolterra", dict(n_steps=256, dt=0.05, σ=0.1, x0=50.0, y0=50.0, obs=(18.0, 17.0, 14.0, 12.0))),
                     prior=[("U", 0.0, 2.0), ("U", 0.0, 0.1), ("U", 0.0, 2.0)], s=4),
