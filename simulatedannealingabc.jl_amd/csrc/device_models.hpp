@@ -294,7 +294,13 @@ struct Sim<SABC_MODEL_GAUSS2D, D, S> {
 // __shfl_xor) and the requested order statistics are read out of the owning lanes.  All 64 lanes
 // must call this with the same (th, pid, iter).
 constexpr int kGkMaxDraws = 128;
-constexpr int kGkParticlesPerWave = 16;
+// particles a wave takes through its lane-parallel phases (proposal / prior gate, ECDF, accept) between the simulations,
+// which it does one particle at a time: the lane-parallel phases cost the same for 16 busy lanes as for 64.
+// Measured on cfg4 at n = 1e6 (tools/exp_ab2.sh, two runs each): 16 per wave 610 us, 32: 544 us, 64: 540 us.
+#ifndef SABC_GK_PW
+#define SABC_GK_PW 64
+#endif
+constexpr int kGkParticlesPerWave = SABC_GK_PW;
 
 // (1 + z^2)^k as exp(k log(1 + z^2)): the argument of the log is >= 1 and normal, so the
 // table-driven log of device_rng.hpp applies (relative error ~ k log(1+z^2) * 2e-16)

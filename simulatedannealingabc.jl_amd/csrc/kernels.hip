@@ -19,17 +19,17 @@
 namespace sabc {
 
 // ------------------------------------------------------------------------------------------
-// g-and-k (BASELINE config 4): wave-per-particle variants.  A block of 4 waves covers
-// 4 * kGkParticlesPerWave consecutive particles; scalar work (proposal, prior, accept) is done
-// redundantly by all lanes of the wave (same counters -> same values, no broadcast needed), the
-// simulator and the 4 ECDF lookups are spread over the lanes.
+// g-and-k (BASELINE config 4): the SIMULATION is wave-per-particle (128 draws sorted across the lanes); a wave owns
+// kGkParticlesPerWave consecutive particles (a block of 4 waves 4 x that), does their proposals, prior gates, ECDF
+// lookups and accept steps one particle per lane, and simulates them one after the other in between.
 // ------------------------------------------------------------------------------------------
 constexpr int kGkD = 4, kGkS = 4;
 constexpr int kGkPerBlock = (kBlock / 64) * kGkParticlesPerWave;
-// k_update_gk: every wave takes kGkReps groups of 16 particles in turn and the workgroup writes ONE partial row for all of
-// them.  Measured at n = 1e6 (tools/exp_ab2.sh, three runs each): 1 group 663 us, 2 groups 786 us, 4 groups 812 us -- the
-// loop around the phases costs the register allocator 240 more bytes of scratch and 16 more SGPR reloads per particle,
-// far more than the 12 us the shorter partial-row matrix saves in k_reduce_partials + k_control.  So: one group.
+// k_update_gk: every wave takes kGkReps groups of kGkParticlesPerWave particles in turn and the workgroup writes ONE partial
+// row for all of them.  Measured at n = 1e6 with groups of 16 (tools/exp_ab2.sh, three runs each): 1 group 663 us, 2 groups
+// 786 us, 4 groups 812 us -- the loop around the phases costs the register allocator 240 more bytes of scratch and 16 more
+// SGPR reloads per particle.  So: one group, and the group itself grew to 64 (device_models.hpp) -- the lane-parallel
+// phases then run with all lanes busy instead of being repeated.
 #ifndef SABC_GK_REPS
 #define SABC_GK_REPS 1
 #endif
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(kBlock, 4)
 k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
             const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int D = kGkD, S = kGkS, NP = n_partials(D, S), PW = kGkParticlesPerWave;
-  static_assert(PW * S == 64, "phase 2 maps one (particle, statistic) pair to each lane");
+  static_assert(S == 4 && (PW * S) % 64 == 0 && PW <= 64, "phase 2 maps one (particle, statistic) pair to each lane, PW S / 64 times");
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   rng_tables_init();
   __shared__ GkStage stage[kBlock / 64];
@@ -143,8 +143,8 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
 
   // ---- phase 2: the 16 x 4 (particle, statistic) pairs of the wave at once, one per lane: quantile function of the
   // order statistic of the normals -> distance (device_models.hpp: gk_increasing), then the ECDF lookup (:316)
-  {
-    const int it = lane >> 2, j = lane & 3;
+  for (int pass = 0; pass < PW * S / 64; ++pass) {
+    const int it = pass * (64 / S) + (lane >> 2), j = lane & 3;
     double upv = 0.0;
     if (t0 + it < act_n && st.lpp[it] > -INFINITY) {
       int64_t len = cdf.len[0];
@@ -208,7 +208,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
     }
     moment_terms<D, S>(cb->pivot, accepted, th, u, drho, term);
   }
-  // sum the moment terms over the wave's 16 particle lanes (lanes >= 16 hold zeros) into the wave's running row, ...
+  // sum the moment terms over the wave's PW particle lanes (lanes >= PW hold zeros) into the wave's running row, ...
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
     double v = term[q];
@@ -270,9 +270,10 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  {   // order statistics of the normals -> distances, the 16 x 4 pairs of the wave at once (gk_increasing)
-    static_assert(PW * S == 64, "one (particle, statistic) pair per lane");
-    const int it = lane >> 2, j = lane & 3;
+  // order statistics of the normals -> distances, 16 x 4 (particle, statistic) pairs of the wave at once (gk_increasing)
+  static_assert(S == 4 && (PW * S) % 64 == 0 && PW <= 64, "one (particle, statistic) pair per lane, PW S / 64 times");
+  for (int pass = 0; pass < PW * S / 64; ++pass) {
+    const int it = pass * (64 / S) + (lane >> 2), j = lane & 3;
     if (i0 + it < n) {
       double th[D];
 #pragma unroll
@@ -1253,7 +1254,7 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 // workgroups (= partial rows) of one k_update launch over act_n particles
 int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   if (act_n <= 0) return 0;
-  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_update_blocks(act_n)   // 256 particles per workgroup (wave per particle, 4 groups of 16 per wave)
+  return m.model_id == SABC_MODEL_GK ? (int64_t)gk_update_blocks(act_n)   // 4 waves x kGkParticlesPerWave particles per workgroup
                                      : (act_n + kUpdateBlock - 1) / kUpdateBlock;   // one thread per particle
 }
 
