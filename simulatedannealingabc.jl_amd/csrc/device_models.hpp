@@ -220,6 +220,54 @@ __device__ __forceinline__ double cdf_apply_mid(const double *__restrict__ T, in
   return cdf_interp(T, len, lo, x);
 }
 
+// N lookups into the SAME table, step by step together: every step of the search is a dependent read (16 in the mid
+// level + 4 in the line + the interpolation's pair at n = 1e6) and the N values are independent, so the N reads of a step
+// are in flight together -- a chain of ~22 round trips instead of ~22 N.  The mid level is walked in the power-of-two
+// "advance" form (uniform trip count); it tests the same monotone predicate as cdf_apply_mid's bisection, so the rank --
+// and u -- is bit-identical.  A lane with nothing to look up passes any finite x and ignores u.
+template <int N>
+__device__ __forceinline__ void cdf_apply_mid_lockstep(const double *__restrict__ T, int64_t len, const double *__restrict__ M,
+                                                       const double *x, double *u) {
+  const int64_t mcount = (len + 15) >> kCdfLineShift;     // entries of M that lie inside the table
+  int64_t top = 1;
+  while (top < mcount) top <<= 1;
+  int64_t a[N];
+#pragma unroll
+  for (int p = 0; p < N; ++p) a[p] = 0;                   // last m with M[m] < x, given M[0] = T[0] < x (else discarded)
+  for (int64_t step = top >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      const int64_t q = a[p] + step;
+      const int64_t qs = q < mcount ? q : mcount - 1;      // a probe behind the table reads its last entry and is refused
+      const double v = M[qs];
+      a[p] = (q < mcount && v < x[p]) ? q : a[p];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < N; ++p) a[p] <<= kCdfLineShift;
+#pragma unroll
+  for (int step = 1 << kCdfLineShift >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+    for (int p = 0; p < N; ++p) a[p] += (T[a[p] + step] < x[p]) ? step : 0;      // (+inf behind len)
+  }
+  const double first = T[0], last = T[len - 1], L1 = (double)(len - 1);
+  double t0[N], t1[N];
+  int64_t i0[N];
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    const int64_t lo = first < x[p] ? a[p] + 1 : 0;        // lo = #knots < x
+    i0[p] = lo > 0 ? lo - 1 : 0;
+    t0[p] = T[i0[p]]; t1[p] = T[i0[p] + 1];
+  }
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    const double y0 = (double)i0[p] / L1, y1 = (double)(i0[p] + 1) / L1;
+    const double t = (x[p] - t0[p]) / (t1[p] - t0[p]);     // cdf_interp
+    const double v = y0 + t * (y1 - y0);
+    u[p] = !(x[p] >= first) ? ((x[p] != x[p]) ? x[p] : 0.0) : (x[p] > last ? 1.0 : v);
+  }
+}
+
 __device__ __forceinline__ double finite_or_big(double v) { return isfinite(v) ? v : 1e30; }
 
 // ---- simulators ----
@@ -411,6 +459,21 @@ __device__ __forceinline__ void bitonic_sort128(double &v0, double &v1) {
   bitonic_merge<K, K / 2>(v0, v1);
 }
 
+// the same network over TWO independent sets of 128 values, step by step: the exchanges of one set (a trip through the LDS
+// crossbar or a permlane swap) are in flight while the other set's compare and selects issue
+template <int K, int J>
+__device__ __forceinline__ void bitonic_merge_x2(double &a0, double &a1, double &b0, double &b1) {
+  bitonic_step<K, J>(a0, a1);
+  bitonic_step<K, J>(b0, b1);
+  if constexpr (J > 1) bitonic_merge_x2<K, J / 2>(a0, a1, b0, b1);
+}
+
+template <int K>
+__device__ __forceinline__ void bitonic_sort128_x2(double &a0, double &a1, double &b0, double &b1) {
+  if constexpr (K > 2) bitonic_sort128_x2<K / 2>(a0, a1, b0, b1);
+  bitonic_merge_x2<K, K / 2>(a0, a1, b0, b1);
+}
+
 // The quantile function is INCREASING in z when B > 0, k >= 0 and 0 <= c <= 0.83: d/dz of z (1 + c tanh(g z / 2)) (1 + z^2)^k
 // is (1 + z^2)^k [(1 + c t)(1 + 2 k z^2 / (1 + z^2)) + c w sech^2 w] with w = g z / 2, t = tanh w, and
 // tanh a + a sech^2 a <= 1.1997, so the bracket is >= 1 - 1.1997 c > 0 for every g.  Then the order statistics of the
@@ -452,6 +515,34 @@ __device__ __forceinline__ void gk_simulate_wave_ranks(const ModelDesc &m, const
     const double lo = __shfl(v0, want >> 1, 64), hi = __shfl(v1, want >> 1, 64);
     const double v = (want & 1) ? hi : lo;
     out[j] = inc ? v : finite_or_big(fabs(v - m.p[2 + S + j]));
+  }
+}
+
+// two particles at a time (A and B may be the same particle: an odd one out is simulated against itself)
+template <int S>
+__device__ __forceinline__ void gk_simulate_wave_ranks_x2(const ModelDesc &m, const double *thA, const double *thB, uint64_t pidA,
+                                                          uint64_t pidB, uint64_t iter, double *outA, double *outB) {
+  const int lane = threadIdx.x & 63;
+  const int n_draws = (int)m.p[0];
+  const double c = m.p[1];
+  const bool incA = gk_increasing(thA, c), incB = gk_increasing(thB, c);     // uniform over the wave
+  double a0, a1, b0, b1;
+  box_muller(stream_block(m.seed, pidA, PURPOSE_SIM, iter, (uint32_t)lane), a0, a1);
+  box_muller(stream_block(m.seed, pidB, PURPOSE_SIM, iter, (uint32_t)lane), b0, b1);
+  if (!incA) { a0 = gk_quantile(thA, c, a0); a1 = gk_quantile(thA, c, a1); }
+  if (!incB) { b0 = gk_quantile(thB, c, b0); b1 = gk_quantile(thB, c, b1); }
+  const bool in0 = 2 * lane < n_draws, in1 = 2 * lane + 1 < n_draws;
+  a0 = in0 ? a0 : INFINITY; a1 = in1 ? a1 : INFINITY;
+  b0 = in0 ? b0 : INFINITY; b1 = in1 ? b1 : INFINITY;
+  bitonic_sort128_x2<kGkMaxDraws>(a0, a1, b0, b1);
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
+    const double alo = __shfl(a0, want >> 1, 64), ahi = __shfl(a1, want >> 1, 64);
+    const double blo = __shfl(b0, want >> 1, 64), bhi = __shfl(b1, want >> 1, 64);
+    const double va = (want & 1) ? ahi : alo, vb = (want & 1) ? bhi : blo;
+    outA[j] = incA ? va : finite_or_big(fabs(va - m.p[2 + S + j]));
+    outB[j] = incB ? vb : finite_or_big(fabs(vb - m.p[2 + S + j]));
   }
 }
 

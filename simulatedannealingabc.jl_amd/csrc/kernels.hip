@@ -34,6 +34,9 @@ constexpr int kGkPerBlock = (kBlock / 64) * kGkParticlesPerWave;
 #define SABC_GK_REPS 1
 #endif
 constexpr int kGkReps = SABC_GK_REPS;
+#ifndef SABC_GK_PAIR
+#define SABC_GK_PAIR 1
+#endif
 constexpr int kGkUpdatePerBlock = kGkPerBlock * kGkReps;
 
 // per-wave staging of what phase 1 (propose + simulate) hands to phase 2 (ECDF) and 3 (accept)
@@ -124,45 +127,74 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase 1b, one particle at a time with the whole wave: simulate (:315); lane l draws 2 of the 128
-  for (int it = 0; it < PW; ++it) {
-    if (t0 + it >= act_n) break;                       // uniform over the wave
-    if (!(st.lpp[it] > -INFINITY)) continue;           // outside the prior's support: not simulated (:314)
-    double thp[D], rp[S];
+  // ---- phase 1b, the whole wave on the simulations (:315), lane l draws 2 of a particle's 128; TWO particles at a time
+  // (SABC_GK_PAIR): their sorting networks are independent, so the lane exchanges of one overlap the selects of the other.
+  // Particles outside the prior's support are not simulated (:314): the wave walks the set bits of `todo`.
+  {
+    unsigned long long todo = __ballot(mine && st.lpp[lane] > -INFINITY);
+    while (todo) {                                       // uniform over the wave
+      const int ia = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+#if SABC_GK_PAIR
+      int ib = ia;                                       // an odd one out is paired with itself
+      if (todo) { ib = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+      double tha[D], thb[D], ra[S], rb[S];
 #pragma unroll
-    for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
-    // the wanted order statistics of the normals where the quantile function is increasing (phase 2 maps them), else rho
-    gk_simulate_wave_ranks<S>(m, thp, (uint64_t)(pp.gid0 + act_lo + t0 + it), c.iter, rp);
-    if (lane == 0) {
+      for (int k = 0; k < D; ++k) { tha[k] = st.thp[ia][k]; thb[k] = st.thp[ib][k]; }
+      // the wanted order statistics of the normals where the quantile function is increasing (phase 2 maps them), else rho
+      gk_simulate_wave_ranks_x2<S>(m, tha, thb, (uint64_t)(pp.gid0 + act_lo + t0 + ia), (uint64_t)(pp.gid0 + act_lo + t0 + ib),
+                                   c.iter, ra, rb);
+      if (lane == 0) {
 #pragma unroll
-      for (int j = 0; j < S; ++j) st.rp[it][j] = rp[j];
+        for (int j = 0; j < S; ++j) { st.rp[ia][j] = ra[j]; st.rp[ib][j] = rb[j]; }
+      }
+#else
+      double thp[D], rp[S];
+#pragma unroll
+      for (int k = 0; k < D; ++k) thp[k] = st.thp[ia][k];
+      gk_simulate_wave_ranks<S>(m, thp, (uint64_t)(pp.gid0 + act_lo + t0 + ia), c.iter, rp);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) st.rp[ia][j] = rp[j];
+      }
+#endif
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- phase 2: the 16 x 4 (particle, statistic) pairs of the wave at once, one per lane: quantile function of the
-  // order statistic of the normals -> distance (device_models.hpp: gk_increasing), then the ECDF lookup (:316)
-  for (int pass = 0; pass < PW * S / 64; ++pass) {
-    const int it = pass * (64 / S) + (lane >> 2), j = lane & 3;
-    double upv = 0.0;
-    if (t0 + it < act_n && st.lpp[it] > -INFINITY) {
-      int64_t len = cdf.len[0];
-      double obs = m.p[2 + S];
+  // ---- phase 2: the PW x 4 (particle, statistic) pairs of the wave, PW S / 64 per lane -- all with the lane's statistic
+  // j = lane & 3: quantile function of the order statistic of the normals -> distance (device_models.hpp: gk_increasing),
+  // then the lane's ECDF lookups (:316) in lockstep on the one table they share
+  {
+    constexpr int NPASS = PW * S / 64;
+    const int j = lane & 3;
+    int64_t len = cdf.len[0];
+    double obs = m.p[2 + S];
 #pragma unroll
-      for (int q = 1; q < S; ++q)
-        if (j == q) { len = cdf.len[q]; obs = m.p[2 + S + q]; }
-      double thp[D];
+    for (int q = 1; q < S; ++q)
+      if (j == q) { len = cdf.len[q]; obs = m.p[2 + S + q]; }
+    double r[NPASS], upv[NPASS];
+    bool live[NPASS];
 #pragma unroll
-      for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
-      double r = st.rp[it][j];
-      if (gk_increasing(thp, m.p[1])) {
-        r = gk_rho_of_normal(thp, m.p[1], r, obs);
-        st.rp[it][j] = r;
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int it = pass * (64 / S) + (lane >> 2);
+      live[pass] = t0 + it < act_n && st.lpp[it] > -INFINITY;
+      r[pass] = 0.0;
+      if (live[pass]) {
+        double thp[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) thp[k] = st.thp[it][k];
+        r[pass] = st.rp[it][j];
+        if (gk_increasing(thp, m.p[1])) {
+          r[pass] = gk_rho_of_normal(thp, m.p[1], r[pass], obs);
+          st.rp[it][j] = r[pass];
+        }
       }
-      upv = cdf_apply_mid(cdf.knots + (int64_t)j * cdf.stride, len, cdf.mid + (int64_t)j * cdf.mid_stride, r);
     }
-    st.up[it][j] = upv;
+    cdf_apply_mid_lockstep<NPASS>(cdf.knots + (int64_t)j * cdf.stride, len, cdf.mid + (int64_t)j * cdf.mid_stride, r, upv);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) st.up[pass * (64 / S) + (lane >> 2)][j] = live[pass] ? upv[pass] : 0.0;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
