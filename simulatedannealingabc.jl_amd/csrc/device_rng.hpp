@@ -125,9 +125,23 @@ __device__ __forceinline__ RngTables &rng_tables() {
 // the copies only; the caller's next __syncthreads() publishes them (k_update shares that barrier with its ECDF index)
 __device__ __forceinline__ void rng_tables_load() {
   RngTables &t = rng_tables();
-  for (int i = threadIdx.x; i < 128; i += blockDim.x) t.logt[i] = make_double2(kLogTab[i][0], kLogTab[i][1]);
-  for (int i = threadIdx.x; i < 33; i += blockDim.x) t.sct[i] = make_double2(kSinCosTab[i & 31][0], kSinCosTab[i & 31][1]);
-  for (int i = threadIdx.x; i < 32; i += blockDim.x) t.exp2t[i] = kExp2Tab[i];
+  const int i = threadIdx.x;
+  if (blockDim.x >= 128) {
+    // every table entry has a thread of its own: the three reads go out together and the workgroup starts after ONE trip
+    // to memory (three loops, each waiting for its own read, were three -- at the front of every workgroup's life)
+    double2 a = make_double2(0.0, 0.0), b = make_double2(0.0, 0.0);
+    double c = 0.0;
+    if (i < 128) a = make_double2(kLogTab[i][0], kLogTab[i][1]);
+    if (i < 33) b = make_double2(kSinCosTab[i & 31][0], kSinCosTab[i & 31][1]);
+    if (i < 32) c = kExp2Tab[i];
+    if (i < 128) t.logt[i] = a;
+    if (i < 33) t.sct[i] = b;
+    if (i < 32) t.exp2t[i] = c;
+    return;
+  }
+  for (int k = i; k < 128; k += blockDim.x) t.logt[k] = make_double2(kLogTab[k][0], kLogTab[k][1]);
+  for (int k = i; k < 33; k += blockDim.x) t.sct[k] = make_double2(kSinCosTab[k & 31][0], kSinCosTab[k & 31][1]);
+  for (int k = i; k < 32; k += blockDim.x) t.exp2t[k] = kExp2Tab[k];
 }
 
 __device__ __forceinline__ void rng_tables_init() {

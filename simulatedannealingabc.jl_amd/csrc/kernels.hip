@@ -814,6 +814,17 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
 // (64 per chunk, 0.5 MB at n = 1e6: L2-resident) -> the 16 elements of that group (one 128-byte line).
 constexpr int kGatherCoarseMax = 4096;     // chunks held in LDS (n <= 4.2e6); beyond that bs is searched in global memory
 constexpr int kGroupsPerChunk = kScanChunk / 16;
+// the chunk offsets into LDS, four reads in flight per thread (nb <= 4096 and 256 threads: at most 4 trips to memory at the
+// front of every workgroup of a latency-bound kernel instead of 16); the caller's __syncthreads() publishes them
+__device__ __forceinline__ void stage_chunk_offsets(const double *__restrict__ bs, const int64_t nb, double *lds) {
+  for (int64_t i0 = threadIdx.x; i0 < nb; i0 += 4 * kBlock) {
+    double t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int64_t i = i0 + (int64_t)e * kBlock; t[e] = i < nb ? bs[i] : 0.0; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int64_t i = i0 + (int64_t)e * kBlock; if (i < nb) lds[i] = t[e]; }
+  }
+}
 // first index k with cum[k] > t, by the three levels described above (B = the chunk offsets, in LDS or global memory)
 __device__ __forceinline__ int64_t resample_search(const double t, const double *B, const int64_t nb,
                                                    const double *__restrict__ cm, const double *__restrict__ cum,
@@ -852,7 +863,7 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
   if (in_lds) {
-    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    stage_chunk_offsets(bs, nb, bs_lds);
     __syncthreads();
   }
   const double *B = in_lds ? bs_lds : bs;
@@ -974,7 +985,7 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
   if (in_lds) {
-    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    stage_chunk_offsets(bs, nb, bs_lds);
     __syncthreads();
   }
   const double *B = in_lds ? bs_lds : bs;
@@ -1012,7 +1023,7 @@ k_resample_gather_packed(const uint64_t seed, const int row_len, const double *_
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
   if (in_lds) {
-    for (int64_t i = threadIdx.x; i < nb; i += kBlock) bs_lds[i] = bs[i];
+    stage_chunk_offsets(bs, nb, bs_lds);
     __syncthreads();
   }
   const double *B = in_lds ? bs_lds : bs;

@@ -99,7 +99,17 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   rng_tables_load();
   __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
-  for (int i = threadIdx.x; i < S * kCdfCoarse; i += kUpdateBlock) (&cidx[0][0])[i] = cdf.coarse[i];
+  {   // all reads first, then the LDS writes: one trip to memory at the front of the workgroup's life instead of one per pass
+    static_assert((S * kCdfCoarse / 2) % kUpdateBlock == 0, "whole passes of 16 bytes per thread");
+    constexpr int kPasses = S * kCdfCoarse / 2 / kUpdateBlock;
+    const double2 *src = reinterpret_cast<const double2 *>(cdf.coarse);
+    double2 *dst = reinterpret_cast<double2 *>(&cidx[0][0]);
+    double2 tmp[kPasses];
+#pragma unroll
+    for (int q = 0; q < kPasses; ++q) tmp[q] = src[threadIdx.x + q * kUpdateBlock];
+#pragma unroll
+    for (int q = 0; q < kPasses; ++q) dst[threadIdx.x + q * kUpdateBlock] = tmp[q];
+  }
   __syncthreads();                         // publishes both the generator tables and the index
   double acc[NP];
 #pragma unroll
