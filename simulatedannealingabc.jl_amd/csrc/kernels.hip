@@ -719,14 +719,25 @@ k_scan_offsets(double *__restrict__ bs, const double *__restrict__ bq, const int
 // and every particle's slot starts on a 16 / pg-double boundary):
 //   pk[(i / pg) * 16 + (i % pg) * (16 / pg)] = { cum_i, theta_i..., u_i... }
 //   ge[i / pg]  = cum at the line's last particle                      (kScanChunk / pg per chunk)
-//   gc[i / pg / 16] = ge of every 16th line                            (kScanChunk / pg / 16 per chunk: <= 64 doubles)
-// A draw then costs THREE dependent line fetches (a line of gc, a line of ge, the packed line) instead of ~10 (binary
+//   guide[b]    = a line whose running sums reach bucket b of [0, total), n_lines + 2 buckets (guide_bucket)
+// A draw then costs THREE dependent fetches (the guide entry, two line ends, the packed line) instead of ~10 (binary
 // search through `cm` and `cum`, one line per gathered row).  The running sums are the same numbers, so the drawn index
 // is the same.
 struct PackArgs {
-  double *pk, *ge, *gc;  // pk == nullptr: no packing (the sharded path gathers rows by request)
+  double *pk, *ge;       // pk == nullptr: no packing (the sharded path gathers rows by request)
+  int32_t *guide;        // guide[b]: a line whose running sums reach bucket b of [0, total) -- where a draw starts looking
+  const double *totals;  // totals[0] = sum of the weights (written by k_scan_offsets)
   int row_len, pg;
 };
+
+// bucket of a running sum t: n_lines equal buckets over [0, total).  The SAME expression places the lines in
+// k_scan_final and the draws in the gather; it only has to be monotone -- the guide is a starting point, the search
+// around it decides (packed_search).
+__device__ __forceinline__ int64_t guide_bucket(const double t, const double total, const int64_t n_lines) {
+  const double x = t * ((double)n_lines / total);
+  const int64_t b = x > 0.0 ? (int64_t)x : 0;             // (NaN -> 0)
+  return b <= n_lines + 1 ? b : n_lines + 1;
+}
 
 // pass 3: inclusive scan inside each chunk + chunk offset
 __global__ void __launch_bounds__(kBlock)
@@ -799,11 +810,21 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
     if (i < n)
       for (int row = 0; row < pa.row_len; ++row) v[1 + row] = g[(int64_t)row * cap + i];
     double2 *dst = reinterpret_cast<double2 *>(pa.pk + line * 16 + slot * stride);
-    for (int q = 0; 2 * q < stride; ++q) dst[q] = make_double2(v[2 * q], v[2 * q + 1]);
+    // (only the slot's used part: the padding behind 1 + row_len doubles is never read)
+    for (int q = 0; 2 * q < stride && 2 * q < 1 + pa.row_len; ++q) dst[q] = make_double2(v[2 * q], v[2 * q + 1]);
     // the line's end value: its last particle, or the last particle of the population (scum is flat behind n)
     if (i < n && (slot == pa.pg - 1 || i == n - 1)) {
-      pa.ge[line] = scum[loc];
-      if ((line & 15) == 15 || i == n - 1) pa.gc[line >> 4] = scum[loc];
+      const double e1 = scum[loc];
+      pa.ge[line] = e1;
+      // the buckets this line's running sums reach: from the end of the line before it (the chunk's offset for the chunk's
+      // first line, inclusive there so that rounding between the offset and the previous chunk's end leaves no bucket
+      // unwritten) to its own end; the population's last line takes the rest
+      const int first_loc = loc - slot;                              // the line's first particle, inside this chunk
+      const double total = pa.totals[0];
+      int64_t b0 = first_loc > 0 ? guide_bucket(scum[first_loc - 1], total, n_lines) + 1 : guide_bucket(bs[blockIdx.x], total, n_lines);
+      int64_t b1 = i == n - 1 ? n_lines + 1 : guide_bucket(e1, total, n_lines);
+      for (int64_t b = b0; b <= b1; ++b) pa.guide[b] = (int32_t)line;
+      if (i == n - 1) { pa.ge[line + 1] = INFINITY; pa.ge[line + 2] = INFINITY; }
     }
   }
 }
@@ -880,92 +901,76 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
     dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
 }
 
-// The draw on packed lines: chunk by the offsets `B` (as resample_search), then the first line of the chunk whose end value
-// exceeds t -- by the chunk's coarse ends gc (every 16th line; one or a few 128-byte lines) and the 16 line ends behind the
-// one found (one line of ge) --, then the first slot of that line whose running sum exceeds t.  Returns the drawn index and
-// the address of its packed row.  Same decisions as resample_search on the same numbers: if no running sum of the chunk
-// exceeds t (rounding of the offsets against the sums) the next chunk's first particle is taken, the last particle at the
-// end of the population.
-// Every level is ONE round trip: the 16 doubles of a 128-byte line are fetched by eight independent 16-byte loads and the
-// position is the COUNT of entries that do not exceed t (the running sums are non-decreasing, so the count is the
-// binary search's answer); a dependent chain of ~11 divergent loads per draw became 3 (the kernel is bound by that
-// chain's latency, not by bytes or issue).  L receives the packed line of the drawn particle, `slot` its slot.
-__device__ __forceinline__ void load_line(const double *__restrict__ p, double (&L)[16]) {
-  const double2 *q = reinterpret_cast<const double2 *>(p);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) { const double2 v = q[k]; L[2 * k] = v.x; L[2 * k + 1] = v.y; }
-}
-
+// The draw on packed lines.  Chunk by the offsets `B` (as resample_search: the oracle's answer is defined per chunk); inside
+// the chunk the first line whose end value exceeds t is found AROUND a guess: guide[bucket of t] (k_scan_final) is a line
+// whose running sums reach t's bucket -- with n_lines buckets usually the line itself or a neighbour --, the ends of that
+// line and of the one before it are read together, and the search walks from there in whichever direction they say
+// (the ends are non-decreasing inside a chunk, so the walk is the search).  Then the packed line: the running sums of its
+// first PG - 1 slots pick the slot, and the caller reads that slot's row.  Per draw: the guide entry, two line ends, PG - 1
+// running sums, the row -- ~8 load instructions in 4 dependent trips, the last two to one line (the binary search through
+// two index levels was ~27 in ~11; the kernel is bound by the number of divergent-address loads).  Same decisions as resample_search on the same
+// numbers: if no running sum of the chunk exceeds t (rounding of the offsets against the sums) the next chunk's first
+// particle is taken, the last particle at the end of the population.  `row` receives the address of the drawn particle's row.
 template <int PG>
-__device__ __forceinline__ int64_t packed_search(const double t, const double *B, const int64_t nb, const double *__restrict__ gc,
-                                                 const double *__restrict__ ge, const double *__restrict__ pk,
-                                                 const int64_t n, double (&L)[16], int &slot) {
+__device__ __forceinline__ int64_t packed_search(const double t, const double total, const double *B, const int64_t nb,
+                                                 const int32_t *__restrict__ guide, const double *__restrict__ ge,
+                                                 const double *__restrict__ pk, const int64_t n, const double *&row) {
   constexpr int kStride = 16 / PG;
   constexpr int64_t kLinesPerChunk = kScanChunk / PG;
-  constexpr int kGroupsOfChunk = (int)(kLinesPerChunk / 16);      // 16, 32 or 64 entries of gc per chunk
+  const int64_t n_lines = (n + PG - 1) / PG;
+  int64_t s = guide[guide_bucket(t, total, n_lines)];     // in flight during the search of the offsets
   int64_t blo = 0, bhi = nb;
   while (blo < bhi) {
     const int64_t mid = blo + ((bhi - blo) >> 1);
     if (B[mid] > t) bhi = mid; else blo = mid + 1;
   }
   const int64_t chunk = blo - 1;
-  const int64_t n_lines = (n + PG - 1) / PG;
   const int64_t l0 = chunk * kLinesPerChunk;
   int64_t end = l0 + kLinesPerChunk;
   if (end > n_lines) end = n_lines;
-  // coarse: first 16-line group of the chunk whose end exceeds t (the chunk's last group may be partial: its end is the
-  // population's last particle).  More than 16 groups per chunk: halve by the last entry of the lower half first.
-  const int64_t gend = (end + 15) >> 4;
-  int64_t gbase = l0 >> 4;
-  int nwin = kGroupsOfChunk / 16;
-  while (nwin > 1) {
-    const int half = nwin >> 1;
-    const int64_t probe = gbase + 16 * half - 1;
-    if (probe < gend && !(gc[probe] > t)) { gbase += 16 * half; nwin -= half; } else nwin = half;
+  s = s < l0 ? l0 : (s > end - 1 ? end - 1 : s);
+  const double e_prev = s > l0 ? ge[s - 1] : -INFINITY;
+  double e_s = ge[s];
+  if (e_prev > t) {                                       // the guess lies behind the line: walk back
+    s -= 1;
+    while (s > l0 && ge[s - 1] > t) s -= 1;
+  } else {
+    int walked = 0;
+    while (!(e_s > t) && s + 1 < end) {
+      if (++walked > 8) {                                 // a bucket full of all-but-weightless lines: bisect the rest of the chunk
+        int64_t lo = s + 1, hi = end;                     // first line in [lo, hi) whose end exceeds t, or `end`
+        while (lo < hi) {
+          const int64_t mid = lo + ((hi - lo) >> 1);
+          if (ge[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        s = lo;
+        e_s = s < end ? INFINITY : -INFINITY;
+        break;
+      }
+      s += 1;
+      e_s = ge[s];
+    }
+    if (!(e_s > t)) s = end;                              // no line of the chunk exceeds t
   }
-  load_line(gc + gbase, L);
-  int cnt = 0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) cnt += (gbase + q < gend && !(L[q] > t)) ? 1 : 0;
-  const int64_t glo = gbase + cnt;
   int64_t idx;
-  if (glo < gend) {
-    const int64_t lo = glo << 4;
-    int64_t hi = lo + 16;
-    if (hi > end) hi = end;
-    load_line(ge + lo, L);
-    int lc = 0;
+  if (s < end) {
+    // the slot: the COUNT of the running sums of the line's first PG - 1 slots that do not exceed t (independent reads;
+    // the line's end exceeds t, so its last slot needs no test)
+    double cw[PG > 1 ? PG - 1 : 1];
 #pragma unroll
-    for (int q = 0; q < 15; ++q) lc += (lo + q < hi - 1 && !(L[q] > t)) ? 1 : 0;   // the group's end exceeds t: its last line needs no test
-    const int64_t line = lo + lc;
-    load_line(pk + line * 16, L);
-    slot = 0;
+    for (int q = 0; q < PG - 1; ++q) cw[q] = pk[s * 16 + q * kStride];
+    int slot = 0;
 #pragma unroll
-    for (int q = 0; q < PG - 1; ++q) slot += !(L[q * kStride] > t) ? 1 : 0;          // likewise the line's last slot
-    idx = line * PG + slot;
-    if (idx >= n) { idx = n - 1; slot = (int)(idx - line * PG); }                     // (the last line; its empty slots hold +inf)
+    for (int q = 0; q < PG - 1; ++q) slot += !(cw[q] > t) ? 1 : 0;
+    idx = s * PG + slot;
+    if (idx >= n) idx = n - 1;                            // (the last line; its empty slots hold +inf)
   } else {
     idx = (chunk + 1) * (int64_t)kScanChunk;
     if (idx >= n) idx = n - 1;
-    const int64_t line = idx / PG;
-    slot = (int)(idx - line * PG);
-    load_line(pk + line * 16, L);
   }
+  const int64_t line = idx / PG;
+  row = pk + line * 16 + (idx - line * PG) * kStride + 1;
   return idx;
-}
-
-// value `k` of the row in slot `slot` of the packed line L (k and PG at compile time: a select chain, no indexed registers)
-template <int PG>
-__device__ __forceinline__ double line_value(const double (&L)[16], const int slot, const int k) {
-  constexpr int kStride = 16 / PG;
-  double v = L[1 + k];
-#pragma unroll
-  for (int q = 1; q < PG; ++q) {
-    int hit = slot == q;
-    asm volatile("" : "+v"(hit));     // opaque: related conditions would be folded into an INDEXED read of a scratch copy of L
-    v = hit ? L[q * kStride + 1 + k] : v;
-  }
-  return v;
 }
 
 constexpr int packed_per_line(int row_len) {
@@ -976,9 +981,9 @@ constexpr int packed_per_line(int row_len) {
 // moment sums of the RESAMPLED population (what k_stats would compute in a pass of its own: Sigma, eps and the history
 // row are taken from the resampled population, :348-353) come out of the same kernel, in the same per-workgroup order.
 template <int D, int S>
-__global__ void __launch_bounds__(kBlock, 4)     // up to 128 VGPRs: a 16-double line is live across the search
+__global__ void __launch_bounds__(kBlock)
 k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, const double *__restrict__ ge,
-                        const double *__restrict__ gc, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
+                        const int32_t *__restrict__ guide, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb, const double *__restrict__ totals,
                         const uint64_t iter, const PopPtrs dst, const ControlBlock *__restrict__ cb,
                         double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
@@ -996,17 +1001,17 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
   if (li < dst.n_local) {
     const uint64_t gid = (uint64_t)(dst.gid0 + li);
     const u32x4 w = stream_block(seed, gid, PURPOSE_RESAMPLE, iter, 0);
-    const double t = u52(w.x, w.y) * totals[0];
+    const double total = totals[0];
+    const double t = u52(w.x, w.y) * total;
     constexpr int PG = packed_per_line(D + S);
-    double L[16];
-    int slot;
-    (void)packed_search<PG>(t, B, nb, gc, ge, pk, n, L, slot);
+    const double *row;
+    (void)packed_search<PG>(t, total, B, nb, guide, ge, pk, n, row);
     double th[D], u[S], rho[S];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = line_value<PG>(L, slot, k); dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
+    for (int k = 0; k < D; ++k) { th[k] = row[k]; dst.pop[(int64_t)k * dst.cap + li] = th[k]; }
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      u[j] = line_value<PG>(L, slot, D + j);
+      u[j] = row[D + j];
       dst.pop[(int64_t)(D + j) * dst.cap + li] = u[j];
       rho[j] = dst.rho[(int64_t)j * dst.cap + li];                        // rho stays where it is (:131-132)
     }
@@ -1018,7 +1023,7 @@ k_resample_gather_stats(const uint64_t seed, const double *__restrict__ pk, cons
 // the same without the sums, d and s at run time (host-callback and source-compiled simulators)
 __global__ void __launch_bounds__(kBlock)
 k_resample_gather_packed(const uint64_t seed, const int row_len, const double *__restrict__ pk, const double *__restrict__ ge,
-                         const double *__restrict__ gc, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb,
+                         const int32_t *__restrict__ guide, const int pg, const int64_t n, const double *__restrict__ bs, const int64_t nb,
                          const double *__restrict__ totals, const uint64_t iter, const PopPtrs dst) {
   extern __shared__ double bs_lds[];
   const bool in_lds = nb <= kGatherCoarseMax;
@@ -1030,14 +1035,12 @@ k_resample_gather_packed(const uint64_t seed, const int row_len, const double *_
   const int64_t li = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (li >= dst.n_local) return;
   const u32x4 w = stream_block(seed, (uint64_t)(dst.gid0 + li), PURPOSE_RESAMPLE, iter, 0);
-  const double t = u52(w.x, w.y) * totals[0];
-  double L[16];
-  int slot;
-  const int64_t idx = pg == 4 ? packed_search<4>(t, B, nb, gc, ge, pk, n, L, slot)
-                    : pg == 2 ? packed_search<2>(t, B, nb, gc, ge, pk, n, L, slot)
-                              : packed_search<1>(t, B, nb, gc, ge, pk, n, L, slot);
-  const int64_t line = idx / pg;
-  const double *row = pk + line * 16 + (idx - line * pg) * (16 / pg) + 1;      // the line just fetched: L1 hits
+  const double total = totals[0];
+  const double t = u52(w.x, w.y) * total;
+  const double *row;
+  if (pg == 4) (void)packed_search<4>(t, total, B, nb, guide, ge, pk, n, row);
+  else if (pg == 2) (void)packed_search<2>(t, total, B, nb, guide, ge, pk, n, row);
+  else (void)packed_search<1>(t, total, B, nb, guide, ge, pk, n, row);
   for (int r = 0; r < row_len; ++r) dst.pop[(int64_t)r * dst.cap + li] = row[r];
 }
 
@@ -1432,7 +1435,8 @@ int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_
   return SABC_LAUNCH_RC();
 }
 
-// doubles of the packed-line scratch of launch_resample_local for a shard of n particles: lines of 16 doubles + line ends
+// doubles of the packed-line scratch of launch_resample_local for a shard of n particles:
+// packed lines | line ends (+ two of +inf, rounded up to a line) | the guide (n_lines + 2 int32)
 static inline int64_t pack_ge_doubles(int64_t lines) { return ((lines + 8 + 15) / 16) * 16; }
 
 int64_t resample_pack_doubles(int row_len, int64_t n) {
@@ -1440,9 +1444,7 @@ int64_t resample_pack_doubles(int row_len, int64_t n) {
   const int pg = per >= 4 ? 4 : per >= 2 ? 2 : per >= 1 ? 1 : 0;
   if (pg == 0) return 0;
   const int64_t lines = (n + pg - 1) / pg;
-  const int64_t nb = (n + kScanChunk - 1) / kScanChunk;
-  // packed lines | line ends (a multiple of 16, so that gc starts a line) | coarse ends: whole 16-entry windows are read
-  return lines * 16 + pack_ge_doubles(lines) + nb * (kScanChunk / pg / 16) + 32;
+  return lines * 16 + pack_ge_doubles(lines) + (lines + 2 + 1) / 2 + 32;
 }
 
 // One shard: weights (fused into the first scan pass), scan, staging copy, draw + gather (+ the moment sums of the
@@ -1466,7 +1468,8 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
   std::memset(&pa, 0, sizeof(pa));
   if (pg > 0 && pack) {
     const int64_t lines = (n + pg - 1) / pg;
-    pa.pk = pack; pa.ge = pack + lines * 16; pa.gc = pa.ge + pack_ge_doubles(lines); pa.row_len = rl; pa.pg = pg;
+    pa.pk = pack; pa.ge = pack + lines * 16; pa.guide = reinterpret_cast<int32_t *>(pa.ge + pack_ge_doubles(lines));
+    pa.totals = totals; pa.row_len = rl; pa.pg = pg;
   }
   hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
@@ -1482,14 +1485,14 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
 #define CALL(M, D, S)                                                                                                    \
   do {                                                                                                                   \
     hipLaunchKernelGGL((k_resample_gather_stats<D, S>), grid, block, lds, stream, m.seed, (const double *)pa.pk,         \
-                       (const double *)pa.ge, (const double *)pa.gc, pg, n, (const double *)bs, nb,                      \
+                       (const double *)pa.ge, (const int32_t *)pa.guide, pg, n, (const double *)bs, nb,                  \
                        (const double *)totals, iter, dst, cb, partials);                                                 \
     *stats_rows = n_blocks(n);                                                                                           \
   } while (0)
   if (m.model_id == SABC_MODEL_GK) { CALL(SABC_MODEL_GK, 4, 4); return SABC_LAUNCH_RC(); }
   if (m.model_id == SABC_MODEL_HOST || m.model_id == SABC_MODEL_USER) {
     hipLaunchKernelGGL(k_resample_gather_packed, grid, block, lds, stream, m.seed, rl, (const double *)pa.pk,
-                       (const double *)pa.ge, (const double *)pa.gc, pg, n, (const double *)bs, nb, (const double *)totals, iter,
+                       (const double *)pa.ge, (const int32_t *)pa.guide, pg, n, (const double *)bs, nb, (const double *)totals, iter,
                        dst);
     return SABC_LAUNCH_RC();
   }
