@@ -122,3 +122,25 @@ def test_resample_draws_at_ragged_sizes(S, O, gpu, name):
         # a draw that picked a neighbouring particle would differ in the first digits
         np.testing.assert_allclose(θ, run.theta, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(np.atleast_2d(res.u.T), run.u, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["gauss1_2stats", "gauss2d_cfg3"])
+def test_resample_with_all_but_weightless_particles(S, O, gpu, name):
+    """δ = 400 in w = exp(-δ Σ u/ū) (:126-127) leaves a few percent of the particles with all of the weight: most packed lines
+    then add nothing to the running sum, whole runs of them share one bucket of the guide table, and a draw's walk from
+    its guide entry falls back to bisecting the chunk (kernels.hip: packed_search).  A resample after every update."""
+    from tests.cases import oracle_config
+    n, k, delta = 20_011, 5, 400.0
+    d = len(MODELS[name]["prior"])
+    model, prior = hip_model_prior(S, name)
+    res = S.sabc(model, prior, n_particles=n, n_simulation=(k + 1) * n, proposal=hip_proposal(S, "rw", d), resample=1e-9, δ=delta,
+                 seed=SEED)
+    run = O.OracleRun(oracle_config(O, name, n, delta=delta))
+    run.initialize((k + 1) * n)
+    run.update(O.make_update_args(n_simulation=k * n, proposal=oracle_proposal(O, "rw", d), n_para=d, n_particles=n, resample=1e-9,
+                                  delta=delta))
+    assert res.state.n_resampling == run.counters["n_resampling"] == 1 + k
+    assert res.state.n_accept == run.counters["n_accept"]
+    θ = res.population.T if d > 1 else res.population[None, :]
+    np.testing.assert_allclose(θ, run.theta, rtol=1e-9, atol=1e-12)
+    assert len(np.unique(θ[0])) < 0.2 * n              # the weights really were that uneven
