@@ -34,7 +34,12 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
     return true;
   }
 
-  if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK) {            // update_proposal!
+  if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK && d >= 2 && d <= 4) {
+    const bool ok = d == 2 ? hostmath::rw_proposal_from_sums<2>(S, Q, n, a.prop_p0, cb.sigma, cb.chol)
+                  : d == 3 ? hostmath::rw_proposal_from_sums<3>(S, Q, n, a.prop_p0, cb.sigma, cb.chol)
+                           : hostmath::rw_proposal_from_sums<4>(S, Q, n, a.prop_p0, cb.sigma, cb.chol);
+    if (!ok) cb.error = SABC_ERR_NOT_POSDEF;                                         // MvNormal(...), :42
+  } else if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK) {     // update_proposal!
     double cov[kMaxPara * kMaxPara];
     hostmath::cov_from_sums(S, Q, d, n, cov);
     if (d == 1) {

@@ -127,5 +127,55 @@ SABC_HD inline void cov_from_sums(const double *S, const double *Q, int d, doubl
     }
 }
 
+// update_proposal!(::RandomWalk) for d > 1 (proposals.jl:46-48 + the Cholesky factor inside MvNormal(...), :42) with the
+// dimension at compile time: the sums are read once, everything in between lives in registers, Sigma and its factor are
+// written once.  The single control lane otherwise walks d x d arrays it cannot keep in registers (run-time d), every
+// element a dependent trip to scratch or LDS -- 18 us per update at d = 4.  Same expressions in the same order as
+// cov_from_sums / cholesky: the same numbers.
+template <int D>
+SABC_HD inline bool rw_proposal_from_sums(const double *S_in, const double *Q_in, double n, double beta, double *sigma_out,
+                                          double *chol_out) {
+  double S[D], Q[D * (D + 1) / 2], sg[D * D], l[D * D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) S[k] = S_in[k];
+#pragma unroll
+  for (int q = 0; q < D * (D + 1) / 2; ++q) Q[q] = Q_in[q];
+  {
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+#pragma unroll
+      for (int m = 0; m <= k; ++m, ++q) {
+        const double c = (Q[q] - S[k] * S[m] / n) / (n - 1.0);
+        sg[k * D + m] = beta * (c + (k == m ? 1e-8 : 0.0));                  // proposals.jl:47
+        sg[m * D + k] = sg[k * D + m];
+      }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) l[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double sum = sg[i * D + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) sum -= l[i * D + k] * l[j * D + k];
+      if (i == j) {
+        if (!(sum > 0.0)) ok = false;
+        l[i * D + i] = sqrt(sum);
+      } else {
+        l[i * D + j] = sum / l[j * D + j];
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) sigma_out[i] = sg[i];
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) chol_out[i] = l[i];
+  }
+  return ok;
+}
+
 }  // namespace hostmath
 }  // namespace sabc
