@@ -478,7 +478,7 @@ __device__ __forceinline__ void bitonic_sort128_x2(double &a0, double &a1, doubl
 // is (1 + z^2)^k [(1 + c t)(1 + 2 k z^2 / (1 + z^2)) + c w sech^2 w] with w = g z / 2, t = tanh w, and
 // tanh a + a sech^2 a <= 1.1997, so the bracket is >= 1 - 1.1997 c > 0 for every g.  Then the order statistics of the
 // simulated data are the quantile function OF the order statistics of the normals: sort(x)[r] = Q(sort(z)[r]) -- the
-// 128 normals are sorted and Q is evaluated at the S wanted ranks only (by the caller, for 16 particles x 4 ranks in one
+// 128 normals are sorted and Q is evaluated at the S wanted ranks only (by the caller, for 16 particles x 4 ranks per
 // pass over the lanes) instead of 128 times per particle.  Outside that region the data themselves are sorted, as the
 // reference does (the oracle always does).  Rounding can order two normals closer than ~1e-14 differently from their
 // images; the order statistic then differs in its last digits only.

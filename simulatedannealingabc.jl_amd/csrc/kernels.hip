@@ -260,10 +260,10 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
 }
 
 // one wave per row of theta: used for the prior sample at initialization and for sabc_op_simulate.
-// Same phase structure as k_update_gk: lanes 0..15 draw / load the parameters of the wave's 16 particles in parallel
+// Same phase structure as k_update_gk: one lane per particle draws / loads the parameters of the wave's particles in parallel
 // (the prior draw is four Philox blocks + Box-Muller pairs per particle: done by all 64 lanes for one particle at a
 // time it cost more than the simulation itself -- 1.8 ms for the 1e6 simulations k_update_gk does in 0.7 ms), the whole
-// wave then simulates them one after the other, lanes 0..15 store.
+// wave then simulates them one after the other, the particles' lanes store.
 __global__ void __launch_bounds__(kBlock)
 k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int64_t n, const int64_t stride,
               const uint64_t pid0, const uint64_t iter, const int sample_prior, double *__restrict__ theta_out,
