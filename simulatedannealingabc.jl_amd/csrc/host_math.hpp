@@ -69,14 +69,34 @@ SABC_HD inline double multi_eps_beta(double ub) {
   if (mirror) ub = 1.0 - ub;
   double lo = 0.0, hi = 1.0 / ub, b = hi;
   for (int it = 0; it < 200; ++it) {
-    const double f = tilted_mean(b) - ub;
+    // tilted_mean(b) and tilted_mean_deriv(b) from ONE expm1 (the same expressions as the two functions above: on the
+    // single control lane an expm1 is a few hundred dependent instructions)
+    double tm, td;
+    if (fabs(b) < 1e-2) {
+      tm = tilted_mean(b);
+      td = tilted_mean_deriv(b);
+    } else {
+      const double em = expm1(b);
+      tm = 1.0 / b - 1.0 / em;
+      td = -1.0 / (b * b) + (em + 1.0) / (em * em);
+    }
+    const double f = tm - ub;
     if (f > 0.0) lo = b; else hi = b;
-    double bn = b - f / tilted_mean_deriv(b);
+    double bn = b - f / td;
     if (!(bn > lo && bn < hi)) bn = lo + 0.5 * (hi - lo);
     if (bn == b || fabs(bn - b) <= 4.0 * DBL_EPSILON * fabs(bn)) { b = bn; break; }
     b = bn;
   }
   return mirror ? -b : b;
+}
+
+// x^(s/2) for x > 0 and a small integer s: sqrt and s - 1 multiplications (pow() is several hundred dependent instructions
+// on the control lane and :110-112 need s^2 + s of them per update; the result differs from pow's in the last digits)
+SABC_HD inline double pow_half_int(double x, int s) {
+  const double r = sqrt(x);
+  double p = 1.0;
+  for (int i = 0; i < s; ++i) p *= r;
+  return p;
 }
 
 // update_epsilon_multi_eps (:100-117); returns false when some ubar_i <= eps() (:107-109)
@@ -90,10 +110,10 @@ SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_o
     double num = 1.0, prodq = 1.0;
     for (int j = 0; j < s; ++j) {
       const double q = ubar[j] / ui;                 // :110
-      num += pow(q, s / 2.0);                   // :111
+      num += pow_half_int(q, s);                // :111  q^(s/2)
       prodq *= q;
     }
-    const double den = cn * (s + 1) * pow(ui, 1.0 + s / 2.0) * prodq;   // :112
+    const double den = cn * (s + 1) * (ui * pow_half_int(ui, s)) * prodq;   // :112  ui^(1 + s/2)
     eps_out[i] = 1.0 / (multi_eps_beta(ui) + v * num / den);                 // :113-114
   }
   return true;
