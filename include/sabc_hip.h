@@ -93,7 +93,8 @@ typedef struct {
   double  prior_c[SABC_MAX_PARA]; /* truncated Normal: lower bound (others: unused) */
   double  prior_d[SABC_MAX_PARA]; /* truncated Normal: upper bound (others: unused) */
   int32_t prior_joint;            /* 0: product of the univariate families above | 1: MvNormal(mu, Sigma) over all n_para
-                                     dimensions: mu = prior_a[0..d), Sigma = L L' with L = prior_chol */
+                                     dimensions: mu = prior_a[0..d), Sigma = L L' with L = prior_chol | 2: host callbacks
+                                     (sabc_set_host_prior; SABC_MODEL_HOST only; prior_kind etc. unused) */
   int32_t reserved2;
   double  prior_chol[SABC_MAX_PARA * SABC_MAX_PARA];   /* prior_joint = 1: lower Cholesky factor of Sigma, row-major d x d */
   int32_t algorithm;              /* SABC_ALG_* */
@@ -136,6 +137,16 @@ typedef int (*sabc_alltoallv_fn)(void *ctx, const void *send, const int64_t *sen
 typedef int (*sabc_simulate_fn)(void *ctx, const double *theta, const int64_t *ids, int64_t m, uint64_t iter,
                                 double *rho_out);
 
+/* SimulatedAnnealingABC.jl:151 takes ANY Distributions.Distribution as prior.  One that is not among the families of
+   sabc_config can be supplied as two host callbacks -- sabc_config::prior_joint = 2, together with SABC_MODEL_HOST only (the
+   per-particle body is then already cut at the host):
+     sample:  rand(prior) for the m particles `ids` (:174), theta_out column-major m x d;
+     logpdf:  logpdf(prior, theta) for m parameter vectors (:314, :318), theta column-major m x d; -inf outside the support.
+   Both return 0 on success.  The library calls `logpdf` once per (half-)batch of an update with the proposals followed by
+   the current particles (m = 2 x batch). */
+typedef int (*sabc_prior_sample_fn)(void *ctx, int64_t m, const int64_t *ids, double *theta_out);
+typedef int (*sabc_prior_logpdf_fn)(void *ctx, int64_t m, const double *theta, double *logpdf_out);
+
 SABC_API int         sabc_abi_version(void);
 SABC_API const char *sabc_last_global_error(void);          /* for failures with no handle */
 SABC_API int         sabc_device_count(void);
@@ -152,6 +163,8 @@ SABC_API int         sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn);
 /* bytes that landed in this shard's receive buffers through the collectives since sabc_create */
 SABC_API int64_t     sabc_comm_bytes(const sabc_handle *h);
 SABC_API int         sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx);   /* SABC_MODEL_HOST */
+SABC_API int         sabc_set_host_prior(sabc_handle *h, sabc_prior_sample_fn sample, sabc_prior_logpdf_fn logpdf,
+                                         void *ctx);                                          /* prior_joint = 2 */
 /* SABC_MODEL_USER: the user's f_dist (SimulatedAnnealingABC.jl:164,175,315) as device code.  `hip_source` is HIP C++
    defining, at global scope,
        __device__ void sabc_user_simulate(const double *theta,        // the d parameters

@@ -65,6 +65,8 @@ ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)
                            C.c_int32, C.c_void_p)
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))
+PRIOR_SAMPLE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double))
+PRIOR_LOGPDF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double))
 
 
 def sources_newer_than_lib() -> bool:
@@ -127,6 +129,7 @@ def bind(L, strict=True):
         "sabc_set_alltoallv": ([vp, ALLTOALLV_FN], C.c_int),
         "sabc_comm_bytes": ([vp], C.c_int64),
         "sabc_set_host_simulator": ([vp, SIMULATE_FN, vp], C.c_int),
+        "sabc_set_host_prior": ([vp, PRIOR_SAMPLE_FN, PRIOR_LOGPDF_FN, vp], C.c_int),
         "sabc_register_device_simulator": ([vp, C.c_char_p], C.c_int),
         "sabc_op_compile_device_simulator": ([C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),

@@ -136,12 +136,31 @@ def _dist_env(distributed):
     return 0, 1, None
 
 
+def as_prior(prior, seed=None):
+    """The reference takes ANY Distributions.Distribution (:151).  Here: the families that exist as data, or -- next to a
+    host-callable f_dist -- a HostPrior / a scipy.stats frozen distribution / a list of univariate ones (host callbacks)."""
+    if isinstance(prior, Distribution):
+        return prior
+    from .distributions import from_scipy
+    try:
+        return from_scipy(prior, seed)
+    except TypeError:
+        raise TypeError("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal), "
+                        "product_distribution([...]) of those, MvNormal, HostPrior, or a scipy.stats frozen "
+                        "distribution (or a list of univariate ones)") from None
+
+
 def as_host_distance(f_dist, prior, args=(), kwargs=None):
     """Wrap a plain callable as a HostDistance.  Like the reference (:163-165) the number of statistics is
     found by calling it once on a draw from the prior; that call is not counted as a simulation (:213-214).
     The wrapper lives on the SABCresult it initialises (`update_population_` finds it there): nothing is cached
     per process, so a prior of another dimension can never meet a stale wrapper and no closure outlives its result."""
     rng = np.random.default_rng()
+    if getattr(prior, "host_prior", False):
+        θ = np.asarray(prior.sample(np.array([0], dtype=np.int64)), dtype=np.float64).reshape(-1)
+        probe = f_dist(float(θ[0]) if prior.univariate else θ, *args, **(kwargs or {}))
+        return HostDistance(f_dist, n_stats=len(np.atleast_1d(np.asarray(probe, dtype=np.float64))), n_para=len(prior),
+                            univariate=prior.univariate, args=args, kwargs=kwargs)
 
     def truncnorm(a, b, c, d):
         from scipy import stats
@@ -190,9 +209,10 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     alg = str(algorithm).lstrip(":")
     if alg not in _ALGORITHMS:                                                # :462-464
         raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
-    if not isinstance(prior, Distribution):
-        raise TypeError("prior must be Normal, Uniform, Exponential, LogNormal, Gamma, Beta, truncated(Normal) or "
-                        "product_distribution([...]) of those")
+    prior = as_prior(prior, seed)
+    if getattr(prior, "host_prior", False) and isinstance(f_dist, DeviceDistance) and not isinstance(f_dist, HostDistance):
+        raise TypeError("a host-callback prior (HostPrior / scipy.stats) needs a host-callable f_dist: a device-coded simulator "
+                        "evaluates the prior inside its fused kernel and needs it as data")
     if not isinstance(f_dist, DeviceDistance):
         if not callable(f_dist):
             raise TypeError("f_dist must be a DeviceDistance or a callable f_dist(θ, *args, **kwargs)")
@@ -216,6 +236,8 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
                 t = t.cuda(device)
             dist.broadcast(t, 0)
             seed = int(t.item())
+    if getattr(prior, "seed_box", None) is not None and prior.seed_box["seed"] is None:
+        prior.seed_box["seed"] = seed % (1 << 62)        # a scipy prior draws with the run's seed
     h = SabcHandle(n_particles=n_particles, model=f_dist, prior=prior, algorithm=_ALGORITHMS[alg], v=v, delta=δ,
                    seed=seed, device=device, rank=rank, world=world)
     if dist is not None:
@@ -247,6 +269,11 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         f_dist, args, kwargs = res._model, (), {}
     if args or kwargs:
         raise TypeError("a DeviceDistance takes its data at construction; extra args/kwargs are not forwarded")
+    if getattr(res._prior, "host_prior", False):
+        # a host-callback prior is code, not data: it has to be the object (or the scipy distribution) of the initialisation
+        if prior is not res._prior and prior is not getattr(res._prior, "source", None):
+            raise ValueError("prior differs from the one this SABCresult was initialised with")
+        prior = res._prior
     if f_dist is not res._model or prior is not res._prior:
         if type(f_dist) is not type(res._model) or list(f_dist.params) != list(res._model.params) or \
                 prior.descriptors() != res._prior.descriptors() or \
@@ -326,6 +353,9 @@ def load_result(path, f_dist, prior, device=0) -> SABCresult:
     z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
     alg = str(z["algorithm"])
     n = int(z["n_particles"])
+    prior = as_prior(prior, int(z["seed"]) % (1 << 62))
+    if not isinstance(f_dist, DeviceDistance) and callable(f_dist):
+        f_dist = as_host_distance(f_dist, prior)
     h = SabcHandle(n_particles=n, model=f_dist, prior=prior, algorithm=_ALGORITHMS[alg], seed=int(z["seed"]), device=device)
     pop = z["population"]
     th = pop.reshape(1, -1) if prior.univariate else np.ascontiguousarray(pop.T)
@@ -355,6 +385,7 @@ def sabc(f_dist, prior, *args, n_particles=100, n_simulation=10_000, algorithm="
     alg = str(algorithm).lstrip(":")
     if alg not in _ALGORITHMS:                                                        # :462-464
         raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
+    prior = as_prior(prior, seed)
     if proposal is None:
         proposal = DifferentialEvolution(n_para=len(prior))                           # :454
     if resample is None:

@@ -286,6 +286,13 @@ int sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx) {
   return 0;
 }
 
+int sabc_set_host_prior(sabc_handle *h, sabc_prior_sample_fn sample, sabc_prior_logpdf_fn logpdf, void *ctx) {
+  if (!h || !sample || !logpdf) return hset(h, SABC_ERR_BAD_CONFIG, "null host prior callback");
+  if (h->eng->model().prior_joint != 2) return hset(h, SABC_ERR_BAD_CONFIG, "the handle was not created with prior_joint = 2");
+  h->be->set_host_prior(sample, logpdf, ctx);
+  return 0;
+}
+
 int sabc_comm_unique_id(void *out_128b) {
   RcclApi *a = rccl_api();
   if (!a) { g_err = "librccl.so could not be loaded"; return SABC_ERR_COMM; }

@@ -120,7 +120,7 @@ __device__ __forceinline__ void mvnormal_sample(const ModelDesc &m, int d, uint6
 
 template <int D>
 __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double *th) {
-  if (D > 1 && m.prior_joint) return mvnormal_logpdf(m, D, th);
+  if (D > 1 && m.prior_joint == 1) return mvnormal_logpdf(m, D, th);
   double lp = 0.0;
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -133,7 +133,7 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
 // rand(prior) at :174
 template <int D>
 __device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
-  if (D > 1 && m.prior_joint) { mvnormal_sample(m, D, pid, th); return; }
+  if (D > 1 && m.prior_joint == 1) { mvnormal_sample(m, D, pid, th); return; }
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = prior_sample_dim(m, k, pid);
 }

@@ -93,7 +93,9 @@ int Engine::validate() {
       ok = false;
   }
   if (!ok) return fail(SABC_ERR_BAD_CONFIG, "unknown model id or model parameters inconsistent with n_para / n_stats");
-  if (cfg_.prior_joint != 0 && cfg_.prior_joint != 1) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
+  if (cfg_.prior_joint < 0 || cfg_.prior_joint > 2) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
+  if (cfg_.prior_joint == 2 && cfg_.model_id != SABC_MODEL_HOST)
+    return fail(SABC_ERR_BAD_CONFIG, "a host-callback prior needs a host-callback simulator (SABC_MODEL_HOST)");
   if (cfg_.prior_joint == 1) {
     for (int k = 0; k < d; ++k)
       if (!(cfg_.prior_chol[k * d + k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "MvNormal prior needs a Cholesky factor with a positive diagonal");

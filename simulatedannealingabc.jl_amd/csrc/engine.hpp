@@ -45,6 +45,7 @@ class Backend {
   virtual int to_host(double *dst_host, const double *src, int64_t n) = 0;
   // host-simulator mode (SABC_MODEL_HOST): f_dist is a host callback; a backend without it says so
   virtual int set_host_simulator(sabc_simulate_fn, void *) { return -1; }
+  virtual int set_host_prior(sabc_prior_sample_fn, sabc_prior_logpdf_fn, void *) { return -1; }   // prior_joint = 2
   virtual int host_prior_simulate() { return -1; }                      // :172-179 with f_dist on the host
   virtual int host_update_range(const StepArgs &, const PartnerView &, int64_t, int64_t) { return -1; }   // :308-331
   virtual int host_stats(int64_t *) { return -1; }                      // moment sums + the update's accept count

@@ -43,6 +43,7 @@ HipBackend::~HipBackend() {
   if (host_aux_dev_) (void)hipFree(host_aux_dev_);
   if (host_rho_dev_) (void)hipFree(host_rho_dev_);
   if (host_acc_dev_) (void)hipFree(host_acc_dev_);
+  if (host_lpcur_dev_) (void)hipFree(host_lpcur_dev_);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (meta_dev_) (void)hipFree(meta_dev_);
   if (cb_dev_) (void)hipFree(cb_dev_);
@@ -242,6 +243,7 @@ int HipBackend::ensure_host_buffers() {
   HB_CHECK(hipMalloc((void **)&host_aux_dev_, 2 * cap * sizeof(double)), "hipMalloc(host aux)");
   HB_CHECK(hipMalloc((void **)&host_rho_dev_, (size_t)m_.s * cap * sizeof(double)), "hipMalloc(host rho)");
   HB_CHECK(hipMalloc((void **)&host_acc_dev_, sizeof(unsigned long long)), "hipMalloc(host accept counter)");
+  if (m_.prior_joint == 2) HB_CHECK(hipMalloc((void **)&host_lpcur_dev_, cap * sizeof(double)), "hipMalloc(host log prior)");
   HB_CHECK(hipMemsetAsync(host_acc_dev_, 0, sizeof(unsigned long long), stream_), "hipMemset");
   return 0;
 }
@@ -251,12 +253,18 @@ int HipBackend::host_prior_simulate() {
   if (ensure_host_buffers()) return -1;
   const int d = m_.d, s = m_.s;
   const int64_t n = sh_.n_local;
-  HB_LAUNCH(launch_host_prior(m_, pop_ptrs(cur_), stream_), "k_host_prior");
   std::vector<double> th((size_t)(d * n)), rho((size_t)(s * n), 0.0);
   std::vector<int64_t> ids((size_t)n);
   for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = sh_.gid0 + i;
   const size_t w = (size_t)n * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
-  if (n > 0) HB_CHECK(hipMemcpy2DAsync(th.data(), w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
+  if (m_.prior_joint == 2) {                            // rand(prior) on the host (:174), theta uploaded
+    if (!prior_sample_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
+    if (n > 0 && prior_sample_fn_(prior_ctx_, n, ids.data(), th.data())) { err_ = "the host prior's sample callback failed"; return -1; }
+    if (n > 0) HB_CHECK(hipMemcpy2DAsync(pop_[cur_], pitch, th.data(), w, w, (size_t)d, hipMemcpyHostToDevice, stream_), "upload theta");
+  } else {
+    HB_LAUNCH(launch_host_prior(m_, pop_ptrs(cur_), stream_), "k_host_prior");
+    if (n > 0) HB_CHECK(hipMemcpy2DAsync(th.data(), w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
+  }
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   if (n > 0 && host_fn_(host_ctx_, th.data(), ids.data(), n, 0, rho.data())) { err_ = "the host simulator (f_dist) failed"; return -1; }
   if (n > 0) HB_CHECK(hipMemcpy2DAsync(rho_, pitch, rho.data(), w, w, (size_t)s, hipMemcpyHostToDevice, stream_), "upload rho");
@@ -275,6 +283,23 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
   HB_CHECK(hipMemcpyAsync(thp.data(), host_thp_dev_, thp.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download proposals");
   HB_CHECK(hipMemcpyAsync(aux.data(), host_aux_dev_, aux.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download aux");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  if (m_.prior_joint == 2) {
+    // logpdf(prior, .) on the host (:314, :318): one call for the proposals followed by the batch's current particles
+    if (!prior_logpdf_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
+    std::vector<double> both((size_t)(2 * cnt * d)), lp((size_t)(2 * cnt), -INFINITY), cur((size_t)(d * cnt));
+    const size_t w = (size_t)cnt * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
+    HB_CHECK(hipMemcpy2DAsync(cur.data(), w, pop_[cur_] + lo, pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
+    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    for (int k = 0; k < d; ++k)
+      for (int64_t t = 0; t < cnt; ++t) {
+        both[(size_t)(k * 2 * cnt + t)] = thp[(size_t)(k * cnt + t)];
+        both[(size_t)(k * 2 * cnt + cnt + t)] = cur[(size_t)(k * cnt + t)];
+      }
+    if (prior_logpdf_fn_(prior_ctx_, 2 * cnt, both.data(), lp.data())) { err_ = "the host prior's logpdf callback failed"; return -1; }
+    for (int64_t t = 0; t < cnt; ++t) aux[(size_t)t] = lp[(size_t)t] == lp[(size_t)t] ? lp[(size_t)t] : -INFINITY;   // NaN: outside
+    HB_CHECK(hipMemcpyAsync(host_aux_dev_, aux.data(), (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream_), "upload log prior");
+    HB_CHECK(hipMemcpyAsync(host_lpcur_dev_, lp.data() + cnt, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream_), "upload log prior");
+  }
   // only proposals inside the prior's support are simulated (:314-315)
   std::vector<int64_t> ids, where;
   for (int64_t t = 0; t < cnt; ++t)
@@ -289,7 +314,7 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
   HB_CHECK(hipMemcpyAsync(host_rho_dev_, rho.data(), rho.size() * sizeof(double), hipMemcpyHostToDevice, stream_), "upload rho");
   prof_begin(SABC_KERNEL_UPDATE);
   HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, host_thp_dev_, host_aux_dev_, host_rho_dev_,
-                               host_acc_dev_, stream_), "k_host_accept");
+                               m_.prior_joint == 2 ? host_lpcur_dev_ : nullptr, host_acc_dev_, stream_), "k_host_accept");
   prof_end(SABC_KERNEL_UPDATE);
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");      // the staging vectors go out of scope
   return 0;
@@ -639,6 +664,7 @@ int HipBackend::cdf_apply_host(const double *rho, int64_t m, double *u_out) {
 }
 
 int HipBackend::prior_host(uint64_t pid0, int64_t n, double *theta_out, double *logpdf_out) {
+  if (m_.prior_joint == 2) { err_ = "sabc_op_prior: the prior of this handle lives in host callbacks"; return -1; }
   if (n <= 0) return 0;
   double *d_th = nullptr, *d_lp = nullptr;
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");

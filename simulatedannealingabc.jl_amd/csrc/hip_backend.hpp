@@ -24,6 +24,10 @@ class HipBackend : public Backend {
   int to_backend(double *dst, const double *src_host, int64_t n) override;
   int to_host(double *dst_host, const double *src, int64_t n) override;
   int set_host_simulator(sabc_simulate_fn fn, void *ctx) override { host_fn_ = fn; host_ctx_ = ctx; return 0; }
+  int set_host_prior(sabc_prior_sample_fn sample, sabc_prior_logpdf_fn logpdf, void *ctx) override {
+    prior_sample_fn_ = sample; prior_logpdf_fn_ = logpdf; prior_ctx_ = ctx;
+    return 0;
+  }
   // SABC_MODEL_USER: compile the simulator source into the update kernels (rtc.hpp); the compiler log goes to error()
   int register_device_simulator(const char *hip_source);
   int host_prior_simulate() override;
@@ -118,6 +122,10 @@ class HipBackend : public Backend {
   std::vector<double> stage_;
   // host-simulator mode
   sabc_simulate_fn host_fn_ = nullptr;
+  sabc_prior_sample_fn prior_sample_fn_ = nullptr;      // prior_joint = 2: rand(prior) / logpdf(prior, .) on the host
+  sabc_prior_logpdf_fn prior_logpdf_fn_ = nullptr;
+  void *prior_ctx_ = nullptr;
+  double *host_lpcur_dev_ = nullptr;                    // log prior of the current particles of a batch (prior_joint = 2)
   void *host_ctx_ = nullptr;
   double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr;
   unsigned long long *host_acc_dev_ = nullptr;

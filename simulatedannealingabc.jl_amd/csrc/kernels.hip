@@ -337,6 +337,7 @@ k_simulate_gk(const ModelDesc m, const double *__restrict__ theta_in, const int6
 // maxima); these kernels are host-bound by construction, so they are written for generality.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double prior_logpdf_rt(const ModelDesc &m, const double *th) {
+  if (m.prior_joint == 2) return 0.0;                  // host-callback prior: the host overwrites this (hip_backend.hip)
   if (m.prior_joint) return mvnormal_logpdf(m, m.d, th);
   double lp = 0.0;
   for (int k = 0; k < m.d; ++k) {
@@ -421,7 +422,8 @@ k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restri
 __global__ void __launch_bounds__(kBlock)
 k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
               const int64_t act_lo, const int64_t act_n, const double *__restrict__ thp_in,
-              const double *__restrict__ aux, const double *__restrict__ rho_prop, unsigned long long *n_accept) {
+              const double *__restrict__ aux, const double *__restrict__ rho_prop, const double *__restrict__ lp_cur,
+              unsigned long long *n_accept) {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   bool accepted = false;
   if (t < act_n) {
@@ -441,7 +443,7 @@ k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restric
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (pp.pop[(int64_t)(d + j) * pp.cap + li] - up[j]) / e;
       }
-      log_accept = lpp - prior_logpdf_rt(m, th) + a + logf;
+      log_accept = lpp - (lp_cur ? lp_cur[t] : prior_logpdf_rt(m, th)) + a + logf;   // (lp_cur: host-callback prior)
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
     accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
@@ -1361,11 +1363,11 @@ int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBloc
 }
 
 int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
-                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop,
+                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop, const double *lp_cur,
                        unsigned long long *n_accept, hipStream_t stream) {
   if (act_n <= 0) return 0;
   hipLaunchKernelGGL(k_host_accept, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, cdf, act_lo, act_n,
-                     thp, aux, rho_prop, n_accept);
+                     thp, aux, rho_prop, lp_cur, n_accept);
   return SABC_LAUNCH_RC();
 }
 

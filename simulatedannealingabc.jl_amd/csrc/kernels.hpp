@@ -136,7 +136,7 @@ int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
 int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
                         int64_t act_lo, int64_t act_n, double *thp, double *aux, hipStream_t stream);
 int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
-                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop,
+                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop, const double *lp_cur,
                        unsigned long long *n_accept, hipStream_t stream);
 int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, unsigned long long *n_accept,
                     hipStream_t stream);

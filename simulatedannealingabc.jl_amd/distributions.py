@@ -197,5 +197,105 @@ class MvNormal(Distribution):
         return f"MvNormal(μ={self.μ.tolist()}, Σ={self.Σ.tolist()})"
 
 
+class HostPrior(Distribution):
+    """ANY prior, as two host callables -- the reference takes any Distributions.Distribution (SimulatedAnnealingABC.jl:151):
+    `sample(ids) -> (m, d)` = rand(prior) for the particles `ids` (:174), `logpdf(Θ (m, d)) -> (m,)` = logpdf(prior, θ)
+    (:314, :318; -inf outside the support).  Only together with a host-callable `f_dist`: the per-particle body is then
+    already cut at the host, and the prior gate joins the simulator there (sabc_set_host_prior).  Proposal, ECDF transform,
+    acceptance, reductions and resampling stay on the GPU."""
+    host_prior = True
+
+    def __init__(self, sample, logpdf, n_para, univariate=None):
+        self.sample, self.logpdf, self.n_para = sample, logpdf, int(n_para)
+        if not 1 <= self.n_para <= _lib.MAX_PARA:
+            raise ValueError(f"1 to {_lib.MAX_PARA} parameters are supported")
+        self._univariate = (self.n_para == 1) if univariate is None else bool(univariate)
+        self.error = None            # an exception raised inside a callback, re-raised by the caller
+
+    @property
+    def univariate(self):
+        return self._univariate
+
+    def __len__(self):
+        return self.n_para
+
+    def descriptors(self):
+        return [(_lib.PRIOR_NORMAL, 0.0, 1.0)] * self.n_para          # placeholders: the library never reads them
+
+    def callbacks(self):
+        import numpy as np
+        d = self.n_para
+
+        def sample_cb(ctx, m, ids, theta_out):
+            try:
+                out = np.ctypeslib.as_array(theta_out, shape=(d, m))
+                x = np.asarray(self.sample(np.ctypeslib.as_array(ids, shape=(m,)).copy()), dtype=np.float64).reshape(m, d)
+                out[...] = x.T
+                return 0
+            except Exception as e:   # never raise through the C frame; the caller re-raises it
+                self.error = e
+                return -1
+
+        def logpdf_cb(ctx, m, theta, lp_out):
+            try:
+                th = np.ctypeslib.as_array(theta, shape=(d, m))
+                out = np.ctypeslib.as_array(lp_out, shape=(m,))
+                out[...] = np.asarray(self.logpdf(np.ascontiguousarray(th.T)), dtype=np.float64).reshape(m)
+                return 0
+            except Exception as e:
+                self.error = e
+                return -1
+
+        return _lib.PRIOR_SAMPLE_FN(sample_cb), _lib.PRIOR_LOGPDF_FN(logpdf_cb)
+
+    def __repr__(self):
+        return f"HostPrior(n_para={self.n_para})"
+
+
+def from_scipy(dist, seed=None):
+    """A scipy.stats frozen distribution (univariate: `stats.cauchy(0, 1)`; multivariate: `stats.multivariate_t(...)`,
+    `stats.dirichlet(...)`, ...) or a list of univariate ones (their product) as a HostPrior.  Draws are keyed by the
+    particle id and `seed` (a sharded run draws the same population as a single shard)."""
+    import numpy as np
+    box = {"seed": seed}            # sabc() fills in the run's seed when none was given here
+    parts = list(dist) if isinstance(dist, (list, tuple)) else None
+    if parts is not None:
+        if not parts or not all(hasattr(p, "logpdf") and hasattr(p, "rvs") for p in parts):
+            raise TypeError("a list prior needs scipy.stats frozen univariate distributions")
+        d = len(parts)
+
+        def sample(ids):
+            out = np.empty((len(ids), d))
+            for r, i in enumerate(ids):
+                rng = np.random.default_rng([int(box["seed"] or 0), int(i)])
+                out[r] = [float(p.rvs(random_state=rng)) for p in parts]
+            return out
+
+        def logpdf(th):
+            return sum(np.asarray(p.logpdf(th[:, k]), dtype=np.float64) for k, p in enumerate(parts))
+
+        hp = HostPrior(sample, logpdf, d, univariate=False)
+        hp.seed_box, hp.source = box, dist
+        return hp
+    if not (hasattr(dist, "logpdf") and hasattr(dist, "rvs")):
+        raise TypeError("prior must be a sabc_amd distribution, a scipy.stats frozen distribution or a list of them")
+    probe = np.atleast_1d(np.asarray(dist.rvs(random_state=np.random.default_rng(0)), dtype=np.float64))
+    d = probe.size
+    univariate = np.ndim(dist.rvs(random_state=np.random.default_rng(0))) == 0
+
+    def sample(ids):
+        out = np.empty((len(ids), d))
+        for r, i in enumerate(ids):
+            out[r] = np.atleast_1d(dist.rvs(random_state=np.random.default_rng([int(box["seed"] or 0), int(i)])))
+        return out
+
+    def logpdf(th):
+        return np.asarray(dist.logpdf(th[:, 0] if univariate else th), dtype=np.float64)
+
+    hp = HostPrior(sample, logpdf, d, univariate=univariate)
+    hp.seed_box, hp.source = box, dist
+    return hp
+
+
 def product_distribution(components):
     return Product(components)

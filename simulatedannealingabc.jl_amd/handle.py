@@ -40,6 +40,8 @@ class SabcHandle:
             for k in range(d):
                 for l in range(k + 1):
                     cfg.prior_chol[k * d + l] = float(L[k, l])
+        if getattr(prior, "host_prior", False):     # any prior, as host callbacks (sabc_set_host_prior)
+            cfg.prior_joint = 2
         cfg.algorithm = int(algorithm)
         cfg.rank, cfg.world = int(rank), int(world)
         cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)
@@ -59,6 +61,14 @@ class SabcHandle:
                 msg = self._L.sabc_last_error(self._h).decode("utf-8", "replace")
                 self.close()
                 raise SABCError(rc, msg)
+        self._host_prior = None
+        if getattr(prior, "host_prior", False):
+            cbs = prior.callbacks()
+            self._keep.extend(cbs)
+            self._host_prior = prior
+            rc = self._L.sabc_set_host_prior(self._h, cbs[0], cbs[1], None)
+            if rc:
+                raise SABCError(rc, self._L.sabc_last_error(self._h).decode("utf-8", "replace"))
         if getattr(model, "model_id", None) == _lib.MODEL_HOST:
             cb = model.callback()
             self._keep.append(cb)
@@ -83,6 +93,9 @@ class SabcHandle:
             pass
 
     def _check(self, rc):
+        if rc and self._host_prior is not None and self._host_prior.error is not None:
+            err, self._host_prior.error = self._host_prior.error, None
+            raise err                     # the exception the prior's sample / logpdf raised inside the host callback
         if rc and self._host_model is not None and self._host_model.error is not None:
             err, self._host_model.error = self._host_model.error, None
             raise err                     # the exception f_dist raised inside the host callback

@@ -12,7 +12,7 @@
 # argument list against the prototypes of include/sabc_hip.h, and the enum values used below.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, MvNormal, UnivariateDistribution
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, MvNormal, UnivariateDistribution, logpdf
 using LinearAlgebra: cholesky, Symmetric
 using ProgressMeter: Progress, next!, finish!          # same progress UI as the reference (:290-292,374)
 import Dates
@@ -182,6 +182,43 @@ function prior_descriptors(d::Distribution)
     [prior_descriptor(c) for c in comps]
 end
 
+# ANY other Distribution (SimulatedAnnealingABC.jl:151): rand(prior) (:174) and logpdf(prior, θ) (:314, :318) stay Julia calls,
+# handed to the library as two host callbacks (sabc_set_host_prior, prior_joint = 2) -- possible next to a host `f_dist` only,
+# where the per-particle body is already cut at the host.
+is_data_prior(d::Distribution) =
+    d isa MvNormal || d isa Union{Normal,Uniform,Exponential,LogNormal,Gamma,Beta,Truncated{<:Normal}} ||
+    ((hasproperty(d, :v) || hasproperty(d, :dists)) &&
+     all(c -> c isa Union{Normal,Uniform,Exponential,LogNormal,Gamma,Beta,Truncated{<:Normal}}, hasproperty(d, :v) ? d.v : d.dists))
+
+function host_prior_callbacks(prior::Distribution)
+    d = length(prior)
+    function sample_cb(ctx::Ptr{Cvoid}, m::Int64, ids::Ptr{Int64}, theta::Ptr{Float64})::Cint
+        try
+            Θ = unsafe_wrap(Array, theta, (Int(m), d))                # column-major m x d
+            for i in 1:m
+                Θ[i, :] .= rand(prior)
+            end
+            return Cint(0)
+        catch
+            return Cint(-1)
+        end
+    end
+    function logpdf_cb(ctx::Ptr{Cvoid}, m::Int64, theta::Ptr{Float64}, lp::Ptr{Float64})::Cint
+        try
+            Θ = unsafe_wrap(Array, theta, (Int(m), d))
+            L = unsafe_wrap(Array, lp, (Int(m),))
+            Threads.@threads for i in 1:m
+                L[i] = d == 1 ? logpdf(prior, Θ[i, 1]) : logpdf(prior, Θ[i, :])
+            end
+            return Cint(0)
+        catch
+            return Cint(-1)
+        end
+    end
+    (@cfunction($sample_cb, Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64})),
+     @cfunction($logpdf_cb, Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64})))
+end
+
 # ---- result types: same field names as SimulatedAnnealingABC.jl:28-60 ----
 mutable struct SABCstate
     ϵ::Vector{Float64}
@@ -232,8 +269,11 @@ end
 
 function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v, δ, seed, device=0, rank=0, world=1,
                        comm_id=nothing)
-    pd = prior_descriptors(prior)
-    joint, chol = prior_chol(prior)
+    host_prior = !is_data_prior(prior)
+    host_prior && !(f_dist isa HostDistance) &&
+        error("a prior that is not Normal / Uniform / Exponential / LogNormal / Gamma / Beta / truncated(Normal) / a product of those / MvNormal needs a Julia function as f_dist")
+    pd = host_prior ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
+    joint, chol = host_prior ? (Int32(2), Float64[]) : prior_chol(prior)
     p = params(f_dist)
     cfg = Ref(CConfig(3, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
@@ -259,8 +299,13 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     end
     if f_dist isa HostDistance
         cb = host_callback(f_dist)
-        HOST_CALLBACKS[h[]] = (cb, f_dist)             # keep the closure (and the wrapped model) alive with the handle
+        pcb = host_prior ? host_prior_callbacks(prior) : nothing
+        HOST_CALLBACKS[h[]] = (cb, f_dist, pcb, prior) # keep the closures (and what they wrap) alive with the handle
         check(h[], ccall((:sabc_set_host_simulator, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), h[], cb, C_NULL))
+        if host_prior
+            check(h[], ccall((:sabc_set_host_prior, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                             h[], pcb[1], pcb[2], C_NULL))
+        end
     end
     h
 end

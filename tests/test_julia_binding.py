@@ -171,6 +171,12 @@ def test_hard_coded_enum_values():
     # the host-simulator callback signature == sabc_simulate_fn
     cb = re.search(r"@cfunction\(\$cb, (\w+), \(([^()]*)\)\)", src)
     assert jkind(cb.group(1)) == "i32" and [jkind(a) for a in cb.group(2).split(",")] == ["ptr", "ptr", "ptr", "i64", "u64", "ptr"]
+    # the host-prior callbacks == sabc_prior_sample_fn / sabc_prior_logpdf_fn (the typedefs' parameter lists, from the header)
+    for jl_name, c_name in (("sample_cb", "sabc_prior_sample_fn"), ("logpdf_cb", "sabc_prior_logpdf_fn")):
+        cb = re.search(r"@cfunction\(\$%s, (\w+), \(([^()]*)\)\)" % jl_name, src)
+        proto = re.search(r"typedef int \(\*%s\)\(([^()]*)\);" % c_name, hdr).group(1)
+        assert jkind(cb.group(1)) == "i32" and [jkind(a) for a in cb.group(2).split(",")] == [ckind(a) for a in proto.split(",")]
+    assert "Int32(2), Float64[]" in src and re.search(r"#define SABC_ABI_VERSION", hdr)     # prior_joint = 2 <-> sabc_set_host_prior
 
 
 def test_reference_surface_is_kept():
