@@ -157,7 +157,7 @@ __device__ __forceinline__ double cdf_apply(const double *__restrict__ T, int64_
 // ---- the same function with an index over the knot table -------------------------------------
 // A plain binary search into an 8 MB table (n = 1e6) touches ~7 distinct 128-byte lines per lookup, most of
 // them outside the 4 MB L2 of the XCD.  Index levels (built once per table, k_cdf_index):
-//   C  coarse, LDS:    C[k] = T[k << shift], kCdfCoarse entries (+inf padded)          -> 10 LDS steps
+//   C  coarse, LDS:    C[k] = T[k << shift], COARSE entries (+inf padded)              -> 10-11 LDS steps
 //   M  mid, L2-hot:    M[m] = T[m << 4] (every 16th knot = first knot of each line)    -> shift - 4 steps in <= 0.5 MB
 //   T  the table:      the 15 knots behind T[m << 4], all in ONE line (+inf padded)     -> 4 steps in one line
 // so a lookup costs one line of the big table.  Every step tests the same monotone predicate T[i] < x as the
@@ -179,16 +179,17 @@ __device__ __forceinline__ int64_t cdf_advance(const double *__restrict__ T, int
   return a;
 }
 
-// coarse (LDS) -> mid -> line
+// coarse (LDS, COARSE entries) -> mid -> line
+template <int COARSE>
 __device__ __forceinline__ double cdf_apply_3level(const double *__restrict__ T, int64_t len, int shift, const double *C,
                                                    const double *__restrict__ M, double x) {
   if (!(x >= T[0])) return (x != x) ? x : 0.0;
   if (x > T[len - 1]) return 1.0;
   int c = 0;                               // c = #coarse entries < x
 #pragma unroll
-  for (int step = kCdfCoarse >> 1; step >= 1; step >>= 1)
+  for (int step = COARSE >> 1; step >= 1; step >>= 1)
     if (C[c + step - 1] < x) c += step;
-  if (C[c] < x) c += 1;                    // the last entry (index kCdfCoarse-1) is only reachable here
+  if (C[c] < x) c += 1;                    // the last entry (index COARSE-1) is only reachable here
   int64_t lo = 0;                          // lo = #knots < x
   if (c > 0) {
     int64_t a = (int64_t)(c - 1) << shift; // T[a] < x, and T[a + 2^shift] >= x or beyond the table (+inf padding)

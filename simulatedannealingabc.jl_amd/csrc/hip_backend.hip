@@ -109,7 +109,7 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   }
   HB_CHECK(hipMalloc((void **)&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
   HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
-  HB_CHECK(hipMalloc((void **)&coarse_, (size_t)m.s * kCdfCoarse * sizeof(double)), "hipMalloc(coarse)");
+  HB_CHECK(hipMalloc((void **)&coarse_, (size_t)m.s * cdf_coarse_entries(m.s) * sizeof(double)), "hipMalloc(coarse)");
   knot_stride_ = (((int64_t)N + 2 + 15) / 16) * 16;       // every table starts on a 128-byte line
   HB_CHECK(hipMalloc((void **)&knots_, (size_t)m.s * (size_t)knot_stride_ * sizeof(double)), "hipMalloc(knots)");
   mid_stride_ = cdf_mid_stride(knot_stride_);
@@ -638,13 +638,14 @@ int HipBackend::set_knots(int stat, const double *knots, int64_t len) {
   return build_coarse(stat);
 }
 
-// index levels of the ECDF search (device_models.hpp): coarse = the smallest shift with ceil(len / 2^shift) <= kCdfCoarse
+// index levels of the ECDF search (device_models.hpp): coarse = the smallest shift with ceil(len / 2^shift) <= cdf_coarse_entries(s)
 int HipBackend::build_coarse(int stat) {
   int shift = 0;
-  while ((((int64_t)cdf_len_[stat] + ((int64_t)1 << shift) - 1) >> shift) > kCdfCoarse) ++shift;
+  const int nc = cdf_coarse_entries(m_.s);
+  while ((((int64_t)cdf_len_[stat] + ((int64_t)1 << shift) - 1) >> shift) > nc) ++shift;
   cdf_shift_[stat] = shift;
   HB_LAUNCH(launch_cdf_index(knots_ + (int64_t)stat * knot_stride_, cdf_len_[stat], knot_stride_, shift,
-                             coarse_ + (int64_t)stat * kCdfCoarse, mid_ + (int64_t)stat * mid_stride_, mid_stride_, stream_),
+                             coarse_ + (int64_t)stat * nc, nc, mid_ + (int64_t)stat * mid_stride_, mid_stride_, stream_),
             "k_cdf_index");
   return 0;
 }

@@ -1146,9 +1146,9 @@ k_cdf_fill(const double *__restrict__ sorted, const int64_t n, const int64_t *__
 
 __global__ void __launch_bounds__(kBlock)
 k_cdf_index(double *__restrict__ knots, const int64_t len, const int64_t stride, const int shift, double *__restrict__ coarse,
-            double *__restrict__ mid, const int64_t mid_len) {
+            const int n_coarse, double *__restrict__ mid, const int64_t mid_len) {
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k < kCdfCoarse) {
+  if (k < n_coarse) {
     const int64_t p = k << shift;
     coarse[k] = p < len ? knots[p] : INFINITY;
   }
@@ -1303,7 +1303,7 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   if (act_n <= 0) return 0;
   return m.model_id == SABC_MODEL_GK ? (int64_t)gk_update_blocks(act_n)   // 4 waves x kGkParticlesPerWave particles per workgroup
-                                     : (act_n + kUpdateBlock - 1) / kUpdateBlock;   // one thread per particle
+                                     : (act_n + update_block_threads(m.s) - 1) / update_block_threads(m.s);   // one thread per particle
 }
 
 // ev0 / ev1 (optional): timing events attached to the dispatch packet itself (hipExtLaunchKernel), so that
@@ -1318,11 +1318,11 @@ int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream, hipEvent_t ev0,
                   hipEvent_t ev1, const RtcKernels *rtc) {
   if (act_n <= 0) return 0;
-  const dim3 grid((unsigned)update_rows(m, act_n)), block(m.model_id == SABC_MODEL_GK ? kBlock : kUpdateBlock);
+  const dim3 grid((unsigned)update_rows(m, act_n)), block(m.model_id == SABC_MODEL_GK ? kBlock : update_block_threads(m.s));
   double *out = partials + row0 * n_partials(m.d, m.s);
   if (m.model_id == SABC_MODEL_USER) {
     if (!rtc || c.prop_kind < 0 || c.prop_kind > 2 || !rtc->update[c.prop_kind]) return (int)hipErrorInvalidValue;
-    return module_launch(rtc->update[c.prop_kind], grid.x, kUpdateBlock, stream, ev0, ev1, m, c, cb, pp, cdf, pv, act_lo, act_n, out);
+    return module_launch(rtc->update[c.prop_kind], grid.x, update_block_threads(m.s), stream, ev0, ev1, m, c, cb, pp, cdf, pv, act_lo, act_n, out);
   }
   if (m.model_id == SABC_MODEL_GK) {
     const dim3 g((unsigned)update_rows(m, act_n));
@@ -1561,13 +1561,13 @@ int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *me
   return SABC_LAUNCH_RC();
 }
 
-int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, double *mid, int64_t mid_len,
-                     hipStream_t stream) {
-  int64_t work = kCdfCoarse;
+int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, int n_coarse, double *mid,
+                     int64_t mid_len, hipStream_t stream) {
+  int64_t work = n_coarse;
   if (mid_len > work) work = mid_len;
   if (stride - len > work) work = stride - len;
-  hipLaunchKernelGGL(k_cdf_index, dim3((unsigned)n_blocks(work)), dim3(kBlock), 0, stream, knots, len, stride, shift, coarse, mid,
-                     mid_len);
+  hipLaunchKernelGGL(k_cdf_index, dim3((unsigned)n_blocks(work)), dim3(kBlock), 0, stream, knots, len, stride, shift, coarse,
+                     n_coarse, mid, mid_len);
   return SABC_LAUNCH_RC();
 }
 

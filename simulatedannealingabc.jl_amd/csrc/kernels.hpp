@@ -17,25 +17,40 @@ struct PopPtrs {
   int64_t cap, n_local, gid0;
 };
 
-// coarse level of the two-level ECDF search: every 2^shift-th knot, kCdfCoarse entries per statistic
-// (padded with +inf), small enough to sit in LDS for the lifetime of a workgroup
+// coarse level of the ECDF search: every 2^shift-th knot, cdf_coarse_entries(s) per statistic (padded with +inf), in LDS
+// for the lifetime of a workgroup of update_block_threads(s) threads.  What a lookup costs is the number of DISTINCT
+// LINES it touches behind the LDS level (each a trip to the L2 for every lane), not its number of loads: with 1024
+// entries per statistic a block of the table is 1024 knots = 64 entries of the mid level = 4 lines, of which the
+// bisection touches 2-3; with 2048 entries it is 2 lines (1-2 touched).  The LDS copy is per workgroup, so models with
+// several statistics pay for the finer index with a larger workgroup -- and need 6 waves per SIMD (<= 80 VGPRs) to keep
+// three of them on a CU.  Same-box A/B, k_update at n = 1e6, cfg3 | cfg5: 256 threads + 1024 entries 239.5 | 855.6 us;
+// 512 + 2048 at 4 waves per SIMD 242.5 | 873.8; 512 + 2048 at 6 waves 234.7 | 845.6 (kept); 1024 + 4096 269 | 935;
+// 256 + 2048 244 | 893.  (Cutting the mid level's line-crossing steps out altogether, a wrong-result experiment, gave
+// 214 us for cfg3: the lines are worth more than this arrangement recovers.)
 #ifndef SABC_CDF_COARSE
-#define SABC_CDF_COARSE 1024
+#define SABC_CDF_COARSE 1024          // one statistic
 #endif
-constexpr int kCdfCoarse = SABC_CDF_COARSE;
+#ifndef SABC_CDF_COARSE_MS
+#define SABC_CDF_COARSE_MS 2048       // several statistics
+#endif
+#ifndef SABC_UPDATE_BLOCK_MS
+#define SABC_UPDATE_BLOCK_MS 512
+#endif
+constexpr int kCdfCoarseMax = SABC_CDF_COARSE > SABC_CDF_COARSE_MS ? SABC_CDF_COARSE : SABC_CDF_COARSE_MS;
+constexpr int cdf_coarse_entries(int s) { return s <= 1 ? SABC_CDF_COARSE : SABC_CDF_COARSE_MS; }
 
 struct CdfPtrs {
   const double *knots;   // [s][stride]; stride is a multiple of 16 (each table starts on a 128-byte line), +inf behind len
   int64_t stride;
   int64_t len[kMaxStats];
-  const double *coarse;  // [s][kCdfCoarse]
+  const double *coarse;  // [s][cdf_coarse_entries(s)]
   const double *mid;     // [s][mid_stride]: every 16th knot (the first knot of each line), +inf padded
   int64_t mid_stride;
   int32_t shift[kMaxStats];
 };
-// entries of the mid level that a search can touch for a table of `stride` knots: (kCdfCoarse << shift) >> 4 + 1 with
-// (kCdfCoarse << shift) < 2 * stride + 2 * kCdfCoarse
-inline int64_t cdf_mid_stride(int64_t stride) { return ((2 * stride + 2 * kCdfCoarse) >> 4) + 2; }
+// entries of the mid level that a search can touch for a table of `stride` knots: (coarse << shift) >> 4 + 1 with
+// (coarse << shift) < 2 * stride + 2 * coarse
+inline int64_t cdf_mid_stride(int64_t stride) { return ((2 * stride + 2 * kCdfCoarseMax) >> 4) + 2; }
 
 constexpr int kBlock = 256;        // 4 wavefronts of 64
 // threads per workgroup of k_update (thread-per-particle form): the grid's tail -- the last workgroups of every CU run
@@ -43,7 +58,18 @@ constexpr int kBlock = 256;        // 4 wavefronts of 64
 #ifndef SABC_UPDATE_BLOCK
 #define SABC_UPDATE_BLOCK 256
 #endif
-constexpr int kUpdateBlock = SABC_UPDATE_BLOCK;
+constexpr int update_block_threads(int s) { return s <= 1 ? SABC_UPDATE_BLOCK : SABC_UPDATE_BLOCK_MS; }
+// second argument of __launch_bounds__ for k_update: waves per SIMD the register allocation has to leave room for
+#ifndef SABC_UPDATE_MIN_WAVES
+#define SABC_UPDATE_MIN_WAVES 4
+#endif
+#ifndef SABC_UPDATE_MIN_WAVES_MS
+#define SABC_UPDATE_MIN_WAVES_MS 6
+#endif
+// (four or more statistics: the LDS index alone holds a CU to two workgroups = 4 waves per SIMD, so the registers may be used)
+constexpr int update_min_waves(int s) {
+  return s <= 1 ? SABC_UPDATE_MIN_WAVES : 3 * (cdf_coarse_entries(s) * s * 8 + 4096) <= 160 * 1024 ? SABC_UPDATE_MIN_WAVES_MS : SABC_UPDATE_MIN_WAVES;
+}
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 // (a grid-stride variant of k_update with <= 1024 workgroups cost 20 more VGPRs and 11 % of its speed:
 // one workgroup per 256 particles and dynamic workgroup scheduling stay)
@@ -124,8 +150,8 @@ int launch_resample_scatter(const double *rows_in, const int64_t *slot, int64_t 
 int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *meta, hipStream_t stream);
 // the index levels of one table: coarse[k] = knots[k << shift], mid[m] = knots[m << 4] (+inf beyond len), and
 // +inf written into knots[len, stride)
-int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, double *mid, int64_t mid_len,
-                     hipStream_t stream);
+int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, int n_coarse, double *mid,
+                     int64_t mid_len, hipStream_t stream);
 // compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
 int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
                           hipStream_t stream);

@@ -12,9 +12,6 @@
 
 #include "../../include/sabc_hip.h"
 
-#ifndef SABC_UPDATE_BLOCK      // kernels.hpp's default, for a build that does not set it
-#define SABC_UPDATE_BLOCK 256
-#endif
 
 namespace sabc {
 
@@ -148,10 +145,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   const char *rocm = std::getenv("ROCM_PATH");
   const std::string inc_rocm = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
   const std::string inc_csrc = "-I" + csrc_dir;
-  // the workgroup size of k_update is a build-time choice of this library: the runtime-compiled kernels follow it
-  const std::string def_block = "-DSABC_UPDATE_BLOCK=" + std::to_string(SABC_UPDATE_BLOCK);
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", def_block.c_str(), inc_csrc.c_str(),
-                        inc_rocm.c_str()};
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str()};
   const int rc = api->CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
   size_t ls = 0;
   api->GetProgramLogSize(prog, &ls);

@@ -88,20 +88,18 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
 // K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
 //     + fused block partials.   SimulatedAnnealingABC.jl:308-331
 // ------------------------------------------------------------------------------------------
-#ifndef SABC_UPDATE_MIN_BLOCKS
-#define SABC_UPDATE_MIN_BLOCKS 4
-#endif
 template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(kUpdateBlock, SABC_UPDATE_MIN_BLOCKS)
+__global__ void __launch_bounds__(update_block_threads(S), update_min_waves(S))
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
          const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int NP = n_partials(D, S);
   if (cb->halt) return;                    // queued ahead of a resample decision that fired (uniform)
   rng_tables_load();
-  __shared__ double cidx[S][kCdfCoarse];   // coarse level of the ECDF tables, 8 KB per statistic
+  constexpr int kUpdateBlock = update_block_threads(S), kCoarse = cdf_coarse_entries(S);
+  __shared__ double cidx[S][kCoarse];      // coarse level of the ECDF tables, 8 or 16 KB per statistic
   {   // all reads first, then the LDS writes: one trip to memory at the front of the workgroup's life instead of one per pass
-    static_assert((S * kCdfCoarse / 2) % kUpdateBlock == 0, "whole passes of 16 bytes per thread");
-    constexpr int kPasses = S * kCdfCoarse / 2 / kUpdateBlock;
+    static_assert((S * kCoarse / 2) % kUpdateBlock == 0, "whole passes of 16 bytes per thread");
+    constexpr int kPasses = S * kCoarse / 2 / kUpdateBlock;
     const double2 *src = reinterpret_cast<const double2 *>(cdf.coarse);
     double2 *dst = reinterpret_cast<double2 *>(&cidx[0][0]);
     double2 tmp[kPasses];
@@ -184,7 +182,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
       double a = 0.0;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        up[j] = cdf_apply_3level(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
+        up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
                                  cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (u[j] - up[j]) / e;                                             // :319
