@@ -123,6 +123,47 @@ def test_a_new_model_from_source_against_the_oracle(S, O, gpu):
     assert abs(res.population[:, 0].mean() - 3.0) < 1.0 and abs(res.population[:, 1].mean() - 0.7) < 0.4
 
 
+# distances on a grid of 1/8: thousands of tied ECDF knots (count data do this) -- and both statistics tie differently
+TIES_SRC = r"""
+__device__ void sabc_user_simulate(const double *theta, const double *p, sabc::NormalStream &rng, double *rho) {
+  double z0, z1;
+  rng.pair(z0, z1);
+  rho[0] = floor(fabs(theta[0] + z0 - p[0]) * 8.0) / 8.0 + 0.125;
+  rho[1] = floor(fabs(theta[0] + 0.5 * z1 - p[0]) * 2.0) / 2.0 + 0.5;
+}
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alg", ["single_eps", "multi_eps"])
+def test_tied_distances_against_the_oracle(S, O, gpu, alg):
+    """Discrete-valued distances give an ECDF table of a few dozen distinct values repeated thousands of times: the
+    LDS-indexed three-level lookup of the fused update kernel (knots equal to the query on every level), the sort and the
+    knot construction against the oracle's plain interpolation (cdf_estimators.jl:29-42)."""
+    n, k, center = 6000, 8, 0.7
+
+    def f(θ, pid, it):
+        z0, z1 = O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, 0)
+        th = float(np.atleast_1d(θ)[0])
+        return (float(np.floor(abs(th + z0 - center) * 8.0) / 8.0 + 0.125), float(np.floor(abs(th + 0.5 * z1 - center) * 2.0) / 2.0 + 0.5))
+    prior = S.Normal(0.0, 2.0)
+    res = S.sabc(S.DeviceSource(TIES_SRC, 1, 2, [center]), prior, n_particles=n, n_simulation=(k + 1) * n,
+                 proposal=S.RandomWalk(n_para=1), resample=n // 2, algorithm=alg, seed=SEED)
+    cfg = O.make_config(n_particles=n, n_para=1, n_stats=2, model_id=O.MODEL_HOST, model_params=[], seed=SEED,
+                        prior=[(O.PRIOR_NORMAL, 0.0, 2.0)], host_fn=O.host_simulator(f, 1, 2),
+                        algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS)
+    run = O.OracleRun(cfg)
+    run.initialize((k + 1) * n)
+    run.update(O.make_update_args(n_simulation=k * n, proposal=oracle_proposal(O, "rw", 1), n_para=1, n_particles=n, resample=n // 2))
+    c = run.counters
+    assert len(np.unique(res.ρ[:, 0])) < 100 and len(np.unique(res.ρ[:, 1])) < 30         # the ties are there
+    assert (res.state.n_accept, res.state.n_resampling) == (c["n_accept"], c["n_resampling"])
+    np.testing.assert_allclose(res.population, run.theta[0], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res.u.T, run.u, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(res.ρ.T, run.rho)
+    np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=1e-9)
+
+
 @pytest.mark.gpu
 def test_unregistered_or_broken_source_fails_loudly(S, gpu):
     with pytest.raises(S.SABCError) as e:
