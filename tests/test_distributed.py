@@ -228,7 +228,10 @@ def test_cpu_engine_sharded_partner_proposals(S, O, tmp_path, prop):
 @pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 20001), ("gauss2_2stats", "multi_eps", "de", 10000),
                                               ("gauss2d_cfg3", "single_eps", "stretch", 10000),
                                               ("gauss2_2stats", "single_eps", "de", 10003),      # ragged last shard, odd halves
-                                              ("gauss1_cfg2", "single_eps", "stretch", 9999)])
+                                              ("gauss1_cfg2", "single_eps", "stretch", 9999),
+                                              # the wave-per-particle g-and-k kernel (64 particles per wave) on ragged shards
+                                              ("gk_cfg4", "multi_eps", "de", 2003), ("gk_cfg4", "single_eps", "rw", 3001),
+                                              ("lv_cfg5", "single_eps", "stretch", 1500)])
 def test_hip_two_shards_on_one_gpu(S, gpu, tmp_path, case, alg, prop, n):
     """libsabc_hip.so with world = 2 (gloo hooks, both ranks on this GPU) against the CPU engine with the
     same sharding, and for RandomWalk against its own single-process run."""
