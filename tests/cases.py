@@ -1,8 +1,11 @@
 """Shared case table: each case describes one (model, prior, algorithm, proposal) combination
 and can be instantiated on the oracle and on the HIP engine with the same seed."""
+import os
+
 import numpy as np
 
-SEED = 20241220
+# the seed of every parity run; tools/seed_sweep.sh repeats the device-vs-oracle suites with other values (SABC_TEST_SEED)
+SEED = int(os.environ.get("SABC_TEST_SEED", "20241220"))
 
 
 def y_obs_mean():
