@@ -178,9 +178,12 @@ def test_cdfs_dist_prior_callable(S, O, gpu):
 @pytest.mark.parametrize("alg", ["multi_eps", "single_eps"])
 @pytest.mark.parametrize("name", ["gauss1_uniform", "gauss2_meansd", "gauss1_2stats", "gauss2_2stats"])
 def test_reference_integration_tests_on_device(S, gpu, name, alg):
-    """test/runtests.jl:56-79,95-116,133-156,172-196 restated on the device path (unseeded, like the reference)."""
+    """test/runtests.jl:56-79,95-116,133-156,172-196 restated on the device path.  Seeded, unlike the reference: `all(ϵ .< 1)`
+    after 1000 simulations of 100 particles is a property of most runs, not of all -- tools/stress_small_runs.py finds 1 seed
+    in 200 (multi-eps, two statistics) where the device AND the oracle end the first stage with ϵ = (2.2, -1.6), the
+    schedule's negative-β branch; an unseeded test would turn red once in a few dozen suite runs."""
     model, prior = hip_model_prior(S, name)
-    res = S.sabc(model, prior, n_particles=100, n_simulation=1000, algorithm=alg)
+    res = S.sabc(model, prior, n_particles=100, n_simulation=1000, algorithm=alg, seed=SEED)
     assert res.state.n_simulation <= 1000 and res.state.n_population_updates == 9 and len(res.population) == 100
     if MODELS[name]["s"] > 1:
         assert np.all(res.state.ϵ < 1)
@@ -197,7 +200,7 @@ def test_reference_proposal_tests_on_device(S, gpu, name, prop):
     """test/runtests.jl:211-267."""
     model, prior = hip_model_prior(S, name)
     p = hip_proposal(S, prop, len(prior))
-    res = S.sabc(model, prior, proposal=p, n_particles=100, n_simulation=1000)
+    res = S.sabc(model, prior, proposal=p, n_particles=100, n_simulation=1000, seed=SEED)
     assert res.state.n_simulation <= 1000 and len(res.population) == 100
     S.update_population_(res, model, prior, proposal=p, n_simulation=1000)
     assert res.state.n_simulation <= 2000
