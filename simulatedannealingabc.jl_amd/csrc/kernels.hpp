@@ -72,7 +72,7 @@ constexpr int update_min_waves(int s) {
 }
 constexpr int kScanChunk = 1024;   // elements per scan block (4 per thread)
 // (a grid-stride variant of k_update with <= 1024 workgroups cost 20 more VGPRs and 11 % of its speed:
-// one workgroup per 256 particles and dynamic workgroup scheduling stay)
+// one workgroup per 256 (several statistics: 512) particles and dynamic workgroup scheduling stay)
 // partial-row matrices up to this many doubles are summed inside the control kernel (one launch,
 // one CU); larger ones by the np-workgroup reduction first
 #ifndef SABC_FUSE_REDUCE_MAX
