@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define SABC_ABI_VERSION 3      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal) */
+#define SABC_ABI_VERSION 4      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
+                                   4: peer-to-peer transport (sabc_comm_p2p_*), launch counters */
 #define SABC_MAX_PARA 8
 #define SABC_MAX_STATS 8
 #define SABC_MAX_MODEL_PARAMS 32
@@ -185,6 +186,31 @@ SABC_API int         sabc_comm_unique_id(void *out_128b);
 /* one allreduce + one allgather through the installed collectives, checked on the host */
 SABC_API int         sabc_comm_selftest(sabc_handle *h);
 
+/* ---- peer-to-peer transport: the shards of ONE node exchange through each other's HBM (xGMI) ----
+   Replaces, per population update, k_reduce_partials -> ncclAllReduce -> k_control by one launch that stores this shard's
+   row of fused sums into slots every peer has mapped, waits (bounded) for the peers' rows, adds them in rank order and
+   runs the control step (SimulatedAnnealingABC.jl:334,348-354); DifferentialEvolution / StretchMove partners
+   (proposals.jl:105-106,141) and the rows a resample draws (:129-132) are read from their owner's memory directly.
+   Set-up: every shard fills a descriptor (IPC handles of its slot area, both population buffers and rho, + its pid and
+   raw pointers for shards living in the same process); the descriptors of all shards, in rank order, go to
+   sabc_comm_p2p_init -- exchanged by the caller, or (all_descs == NULL) by the library over the collectives already
+   installed (sabc_set_collectives / sabc_comm_init_rccl), which also stay as the fallback transport.
+   Every wait is bounded (sabc_comm_p2p_set_timeout, default 2000 ms): a shard that gives up fails the call with
+   SABC_ERR_COMM per sabc_update's error contract and switches the handle back to the fallback transport. */
+#define SABC_P2P_DESC_BYTES 384
+#define SABC_P2P_MAX_WORLD 8
+SABC_API int         sabc_comm_p2p_descriptor(sabc_handle *h, void *out_desc);
+SABC_API int         sabc_comm_p2p_init(sabc_handle *h, const void *all_descs);
+/* one exchange of known rows + one barrier over the mapped slots, checked on the host; SABC_ERR_COMM within the bound */
+SABC_API int         sabc_comm_p2p_selftest(sabc_handle *h);
+SABC_API int         sabc_comm_p2p_set_timeout(sabc_handle *h, double milliseconds);
+SABC_API int         sabc_comm_p2p_disable(sabc_handle *h);
+/* 1 while the handle runs over the peer-to-peer transport */
+SABC_API int         sabc_comm_p2p_active(const sabc_handle *h);
+/* test hook: n > 0: this shard skips its next n posts (rows of sums / barrier flags / call status), so that its peers run
+   into the bound; n < 0: -n more posts go out first, then one is skipped */
+SABC_API int         sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n);
+
 /* ---- the hot path ---- */
 /* initialization(), SimulatedAnnealingABC.jl:151-227.  n_simulation is sabc()'s budget (:155). */
 SABC_API int sabc_initialize(sabc_handle *h, int64_t n_simulation);
@@ -267,6 +293,11 @@ SABC_API int sabc_profile_enable(sabc_handle *h, int32_t level);
 SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
 /* how many times update()/initialize() had to wait for the device so far (run-ahead windows) */
 SABC_API int64_t sabc_host_syncs(const sabc_handle *h);
+/* kernels the library has launched on its stream so far, and collective calls it has issued (hooks / RCCL): per
+   population update at world > 1 the RCCL transport takes k_update + k_reduce_partials + ncclAllReduce + k_control,
+   the peer-to-peer transport k_update + ONE launch */
+SABC_API int64_t sabc_kernel_launches(const sabc_handle *h);
+SABC_API int64_t sabc_collective_calls(const sabc_handle *h);
 
 #ifdef __cplusplus
 }

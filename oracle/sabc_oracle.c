@@ -169,7 +169,7 @@ static double norm_cdf(double x) { return 0.5 * erfc(-x * 0.70710678118654752440
 /* mass of the standard normal between the standardised bounds (complement form in the upper tail) */
 static void truncnormal_mass(const orc_config *cfg, int k, double *p_lo, double *mass) {
   const double lo = (cfg->prior_c[k] - cfg->prior_a[k]) / cfg->prior_b[k], hi = (cfg->prior_d[k] - cfg->prior_a[k]) / cfg->prior_b[k];
-  *p_lo = norm_cdf(lo);
+  *p_lo = lo > 0 ? -norm_cdf(-lo) : norm_cdf(lo);       /* negative: bounds in the upper tail, drawn in the mirrored lower tail */
   *mass = lo > 0 ? norm_cdf(-lo) - norm_cdf(-hi) : norm_cdf(hi) - norm_cdf(lo);
 }
 
@@ -227,7 +227,8 @@ void orc_prior_sample(const orc_config *cfg, uint64_t pid, double *theta) {
     } else if (kind == ORC_PRIOR_TRUNCNORMAL) {            /* inverse CDF on [Phi(lo'), Phi(hi')] */
       double p_lo, mass;
       truncnormal_mass(cfg, k, &p_lo, &mass);
-      double x = cfg->prior_a[k] + cfg->prior_b[k] * orc_norm_quantile(p_lo + ua * mass);
+      double x = p_lo < 0.0 ? cfg->prior_a[k] - cfg->prior_b[k] * orc_norm_quantile(-p_lo - ua * mass)
+                            : cfg->prior_a[k] + cfg->prior_b[k] * orc_norm_quantile(p_lo + ua * mass);
       theta[k] = fmin(fmax(x, cfg->prior_c[k]), cfg->prior_d[k]);
     } else {
       theta[k] = cfg->prior_a[k] + (cfg->prior_b[k] - cfg->prior_a[k]) * ua;

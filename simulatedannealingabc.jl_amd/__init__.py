@@ -9,7 +9,7 @@ from ._lib import SABCError, build, lib  # noqa: F401
 from .api import (SABCresult, SABCstate, initialization, is_logging, load_result, sabc, save_result,  # noqa: F401
                   update_population_)
 from .distributions import (Beta, Exponential, Gamma, HostPrior, LogNormal, MvNormal, Normal, Product, TruncatedNormal, Uniform,  # noqa: F401
-                            product_distribution, truncated)
+                            from_scipy, product_distribution, truncated)
 from .handle import (SabcHandle, op_build_cdf, op_cdf_eval, op_eps_multi, op_eps_single,  # noqa: F401
                      op_normal_pairs, op_philox, op_rng_peak, op_sort)
 from .models import DeviceDistance, DeviceSource, GandK, Gaussian2D, GaussianIID, HostDistance, LotkaVolterra  # noqa: F401

@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+P2P_DESC_BYTES, P2P_MAX_WORLD = 384, 8
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
@@ -170,6 +171,15 @@ def bind(L, strict=True):
         "sabc_profile_enable": ([vp, C.c_int32], C.c_int),
         "sabc_profile_get": ([vp, C.c_int32, dp, ip64], C.c_int),
         "sabc_host_syncs": ([vp], C.c_int64),
+        "sabc_kernel_launches": ([vp], C.c_int64),
+        "sabc_collective_calls": ([vp], C.c_int64),
+        "sabc_comm_p2p_descriptor": ([vp, vp], C.c_int),
+        "sabc_comm_p2p_init": ([vp, vp], C.c_int),
+        "sabc_comm_p2p_selftest": ([vp], C.c_int),
+        "sabc_comm_p2p_set_timeout": ([vp, C.c_double], C.c_int),
+        "sabc_comm_p2p_disable": ([vp], C.c_int),
+        "sabc_comm_p2p_active": ([vp], C.c_int),
+        "sabc_comm_p2p_inject_silence": ([vp, C.c_int32], C.c_int),
     }
     for name, (args, res) in sig.items():
         if not strict and not hasattr(L, name):

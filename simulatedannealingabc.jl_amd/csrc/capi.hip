@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -14,6 +15,7 @@
 #include "hip_backend.hpp"
 #include "host_math.hpp"
 #include "kernels.hpp"
+#include "p2p.hpp"
 #include "rtc.hpp"
 
 using namespace sabc;
@@ -25,7 +27,8 @@ thread_local std::string g_err;
 // world == 1
 class NoCollectives : public Collectives {
  public:
-  int allreduce_sum(double *, int64_t) override { return 0; }
+  // only ever called with world > 1 (the engine skips collectives on one shard): no transport was installed
+  int allreduce_sum(double *, int64_t) override { return -1; }
   int allgather(const double *, double *, int64_t) override { return -1; }
 };
 
@@ -95,9 +98,8 @@ struct RcclApi {
 
 RcclApi *rccl_api() {
   static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
       api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -114,7 +116,7 @@ RcclApi *rccl_api() {
       api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
       api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
     }
-  }
+  });
   return (api.lib && api.GetUniqueId && api.CommInitRank && api.AllReduce && api.AllGather) ? &api : nullptr;
 }
 
@@ -357,6 +359,59 @@ int sabc_comm_selftest(sabc_handle *h) {
       for (int64_t k = 0; k < rc[(size_t)p]; ++k)
         if (in[(size_t)o++] != 1000.0 * p + sh.rank) return hset(h, SABC_ERR_COMM, "self-test alltoallv gave wrong words");
   }
+  return 0;
+}
+
+// ---- peer-to-peer transport (csrc/p2p.hpp) ----
+int sabc_comm_p2p_descriptor(sabc_handle *h, void *out_desc) {
+  if (!h || !out_desc) return SABC_ERR_STATE;
+  return h->be->p2p_descriptor(reinterpret_cast<P2PDesc *>(out_desc)) ? hfail(h, SABC_ERR_COMM) : 0;
+}
+
+int sabc_comm_p2p_init(sabc_handle *h, const void *all_descs) {
+  if (!h) return SABC_ERR_STATE;
+  const Shard &sh = h->eng->shard();
+  if (sh.world < 2 || sh.world > SABC_P2P_MAX_WORLD) return hset(h, SABC_ERR_COMM, "the peer-to-peer transport takes 2..8 shards (one node)");
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  std::vector<P2PDesc> all((size_t)sh.world);
+  if (all_descs) {
+    std::memcpy(all.data(), all_descs, all.size() * sizeof(P2PDesc));
+  } else {
+    // the descriptors travel over the collectives already installed (an allgather of raw bytes, carried as doubles)
+    P2PDesc mine;
+    if (h->be->p2p_descriptor(&mine)) return hfail(h, SABC_ERR_COMM);
+    constexpr int64_t kD = (int64_t)(sizeof(P2PDesc) / sizeof(double));
+    double *g = h->be->gather_buffer((int64_t)(sh.world + 1) * kD);
+    if (!g) return hset(h, SABC_ERR_HIP, "out of memory for the descriptor exchange");
+    if (h->be->to_backend(g, reinterpret_cast<const double *>(&mine), kD)) return hfail(h, SABC_ERR_HIP);
+    if (h->coll->allgather(g, g + kD, kD)) return hset(h, SABC_ERR_COMM, "allgather of the peer-to-peer descriptors failed (no transport installed?)");
+    if (h->be->to_host(reinterpret_cast<double *>(all.data()), g + kD, (int64_t)sh.world * kD)) return hfail(h, SABC_ERR_HIP);
+  }
+  return h->be->p2p_init(all.data()) ? hfail(h, SABC_ERR_COMM) : 0;
+}
+
+int sabc_comm_p2p_selftest(sabc_handle *h) {
+  if (!h) return SABC_ERR_STATE;
+  return h->be->p2p_selftest() ? hfail(h, SABC_ERR_COMM) : 0;
+}
+
+int sabc_comm_p2p_set_timeout(sabc_handle *h, double milliseconds) {
+  if (!h || !(milliseconds > 0)) return hset(h, SABC_ERR_BAD_CONFIG, "the bound of a peer-to-peer wait must be positive");
+  h->be->p2p_set_timeout(milliseconds);
+  return 0;
+}
+
+int sabc_comm_p2p_disable(sabc_handle *h) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->p2p_disable();
+  return 0;
+}
+
+int sabc_comm_p2p_active(const sabc_handle *h) { return h && h->eng->p2p() ? 1 : 0; }
+
+int sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->p2p_inject_silence(n);
   return 0;
 }
 
@@ -609,6 +664,8 @@ int sabc_op_rng_peak(int32_t device, int64_t n_lanes, int32_t pairs_per_lane, in
 }
 
 int64_t sabc_host_syncs(const sabc_handle *h) { return h ? h->eng->host_syncs() : 0; }
+int64_t sabc_kernel_launches(const sabc_handle *h) { return h ? h->be->kernel_launches() : 0; }
+int64_t sabc_collective_calls(const sabc_handle *h) { return h ? h->eng->collective_calls() : 0; }
 
 int sabc_profile_enable(sabc_handle *h, int32_t on) {
   if (!h) return SABC_ERR_STATE;

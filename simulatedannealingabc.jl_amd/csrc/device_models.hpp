@@ -86,7 +86,11 @@ __device__ __forceinline__ double prior_sample_dim(const ModelDesc &m, int k, ui
   const double ua = u52(w.x, w.y);
   if (kind == SABC_PRIOR_EXPONENTIAL) return -a * log(ua);
   if (kind == SABC_PRIOR_TRUNCNORMAL) {                         // inverse CDF on [Phi(lo'), Phi(hi')]
-    const double x = a + b * hostmath::norm_quantile(m.prior_k0[k] + ua * m.prior_k1[k]);
+    // bounds in the upper tail (lo' > 0, k0 stored negative = -Phi(-lo')): drawn in the mirrored lower tail, where the
+    // CDF keeps its digits (Phi(lo') rounds to 1 beyond ~8 sigma and every draw would land on the bound)
+    const double k0 = m.prior_k0[k];
+    const double x = k0 < 0.0 ? a - b * hostmath::norm_quantile(-k0 - ua * m.prior_k1[k])
+                              : a + b * hostmath::norm_quantile(k0 + ua * m.prior_k1[k]);
     return fmin(fmax(x, m.prior_c[k]), m.prior_d[k]);
   }
   return a + (b - a) * ua;

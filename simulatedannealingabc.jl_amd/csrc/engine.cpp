@@ -32,7 +32,8 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
       m_.prior_logc[k] = (a > 0 && b > 0) ? std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b) : 0.0;
     } else if (cfg.prior_kind[k] == SABC_PRIOR_TRUNCNORMAL) {
       const double lo = b > 0 ? (cfg.prior_c[k] - a) / b : 0.0, hi = b > 0 ? (cfg.prior_d[k] - a) / b : 0.0;
-      m_.prior_k0[k] = hostmath::norm_cdf(lo);
+      // lo' > 0: the draw runs in the mirrored lower tail (device_models.hpp); the sign of k0 says so
+      m_.prior_k0[k] = lo > 0 ? -hostmath::norm_cdf(-lo) : hostmath::norm_cdf(lo);
       // the mass between the bounds; for bounds in the upper tail the complement form keeps its digits
       m_.prior_k1[k] = lo > 0 ? hostmath::norm_cdf(-lo) - hostmath::norm_cdf(-hi) : hostmath::norm_cdf(hi) - hostmath::norm_cdf(lo);
       m_.prior_logc[k] = (b > 0 && m_.prior_k1[k] > 0) ? std::log(b) + std::log(m_.prior_k1[k]) : 0.0;
@@ -148,6 +149,12 @@ void Engine::history(double *e, double *u, double *r) const {
 // block partials -> shard sums (ControlBlock::sums) -> allreduce over shards; nothing is read back
 int Engine::global_reduce(int64_t rows, bool guarded) {
   if (be_->reduce_partials(rows, guarded)) return fail(SABC_ERR_HIP, "reduce_partials failed");
+  if (sh_.world > 1 && p2p()) {
+    // the sum over the shards happens inside the launch of the control step that follows (p2p.hpp)
+    if (be_->p2p_exchange_pending()) return fail(SABC_ERR_COMM, "peer-to-peer exchange could not be queued");
+    comm_bytes_ += np_ * (int64_t)sizeof(double);
+    return 0;
+  }
   if (sh_.world > 1 && allreduce(be_->sums_buffer(), np_))
     return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
   return 0;
@@ -156,15 +163,36 @@ int Engine::global_reduce(int64_t rows, bool guarded) {
 // the collectives, with the bytes that land in this shard's receive buffers counted
 int Engine::allreduce(double *buf, int64_t count) {
   comm_bytes_ += count * (int64_t)sizeof(double);
+  collective_calls_ += 1;
   return coll_->allreduce_sum(buf, count);
 }
 int Engine::allgather(const double *send, double *recv, int64_t count_per_rank) {
   comm_bytes_ += (int64_t)sh_.world * count_per_rank * (int64_t)sizeof(double);
+  collective_calls_ += 1;
   return coll_->allgather(send, recv, count_per_rank);
 }
 int Engine::alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) {
   for (int p = 0; p < sh_.world; ++p) comm_bytes_ += rc[p] * (int64_t)sizeof(double);
+  collective_calls_ += 1;
   return coll_->alltoallv(send, sc, recv, rc);
+}
+
+// Peer-to-peer transport, end of a call: every shard tells the others how the call went and, when it went well, waits for
+// the same from them -- a shard whose peer gave up in the call's LAST exchange must not return success on its own.  The
+// status exchange is queued BEFORE the call's final read of the control block, which then carries its outcome.
+int Engine::p2p_commit_ok() {
+  if (!p2p()) return 0;
+  if (be_->p2p_commit(0, true)) return fail(SABC_ERR_COMM, "peer-to-peer status exchange could not be queued");
+  return 0;
+}
+// ... and after a failure: tell the peers (no wait) and go back to the installed Collectives -- the wrapper restores the
+// particles and repeats the call over them.
+void Engine::p2p_abort() {
+  if (!p2p()) return;
+  (void)be_->p2p_commit(1, false);
+  ControlBlock scratch;
+  (void)be_->read_control(&scratch);      // the post has left before the call returns (a later set-up wipes the slots)
+  be_->p2p_disable();
 }
 
 int Engine::stats_reduce() {
@@ -196,7 +224,11 @@ int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool noti
 
 int Engine::wait_step(int64_t seq, int64_t *n_accept, int *halted) {
   int err = 0;
-  if (be_->wait_notify(seq, n_accept, &err, halted)) return fail(SABC_ERR_HIP, "waiting for the control step failed");
+  if (be_->wait_notify(seq, n_accept, &err, halted)) {
+    // the stream drained without the step reporting: a peer-to-peer wait that gave up leaves its error in the control block
+    if (p2p() && be_->read_control(&cb_) == 0 && cb_.error == SABC_ERR_COMM) return sync_control();
+    return fail(SABC_ERR_HIP, "waiting for the control step failed");
+  }
   host_syncs_ += 1;
   if (err) { cb_.error = err; return sync_control(); }
   return 0;
@@ -209,6 +241,7 @@ int Engine::sync_control() {
     case 0: return 0;
     case SABC_ERR_ZERO_MEAN_U: return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
     case SABC_ERR_NOT_POSDEF: return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
+    case SABC_ERR_COMM: return fail(SABC_ERR_COMM, "peer-to-peer exchange: a shard did not post within the bound (or reported a failed call)");
     default: return fail(cb_.error, "error raised by the device-side control step");
   }
 }
@@ -239,6 +272,14 @@ int Engine::resample(double delta, uint64_t iter) {
     int64_t rows = -1;
     if (be_->resample_local(delta, iter, &rows)) return fail(SABC_ERR_HIP, "resample kernels failed");   // :126-132
     return rows >= 0 ? global_reduce(rows) : stats_reduce();
+  }
+  if (p2p()) {
+    // weights -> barrier -> every shard scans the owners' weight rows and reads the rows it drew from their owners: nothing
+    // is gathered, no host round trip (host_syncs unchanged)
+    if (be_->resample_p2p(delta, iter)) return fail(SABC_ERR_HIP, "peer-to-peer resample kernels failed");
+    // what crosses: the other shards' weights, read twice by the scan, and the drawn rows that live elsewhere
+    comm_bytes_ += (2 * (sh_.n_global - sh_.n_local) + sh_.n_local * (int64_t)(d + s) * (sh_.world - 1) / sh_.world) * (int64_t)sizeof(double);
+    return stats_reduce();
   }
   if (be_->resample_weights(delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :126-127
   const int64_t rows = d + s + 1;
@@ -311,6 +352,14 @@ int Engine::partner_source(int inactive_half, PartnerView *out) {
     return 0;
   }
   const int d = m_.d;
+  if (p2p()) {
+    // partners are read where they live: two (DE) or one (Stretch) random rows of d doubles per proposal, from the inactive
+    // half of whichever shard owns them -- no gather; the caller puts a barrier between the two half batches
+    PartnerView pv = partner_view(nullptr, 0, inactive_half);
+    if (be_->partner_view_p2p(&pv)) return fail(SABC_ERR_COMM, "peer-mapped populations are not available");
+    *out = pv;
+    return 0;
+  }
   const int64_t hcap = sh_.cap - sh_.cap / 2;                 // the larger (second) half of a full shard
   const int64_t h = sh_.n_local / 2;
   const int64_t off = inactive_half == 1 ? h : 0, cnt = inactive_half == 1 ? sh_.n_local - h : h;
@@ -352,13 +401,19 @@ PartnerView Engine::partner_view(const double *base, int64_t rank_stride, int in
 // initialization(), :151-227
 // ------------------------------------------------------------------------------------------
 int Engine::initialize(int64_t n_simulation) {
-  const int s = m_.s;
   if (n_simulation < sh_.n_global) {                                        // :155-156
     char buf[160];
     std::snprintf(buf, sizeof(buf), "`n_simulation = %lld` is too small for %lld particles.", (long long)n_simulation,
                   (long long)sh_.n_global);
     return fail(SABC_ERR_NSIM_TOO_SMALL, buf);
   }
+  const int rc = initialize_body();
+  if (rc) { const std::string why = err_; p2p_abort(); err_ = why; }
+  return rc;
+}
+
+int Engine::initialize_body() {
+  const int s = m_.s;
   for (int k = 0; k < kMaxPara; ++k) cb_.pivot[k] = 0.0;
   cb_.n_accept = 0; cb_.hist_rows = 0; cb_.error = 0; cb_.eps_len = eps_len_;
   hist_capacity_ = 4;
@@ -370,14 +425,20 @@ int Engine::initialize(int64_t n_simulation) {
     return fail(SABC_ERR_HIP, "prior sample / simulate kernel failed");   // :172-179
   }
   const double *gathered_rho = be_->rho_block();
-  if (sh_.world > 1) {
-    double *g = be_->gather_buffer((int64_t)sh_.world * s * sh_.cap);
-    if (!g) return fail(SABC_ERR_HIP, "out of memory for the rho gather buffer");
-    if (allgather(be_->rho_block(), g, (int64_t)s * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of rho failed");
-    gathered_rho = g;
-  }
   int any_negative = 0;
-  if (be_->build_cdf(gathered_rho, cdf_len_, &any_negative)) return fail(SABC_ERR_HIP, "ECDF build failed");   // :187
+  if (p2p()) {
+    // every shard sorts the full columns, read from their owners' rho blocks (identical ECDF tables everywhere)
+    comm_bytes_ += (sh_.n_global - sh_.n_local) * (int64_t)s * (int64_t)sizeof(double);
+    if (be_->build_cdf_p2p(cdf_len_, &any_negative)) return fail(SABC_ERR_HIP, "ECDF build failed");          // :187
+  } else {
+    if (sh_.world > 1) {
+      double *g = be_->gather_buffer((int64_t)sh_.world * s * sh_.cap);
+      if (!g) return fail(SABC_ERR_HIP, "out of memory for the rho gather buffer");
+      if (allgather(be_->rho_block(), g, (int64_t)s * sh_.cap)) return fail(SABC_ERR_COMM, "allgather of rho failed");
+      gathered_rho = g;
+    }
+    if (be_->build_cdf(gathered_rho, cdf_len_, &any_negative)) return fail(SABC_ERR_HIP, "ECDF build failed");   // :187
+  }
   if (any_negative) return fail(SABC_ERR_NEG_DISTANCE, "Negative distances are not allowed!");             // :185
   for (int j = 0; j < s; ++j)
     if (cdf_len_[j] < 3) return fail(SABC_ERR_EMPTY_CDF, "all prior distances of one statistic are zero");
@@ -387,6 +448,7 @@ int Engine::initialize(int64_t n_simulation) {
   if ((rc = control(0, nullptr, cfg_.v))) return rc;                        // takes the sums over (ubar for the weights)
   if ((rc = resample(cfg_.delta, 0))) return rc;                            // :197
   if ((rc = control(CTRL_EPSILON | CTRL_HISTORY | CTRL_PIVOT, nullptr, cfg_.v))) return rc;   // :200-208
+  if ((rc = p2p_commit_ok())) return rc;
   if ((rc = sync_control())) return rc;
   clear_history();
   if ((rc = drain_history())) return rc;                                    // :180,207-208
@@ -438,6 +500,15 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
       PartnerView pv;                                                       // partners: the inactive halves of ALL shards
       const int rc = partner_source(1 - half, &pv);
       if (rc) return rc;
+      if (p2p()) {
+        // half batch B reads what half batch A wrote on EVERY shard: one flag barrier between the two launches.  (A needs
+        // none: the exchange that ended the previous update was one.)
+        if (half == 1 && be_->p2p_barrier(guarded)) return fail(SABC_ERR_COMM, "peer-to-peer barrier could not be queued");
+        // rows actually read from other shards: 2 (DE) or 1 (Stretch) partners of d doubles per proposal, a share
+        // (world - 1) / world of them remote
+        const int64_t partners = a.proposal_kind == SABC_PROP_DIFFEVO ? 2 : 1;
+        comm_bytes_ += cnt * partners * m_.d * (int64_t)sizeof(double) * (sh_.world - 1) / sh_.world;
+      }
       if (be_->update_range(c, pv, lo, cnt, rows, &r)) return fail(SABC_ERR_HIP, "update kernel failed");
       rows += r;
     }
@@ -469,6 +540,7 @@ int Engine::update(const sabc_update_args &a) {
     eps_hist_.resize(hist_at_entry[0]); u_hist_.resize(hist_at_entry[1]); rho_hist_.resize(hist_at_entry[2]);
     (void)be_->write_control(cb_);
     initialized_ = false;
+    p2p_abort();
     err_ = why;
   }
   return rc;
@@ -568,6 +640,7 @@ int Engine::update_loop(const sabc_update_args &a) {
   if (last_checkpoint != n_pop) {                                           // :378-382
     if ((rc = control(CTRL_HISTORY | CTRL_KEEP_SUMS, &a, a.v))) return rc;
   }
+  if ((rc = p2p_commit_ok())) return rc;
   if ((rc = sync_control())) return rc;
   if ((rc = drain_history())) return rc;
   population_replaced_ = false;                                             // the pivot now follows the population

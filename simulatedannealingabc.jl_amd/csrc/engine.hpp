@@ -92,6 +92,24 @@ class Backend {
     return resample_draw(pop_block(), iter);
   }
   virtual double last_ess() = 0;
+  // ---- peer-to-peer transport (p2p.hpp): the shards of one node exchange through each other's mapped memory.  A backend
+  //      without it never reports p2p_active() and the engine keeps to the Collectives.
+  virtual bool p2p_active() const { return false; }
+  // the reduction queued by reduce_partials() is to be summed over the shards inside the launch of the next control()
+  // (or of sums_buffer()): reduce -> exchange -> control step in one kernel
+  virtual int p2p_exchange_pending() { return -1; }
+  // flag barrier between the shards' streams (guarded: a no-op while ControlBlock::halt is set)
+  virtual int p2p_barrier(bool) { return -1; }
+  // end of a call: post this shard's status (0 = fine), and on the success path wait for everyone's
+  virtual int p2p_commit(int, bool) { return -1; }
+  virtual void p2p_disable() {}
+  // K2 with every shard's rho block read from its owner (barrier included)
+  virtual int build_cdf_p2p(int64_t *, int *) { return -1; }
+  // fills pv->peer[] with every shard's theta block in its owner's memory
+  virtual int partner_view_p2p(PartnerView *) { return -1; }
+  // K5 on shards with nothing gathered and no host round trip: weights -> barrier -> scan over the owners' weight rows ->
+  // draws + rows read from their owners (:124-137)
+  virtual int resample_p2p(double, uint64_t) { return -1; }
   // state import/export (host buffers, column-major n_local x k)
   virtual int download(double *theta, double *u, double *rho) = 0;
   virtual int upload(const double *theta, const double *u, const double *rho) = 0;
@@ -129,6 +147,10 @@ class Engine {
   // bytes that landed in this shard's receive buffers through collectives so far (allreduce: the vector; allgather: all
   // blocks; alltoallv: what arrived)
   int64_t comm_bytes() const { return comm_bytes_; }
+  int64_t collective_calls() const { return collective_calls_; }
+  // the peer-to-peer transport carries this handle (the backend has it mapped and the simulator is device code: a host
+  // callback's duration differs from shard to shard by more than any sensible wait bound)
+  bool p2p() const { return be_->p2p_active() && !host_mode_ && sh_.world > 1; }
 
  private:
   int fail(int code, const std::string &msg) { err_ = msg; return code; }
@@ -166,7 +188,10 @@ class Engine {
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
-  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0;
+  int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
+  void p2p_abort();                                 // ... and after a failure
+  int initialize_body();
   std::vector<double> eps_hist_, u_hist_, rho_hist_;
 };
 

@@ -2,6 +2,7 @@
 #include "hip_backend.hpp"
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 
@@ -18,6 +19,7 @@ namespace sabc {
   do {                                             \
     (void)hipGetLastError();                       \
     const int e_ = (expr);                         \
+    launches_ += 1;                                \
     if (e_) return check((hipError_t)e_, (what));  \
   } while (0)
 
@@ -51,6 +53,7 @@ HipBackend::~HipBackend() {
   if (mbox_host_) (void)hipHostFree(mbox_host_);
   if (totals_host_) (void)hipHostFree(totals_host_);
   rtc_release(&rtc_);
+  p2p_close();
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -349,6 +352,10 @@ int HipBackend::prior_simulate() {
 }
 
 int HipBackend::build_cdf(const double *gathered_rho, int64_t *len_out, int *any_negative) {
+  return build_cdf_blocks(flat_blocks(gathered_rho, m_.s, sh_.cap, sh_.world), len_out, any_negative);
+}
+
+int HipBackend::build_cdf_blocks(const ShardBlocks &rho_blocks, int64_t *len_out, int *any_negative) {
   const int64_t N = sh_.n_global;
   if (!col_a_) {
     HB_CHECK(hipMalloc((void **)&col_a_, (size_t)N * sizeof(double)), "hipMalloc(col_a)");
@@ -359,10 +366,12 @@ int HipBackend::build_cdf(const double *gathered_rho, int64_t *len_out, int *any
     HB_CHECK(hipMalloc(&sort_tmp_, sort_tmp_bytes_), "hipMalloc(sort_tmp)");
   }
   for (int j = 0; j < m_.s; ++j) {
-    HB_LAUNCH(launch_compact_column(gathered_rho, m_.s, j, sh_.cap, N, col_a_, stream_), "k_compact_column");
+    HB_LAUNCH(launch_compact_column(rho_blocks, j, N, col_a_, stream_), "k_compact_column");
     size_t bytes = sort_tmp_bytes_;
     HB_LAUNCH(sort_f64(col_a_, col_b_, N, sort_tmp_, &bytes, stream_), "radix sort");
+    launches_ += 31;                                   // 8 passes of 4 kernels
     HB_LAUNCH(launch_cdf_knots(col_b_, N, knots_ + (int64_t)j * knot_stride_, meta_dev_ + 2 * j, stream_), "k_cdf_knots");
+    launches_ += 1;
   }
   int64_t meta[2 * kMaxStats];
   HB_CHECK(hipMemcpyAsync(meta, meta_dev_, 2 * (size_t)m_.s * sizeof(int64_t), hipMemcpyDeviceToHost, stream_), "memcpy(meta)");
@@ -431,6 +440,15 @@ int HipBackend::flush_reduce() {
   prof_begin(SABC_KERNEL_REDUCE);
   HB_LAUNCH(launch_reduce_partials(partials_, rows, np_, sums_stage_, pending_guarded_ ? &cb_dev_->halt : nullptr, stream_),
             "k_reduce_partials");
+  if (pending_xchg_) {          // somebody wants the GLOBAL sums in the staging buffer: the exchange without the control step
+    pending_xchg_ = false;
+    ControlArgs none;
+    std::memset(&none, 0, sizeof(none));
+    none.mode = pending_guarded_ ? CTRL_GUARDED : 0;
+    const P2PView pv = p2p_view();
+    HB_LAUNCH(launch_reduce_control(partials_, -1, np_, sums_stage_, pending_guarded_, cb_dev_, none, hist_dev_, mbox_dev_, stream_, &pv,
+                                    ++xseq_, /*do_control=*/false, take_silence()), "k_reduce_control (exchange)");
+  }
   prof_end(SABC_KERNEL_REDUCE);
   return 0;
 }
@@ -441,13 +459,25 @@ double *HipBackend::sums_buffer() {
 }
 
 int HipBackend::control(const ControlArgs &a) {
+  const bool xchg = pending_xchg_ && pending_rows_ >= 0;
+  const P2PView pv = xchg ? p2p_view() : P2PView();
   if (pending_rows_ >= 0 && np_ <= 64 && pending_rows_ * np_ <= kFuseReduceMaxDoubles) {
     const int64_t rows = pending_rows_;
     pending_rows_ = -1;
+    pending_xchg_ = false;
     prof_begin(SABC_KERNEL_REDUCE);
-    HB_LAUNCH(launch_reduce_control(partials_, rows, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_),
+    // several shards over the peer-to-peer slots: reduce -> exchange -> control step, ONE launch
+    HB_LAUNCH(launch_reduce_control(partials_, rows, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_,
+                                    xchg ? &pv : nullptr, xchg ? ++xseq_ : 0, true, xchg && take_silence()),
               "k_reduce_control");
     prof_end(SABC_KERNEL_REDUCE);
+    return 0;
+  }
+  if (xchg) {                   // a partial-row matrix too large for one workgroup: np workgroups reduce it first
+    pending_xchg_ = false;
+    if (flush_reduce()) return -1;
+    HB_LAUNCH(launch_reduce_control(partials_, -1, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_, &pv,
+                                    ++xseq_, true, take_silence()), "k_reduce_control (exchange)");
     return 0;
   }
   if (flush_reduce()) return -1;
@@ -523,9 +553,11 @@ int HipBackend::resample_weights(double delta) {
 int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
   const int rows = m_.d + m_.s + 1;
   prof_begin(SABC_KERNEL_RESAMPLE);
-  HB_LAUNCH(launch_weight_scan(gathered_pop, rows, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
+  const ShardBlocks blocks = flat_blocks(gathered_pop, rows, sh_.cap, sh_.world);
+  HB_LAUNCH(launch_weight_scan(blocks, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
+  launches_ += 2;
   const int nxt = 1 - cur_;
-  HB_LAUNCH(launch_resample_gather(m_, gathered_pop, rows, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_),
+  HB_LAUNCH(launch_resample_gather(m_, blocks, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_),
             "k_resample_gather");
   prof_end(SABC_KERNEL_RESAMPLE);
   cur_ = nxt;
@@ -543,6 +575,7 @@ int HipBackend::resample_local(double delta, uint64_t iter, int64_t *stats_rows)
   prof_begin(SABC_KERNEL_RESAMPLE);
   HB_LAUNCH(launch_resample_local(m_, pop_ptrs(cur_), pop_ptrs(nxt), cb_dev_, delta, iter, block_sums_, cum_, totals_dev_, totals_host_dev_,
                                   pack_dev_, partials_, stats_rows, stream_), "resample kernels");
+  launches_ += 3;
   prof_end(SABC_KERNEL_RESAMPLE);
   cur_ = nxt;
   return 0;
@@ -558,7 +591,9 @@ int HipBackend::resample_select(const double *gathered_w, uint64_t iter) {
     HB_CHECK(hipHostMalloc((void **)&bucket_host_, 2 * (size_t)sh_.world * sizeof(unsigned long long)), "hipHostMalloc(buckets)");
   }
   prof_begin(SABC_KERNEL_RESAMPLE);
-  HB_LAUNCH(launch_weight_scan(gathered_w, 1, sh_.cap, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
+  HB_LAUNCH(launch_weight_scan(flat_blocks(gathered_w, 1, sh_.cap, sh_.world), sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_),
+            "weight scan");
+  launches_ += 2;
   HB_LAUNCH(launch_resample_select(m_, sh_.cap, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(cur_), idx_dev_, stream_),
             "k_resample_select");
   prof_end(SABC_KERNEL_RESAMPLE);
@@ -690,6 +725,198 @@ int HipBackend::simulate_host(const double *theta, int64_t n, uint64_t pid0, uin
   if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   (void)hipFree(d_in); (void)hipFree(d_out);
   return rc;
+}
+
+// ---- peer-to-peer transport (p2p.hpp) ----------------------------------------------------------
+P2PView HipBackend::p2p_view() const {
+  P2PView v;
+  std::memset(&v, 0, sizeof(v));
+  for (int r = 0; r < kMaxPeers; ++r) v.slots[r] = peer_slots_[r];
+  v.rank = sh_.rank;
+  v.world = sh_.world;
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
+  v.timeout_ticks = (uint64_t)(p2p_timeout_ms_ * (double)khz);
+  return v;
+}
+
+int HipBackend::p2p_descriptor(P2PDesc *out) {
+  std::memset(out, 0, sizeof(*out));
+  if (sh_.world < 2 || sh_.world > kMaxPeers) { err_ = "the peer-to-peer transport takes 2..8 shards (one node)"; return -1; }
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  if (!slots_) {
+    // fine-grained, uncached device memory: a peer's store is visible to this device's loads without a cache to go through
+    hipError_t e = hipExtMallocWithFlags((void **)&slots_, (size_t)kP2PSlotWords * 8, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void **)&slots_, (size_t)kP2PSlotWords * 8, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { slots_ = nullptr; return check(e, "hipExtMallocWithFlags(slot area)"); }
+    HB_CHECK(hipMemsetAsync(slots_, 0, (size_t)kP2PSlotWords * 8, stream_), "hipMemset(slot area)");
+    HB_CHECK(hipMalloc((void **)&p2p_test_dev_, (2 * kMaxPartials + 2) * sizeof(double)), "hipMalloc(self-test)");
+    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  }
+  if (p2p_on_ || xseq_ || bseq_ || call_) {
+    // a new set-up (after a failed call switched the transport off): the slots are wiped and the sequence numbers start
+    // over HERE, before this shard's descriptor leaves -- no peer can post into the slots before it has the descriptor
+    p2p_on_ = false;
+    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    HB_CHECK(hipMemsetAsync(slots_, 0, (size_t)kP2PSlotWords * 8, stream_), "hipMemset(slot area)");
+    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    xseq_ = bseq_ = call_ = 0;
+    for (void *p : ipc_opened_) (void)hipIpcCloseMemHandle(p);
+    ipc_opened_.clear();
+  }
+  out->magic = kP2PMagic;
+  out->pid = (int32_t)getpid();
+  out->device = device_;
+  out->rank = sh_.rank; out->world = sh_.world;
+  out->cap = sh_.cap; out->n_global = sh_.n_global;
+  out->d = m_.d; out->s = m_.s;
+  out->ptr_slots = (uint64_t)(uintptr_t)slots_;
+  out->ptr_pop[0] = (uint64_t)(uintptr_t)pop_[0]; out->ptr_pop[1] = (uint64_t)(uintptr_t)pop_[1];
+  out->ptr_rho = (uint64_t)(uintptr_t)rho_;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "P2PDesc holds 64-byte IPC handles");
+  // the handles are only needed by shards in OTHER processes; a failure here surfaces there (all-zero handle)
+  hipIpcMemHandle_t hd;
+  void *what[4] = {slots_, pop_[0], pop_[1], rho_};
+  unsigned char *where[4] = {out->ipc_slots, out->ipc_pop[0], out->ipc_pop[1], out->ipc_rho};
+  for (int i = 0; i < 4; ++i) {
+    if (hipIpcGetMemHandle(&hd, what[i]) == hipSuccess) std::memcpy(where[i], &hd, 64);
+    else (void)hipGetLastError();
+  }
+  return 0;
+}
+
+int HipBackend::p2p_init(const P2PDesc *all) {
+  if (!slots_) { err_ = "sabc_comm_p2p_descriptor has to be called first"; return -1; }
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  const int W = sh_.world;
+  p2p_on_ = false;
+  for (int r = 0; r < W; ++r) {
+    const P2PDesc &d = all[r];
+    if (d.magic != kP2PMagic || d.rank != r || d.world != W || d.cap != sh_.cap || d.n_global != sh_.n_global || d.d != m_.d || d.s != m_.s) {
+      err_ = "peer-to-peer descriptor of a shard does not match this handle's configuration";
+      return -1;
+    }
+    if (r == sh_.rank) {
+      peer_slots_[r] = slots_; peer_pop_[0][r] = pop_[0]; peer_pop_[1][r] = pop_[1]; peer_rho_[r] = rho_;
+      continue;
+    }
+    if (d.pid == (int32_t)getpid()) {                   // same process: the pointers themselves
+      if (d.device != device_) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_, d.device) != hipSuccess || !can) { err_ = "no peer access between the devices of two shards"; return -1; }
+        const hipError_t e = hipDeviceEnablePeerAccess(d.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return check(e, "hipDeviceEnablePeerAccess");
+        (void)hipGetLastError();
+      }
+      peer_slots_[r] = (uint64_t *)(uintptr_t)d.ptr_slots;
+      peer_pop_[0][r] = (double *)(uintptr_t)d.ptr_pop[0]; peer_pop_[1][r] = (double *)(uintptr_t)d.ptr_pop[1];
+      peer_rho_[r] = (double *)(uintptr_t)d.ptr_rho;
+      continue;
+    }
+    const unsigned char *from[4] = {d.ipc_slots, d.ipc_pop[0], d.ipc_pop[1], d.ipc_rho};
+    void *got[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+      hipIpcMemHandle_t hd;
+      std::memcpy(&hd, from[i], 64);
+      const hipError_t e = hipIpcOpenMemHandle(&got[i], hd, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) return check(e, "hipIpcOpenMemHandle (a peer shard's memory)");
+      ipc_opened_.push_back(got[i]);
+    }
+    peer_slots_[r] = (uint64_t *)got[0];
+    peer_pop_[0][r] = (double *)got[1]; peer_pop_[1][r] = (double *)got[2];
+    peer_rho_[r] = (double *)got[3];
+  }
+  p2p_on_ = true;
+  return 0;
+}
+
+void HipBackend::p2p_close() {
+  p2p_on_ = false;
+  for (void *p : ipc_opened_) (void)hipIpcCloseMemHandle(p);
+  ipc_opened_.clear();
+  if (slots_) (void)hipFree(slots_);
+  if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
+  slots_ = nullptr; p2p_test_dev_ = nullptr;
+}
+
+// a row of known values through the slots + one barrier; the host checks the sums.  Sequence numbers advance exactly as
+// in a real exchange, so every shard has to call it the same number of times.
+int HipBackend::p2p_selftest() {
+  if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+  HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  const int np = 7, W = sh_.world;
+  double in[np], out[np];
+  for (int q = 0; q < np; ++q) in[q] = (double)(sh_.rank + 1) * (q + 1) + (q == 3 ? 0.1 : 0.0);
+  double *d_in = p2p_test_dev_, *d_out = p2p_test_dev_ + kMaxPartials;
+  int *d_failed = (int *)(p2p_test_dev_ + 2 * kMaxPartials);
+  HB_CHECK(hipMemcpyAsync(d_in, in, sizeof(in), hipMemcpyHostToDevice, stream_), "memcpy");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  const P2PView pv = p2p_view();
+  HB_LAUNCH(launch_p2p_selftest(pv, ++xseq_, np, d_in, d_out, d_failed, stream_), "k_p2p_selftest");
+  HB_LAUNCH(launch_p2p_barrier(pv, ++bseq_, cb_dev_, false, false, stream_), "k_p2p_barrier");
+  int failed = 1;
+  HB_CHECK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream_), "memcpy");
+  HB_CHECK(hipMemcpyAsync(&failed, d_failed, sizeof(int), hipMemcpyDeviceToHost, stream_), "memcpy");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  ControlBlock cb;
+  if (read_control(&cb)) return -1;
+  if (failed || cb.error == SABC_ERR_COMM) { err_ = "peer-to-peer self-test: a shard did not post within the bound"; p2p_on_ = false; return -1; }
+  for (int q = 0; q < np; ++q) {
+    double want = 0.0;
+    for (int r = 0; r < W; ++r) { const double x = (double)(r + 1) * (q + 1) + (q == 3 ? 0.1 : 0.0); want = r == 0 ? x : want + x; }
+    if (out[q] != want) { err_ = "peer-to-peer self-test: wrong sums came back through the slots"; p2p_on_ = false; return -1; }
+  }
+  return 0;
+}
+
+int HipBackend::p2p_barrier(bool guarded) {
+  if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+  HB_LAUNCH(launch_p2p_barrier(p2p_view(), ++bseq_, cb_dev_, guarded, take_silence(), stream_), "k_p2p_barrier");
+  return 0;
+}
+
+int HipBackend::p2p_commit(int status, bool wait) {
+  if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+  if (pending_rows_ >= 0 && flush_reduce()) return -1;
+  HB_LAUNCH(launch_p2p_commit(p2p_view(), ++call_, status, wait, cb_dev_, take_silence(), stream_), "k_p2p_commit");
+  return 0;
+}
+
+int HipBackend::build_cdf_p2p(int64_t *len_out, int *any_negative) {
+  if (p2p_barrier(false)) return -1;                     // every shard's prior simulations are done
+  ShardBlocks b = flat_blocks(nullptr, m_.s, sh_.cap, sh_.world);
+  b.direct = 1;
+  for (int r = 0; r < sh_.world; ++r) b.peer[r] = peer_rho_[r];
+  return build_cdf_blocks(b, len_out, any_negative);
+}
+
+int HipBackend::partner_view_p2p(PartnerView *pv) {
+  if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+  pv->direct = 1;
+  pv->base = nullptr;
+  pv->rank_stride = 0;
+  pv->cap = sh_.cap;
+  for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peer_pop_[cur_][r] : nullptr;   // every shard flips `cur_` in step
+  return 0;
+}
+
+int HipBackend::resample_p2p(double delta, uint64_t iter) {
+  if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+  if (pending_rows_ >= 0 && flush_reduce()) return -1;
+  const int rows = m_.d + m_.s + 1;
+  prof_begin(SABC_KERNEL_RESAMPLE);
+  HB_LAUNCH(launch_resample_weights(m_, pop_ptrs(cur_), cb_dev_, (double)sh_.n_global, delta, stream_), "k_resample_weights");   // :126-127
+  if (p2p_barrier(false)) return -1;                     // every shard's weight row is written
+  ShardBlocks b = flat_blocks(nullptr, rows, sh_.cap, sh_.world);
+  b.direct = 1;
+  for (int r = 0; r < sh_.world; ++r) b.peer[r] = peer_pop_[cur_][r];
+  HB_LAUNCH(launch_weight_scan(b, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
+  launches_ += 2;
+  const int nxt = 1 - cur_;
+  HB_LAUNCH(launch_resample_gather(m_, b, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_), "k_resample_gather");   // :129-132
+  prof_end(SABC_KERNEL_RESAMPLE);
+  cur_ = nxt;
+  return 0;
 }
 
 }  // namespace sabc

@@ -59,6 +59,23 @@ class HipBackend : public Backend {
   int get_knots(int stat, double *out, int64_t len) override;
   int set_knots(int stat, const double *knots, int64_t len) override;
 
+  // peer-to-peer transport (p2p.hpp)
+  bool p2p_active() const override { return p2p_on_; }
+  int p2p_exchange_pending() override { pending_xchg_ = true; return 0; }
+  int p2p_barrier(bool guarded) override;
+  int p2p_commit(int status, bool wait) override;
+  void p2p_disable() override { p2p_on_ = false; pending_xchg_ = false; }
+  int build_cdf_p2p(int64_t *len_out, int *any_negative) override;
+  int partner_view_p2p(PartnerView *pv) override;
+  int resample_p2p(double delta, uint64_t iter) override;
+  int p2p_descriptor(P2PDesc *out);                 // allocates the slot area on first use
+  int p2p_init(const P2PDesc *all);                 // maps every peer's slots, populations and rho; switches the transport on
+  int p2p_selftest();
+  void p2p_set_timeout(double ms) { if (ms > 0) p2p_timeout_ms_ = ms; }
+  // test hook: n > 0: the next n posts are skipped; n < 0: -n more posts go out, then one is skipped
+  void p2p_inject_silence(int n) { if (n >= 0) { p2p_skip_ = 0; p2p_silent_ = n; } else { p2p_skip_ = -n; p2p_silent_ = 1; } }
+  int64_t kernel_launches() const { return launches_; }
+
   // extras used by the C-ABI layer
   int set_stream(hipStream_t s);
   hipStream_t stream() const { return stream_; }
@@ -132,6 +149,26 @@ class HipBackend : public Backend {
   int ensure_host_buffers();
   RtcKernels rtc_;                                        // SABC_MODEL_USER: kernels compiled from the user's source
   const RtcKernels *rtc() const { return rtc_.module ? &rtc_ : nullptr; }
+  // peer-to-peer transport
+  int build_cdf_blocks(const ShardBlocks &rho_blocks, int64_t *len_out, int *any_negative);
+  P2PView p2p_view() const;
+  bool take_silence() {
+    if (p2p_skip_ > 0) { --p2p_skip_; return false; }
+    if (p2p_silent_ > 0) { --p2p_silent_; return true; }
+    return false;
+  }
+  void p2p_close();
+  uint64_t *slots_ = nullptr;                             // this shard's slot area (fine-grained device memory)
+  uint64_t *peer_slots_[kMaxPeers] = {nullptr};
+  double *peer_pop_[2][kMaxPeers] = {{nullptr}};
+  double *peer_rho_[kMaxPeers] = {nullptr};
+  std::vector<void *> ipc_opened_;                        // what hipIpcOpenMemHandle returned (closed on destroy)
+  bool p2p_on_ = false, pending_xchg_ = false;
+  uint32_t xseq_ = 0, bseq_ = 0, call_ = 0;               // exchange / barrier / call sequence numbers (the same on every shard)
+  double p2p_timeout_ms_ = 2000.0;
+  int p2p_silent_ = 0, p2p_skip_ = 0;
+  double *p2p_test_dev_ = nullptr;
+  int64_t launches_ = 0;
   int prof_ = 0, prof_open_ = -1;
   unsigned prof_tick_ = 0;
   struct EvPair { hipEvent_t a, b; };

@@ -14,6 +14,7 @@
 #include <hip/hip_ext.h>
 #include <cstring>
 #include "control.hpp"
+#include "p2p.hpp"
 #include "update_kernel.hpp"
 
 namespace sabc {
@@ -527,22 +528,29 @@ __device__ __forceinline__ void control_load(ControlBlock &lcb, const ControlBlo
     reinterpret_cast<uint64_t *>(&lcb)[i] = reinterpret_cast<const uint64_t *>(cb)[i];
 }
 
+__device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a, const ControlBlock &lcb) {
+  Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
+  mbox->n_accept = lcb.n_accept;
+  mbox->error = lcb.error;
+  mbox->halted = lcb.halt;
+  __threadfence_system();                   // payload before the sequence word, visible to the host
+  mbox->seq = a.notify_seq;
+}
+
 __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, ControlBlock *cb, const ControlArgs &a,
                                                 double *hist, Mailbox *ring, const double *sums, double *stage) {
   if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums) ? 1 : 0;
   __syncthreads();
-  if (!ran) return;                         // guarded and halted: nothing changed, nothing is posted
+  if (!ran) {                               // guarded and halted: nothing changed
+    // ... and nothing is posted, unless the halt is a peer-to-peer wait that gave up (p2p.hpp): the host is waiting for
+    // this step's sequence word and has to learn of the error
+    if (threadIdx.x == 0 && a.notify_seq != 0 && lcb.error == SABC_ERR_COMM) mailbox_post(ring, a, lcb);
+    return;
+  }
   for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
     reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
   if (stage && (int)threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
-  if (threadIdx.x == 0 && a.notify_seq != 0) {
-    Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
-    mbox->n_accept = lcb.n_accept;
-    mbox->error = lcb.error;
-    mbox->halted = lcb.halt;
-    __threadfence_system();                 // payload before the sequence word, visible to the host
-    mbox->seq = a.notify_seq;
-  }
+  if (threadIdx.x == 0 && a.notify_seq != 0) mailbox_post(ring, a, lcb);
 }
 
 __global__ void __launch_bounds__(64)
@@ -557,50 +565,203 @@ k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, co
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, nullptr);
 }
 
-// k_reduce_partials + k_control in one launch, for the case that no allreduce sits between them
-// (one shard).  1024 threads: thread (g, c) sums rows g, g+G, ... of column c (consecutive threads
-// read consecutive addresses), LDS combines the G row groups in a fixed order, lane 0 runs the
-// control step on the sums.  The loads of the control block and of the partial rows are issued together
-// (one round trip); the staging buffer is written only by a step that runs.
+// ------------------------------------------------------------------------------------------
+// peer-to-peer exchange over mapped slots (p2p.hpp)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void p2p_store(uint64_t *p, uint64_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);        // one 8-byte store, past the caches
+}
+__device__ __forceinline__ uint64_t p2p_load(const uint64_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint64_t p2p_clock() { return (uint64_t)wall_clock64(); }
+
+// spin until the word's upper half is `seq`; gives up after `ticks` (or as soon as another lane of the workgroup has)
+__device__ __forceinline__ uint64_t p2p_wait_word(const uint64_t *src, uint32_t seq, uint64_t t0, uint64_t ticks, volatile int *failed) {
+  uint64_t w = p2p_load(src);
+  for (uint32_t polls = 1; (uint32_t)(w >> 32) != seq; ++polls) {
+    if ((polls & 15u) == 0 && (*failed || p2p_clock() - t0 > ticks)) { *failed = 1; break; }
+    __builtin_amdgcn_s_sleep(2);
+    w = p2p_load(src);
+  }
+  return w;
+}
+
+// a wait gave up: the error goes into the control block together with the halt flag (everything queued behind becomes a
+// no-op) and, if the host is waiting for this step, into the mailbox
+__device__ __forceinline__ void p2p_fail(ControlBlock *cb, ControlBlock *lcb, const ControlArgs *a, Mailbox *ring) {
+  cb->error = SABC_ERR_COMM;
+  cb->halt = 1;
+  if (lcb) { lcb->error = SABC_ERR_COMM; lcb->halt = 1; }
+  __threadfence();
+  if (lcb && a && ring && a->notify_seq != 0) mailbox_post(ring, *a, *lcb);
+}
+
+// sum of the shards' rows of `np` doubles: `mine` (LDS) goes to every peer's slots in the LL form, the peers' rows are
+// awaited in this shard's slots, and the rows are added in RANK order (every shard gets bitwise the same sums).
+// All threads of the workgroup call it; returns false when a wait gave up.  words: LDS, world * 2 np.
+__device__ __forceinline__ bool p2p_allreduce_rows(const P2PView &pv, const uint32_t seq, const int np, double *mine,
+                                                   uint32_t *words, volatile int *failed, const int silent) {
+  const int W = pv.world, nw = 2 * np, ring = (int)(seq % kP2PRing);
+  const uint32_t *half = reinterpret_cast<const uint32_t *>(mine);
+  if (!silent)
+    for (int i = threadIdx.x; i < W * nw; i += blockDim.x) {
+      const int p = i / nw, t = i - p * nw;
+      p2p_store(pv.slots[p] + kP2PSumsOff + ((int64_t)ring * kMaxPeers + pv.rank) * kP2PWords + t, ((uint64_t)seq << 32) | half[t]);
+    }
+  const uint64_t t0 = p2p_clock();
+  for (int i = threadIdx.x; i < W * nw; i += blockDim.x) {
+    const int r = i / nw, t = i - r * nw;
+    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PSumsOff + ((int64_t)ring * kMaxPeers + r) * kP2PWords + t, seq, t0,
+                                     pv.timeout_ticks, failed);
+    words[i] = (uint32_t)w;
+  }
+  __syncthreads();
+  if (*failed) return false;
+  if ((int)threadIdx.x < np) {
+    const int q = threadIdx.x;
+    double a = 0.0;
+    for (int r = 0; r < W; ++r) {
+      const double x = __hiloint2double((int)words[r * nw + 2 * q + 1], (int)words[r * nw + 2 * q]);
+      a = r == 0 ? x : a + x;
+    }
+    mine[q] = a;
+  }
+  __syncthreads();
+  return true;
+}
+
+// k_reduce_partials + [the sum over the shards] + k_control in ONE launch.
+//  XCHG = false: one shard, no collective in between.
+//  XCHG = true : several shards over the peer-to-peer slots -- what was k_reduce_partials -> ncclAllReduce -> k_control.
+// 1024 threads: thread (g, c) sums rows g, g+G, ... of column c (consecutive threads read consecutive addresses), LDS
+// combines the G row groups in a fixed order, lane 0 runs the control step on the sums.  The loads of the control block
+// and of the partial rows are issued together (one round trip); the staging buffer is written only by a step that runs.
+// rows < 0: the shard's sums are already in `stage` (k_reduce_partials ran: a partial matrix too large for one workgroup).
+// do_control == 0: only the (global) sums, into `stage` (whoever asked for sums_buffer()).
+struct XchgArgs {
+  P2PView pv;
+  uint32_t seq;
+  int32_t do_control, silent, reserved;
+};
+
+template <bool XCHG>
 __global__ void __launch_bounds__(1024)
 k_reduce_control(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ stage,
-                 ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring) {
+                 ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, const XchgArgs x) {
   __shared__ ControlBlock lcb;
   __shared__ int ran;
+  __shared__ int failed;
   __shared__ double sm[1024];
   __shared__ double sums[kMaxPartials];
+  __shared__ uint32_t words[XCHG ? kMaxPeers * kP2PWords : 1];
   control_load(lcb, cb);
-  const int G = 1024 / np;
-  const int g = threadIdx.x / np, c = threadIdx.x - g * np;
-  double v = 0.0;
-  if (g < G) {
-    // all of a lane's rows in ONE round trip where they fit (20 at n = 1e6: 3906 rows over 204 row groups), masked so that
-    // there is no tail of dependent single loads (each a trip to the L2: 3-4 of them were ~3 us of this kernel); the
-    // additions stay in row order, a masked slot adds +0
-    constexpr int kInFlight = 24;
-    for (int64_t r0 = g; r0 < rows; r0 += (int64_t)kInFlight * G) {
-      double x[kInFlight];
+  if (threadIdx.x == 0) failed = 0;
+  if (rows >= 0) {
+    const int G = 1024 / np;
+    const int g = threadIdx.x / np, c = threadIdx.x - g * np;
+    double v = 0.0;
+    if (g < G) {
+      // all of a lane's rows in ONE round trip where they fit (20 at n = 1e6: 3906 rows over 204 row groups), masked so that
+      // there is no tail of dependent single loads (each a trip to the L2: 3-4 of them were ~3 us of this kernel); the
+      // additions stay in row order, a masked slot adds +0
+      constexpr int kInFlight = 24;
+      for (int64_t r0 = g; r0 < rows; r0 += (int64_t)kInFlight * G) {
+        double xx[kInFlight];
 #pragma unroll
-      for (int e = 0; e < kInFlight; ++e) {
-        const int64_t r = r0 + (int64_t)e * G;
-        x[e] = r < rows ? partials[r * np + c] : 0.0;
+        for (int e = 0; e < kInFlight; ++e) {
+          const int64_t r = r0 + (int64_t)e * G;
+          xx[e] = r < rows ? partials[r * np + c] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < kInFlight; ++e) v += xx[e];
       }
-#pragma unroll
-      for (int e = 0; e < kInFlight; ++e) v += x[e];
+    }
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    // fixed-shape tree over the G row groups (a serial sum by np lanes would be G dependent LDS reads: 6 us at G = 204)
+    int top = 1;
+    while (top * 2 < G) top *= 2;
+    for (int stride = top; stride >= 1; stride >>= 1) {
+      if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
+      __syncthreads();
+    }
+    if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
+  } else if ((int)threadIdx.x < np) {
+    sums[threadIdx.x] = stage[threadIdx.x];
+  }
+  __syncthreads();
+  if (XCHG) {
+    // every shard takes the same decision here (the halt flag follows from sums all shards share), so a step that is a
+    // no-op posts nothing on ANY shard and nobody waits for it
+    const bool noop = ((a.mode & CTRL_GUARDED) && lcb.halt) || lcb.error == SABC_ERR_COMM;
+    if (noop) {
+      if (threadIdx.x == 0 && x.do_control && a.notify_seq != 0 && lcb.error == SABC_ERR_COMM) mailbox_post(ring, a, lcb);
+      return;
+    }
+    if (!p2p_allreduce_rows(x.pv, x.seq, np, sums, words, &failed, x.silent)) {
+      if (threadIdx.x == 0) p2p_fail(cb, &lcb, x.do_control ? &a : nullptr, ring);
+      return;
+    }
+    if (!x.do_control) {
+      if ((int)threadIdx.x < np) stage[threadIdx.x] = sums[threadIdx.x];
+      return;
     }
   }
-  sm[threadIdx.x] = v;
-  __syncthreads();
-  // fixed-shape tree over the G row groups (a serial sum by np lanes would be G dependent LDS reads: 6 us at G = 204)
-  int top = 1;
-  while (top * 2 < G) top *= 2;
-  for (int stride = top; stride >= 1; stride >>= 1) {
-    if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
-    __syncthreads();
-  }
-  if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
-  __syncthreads();
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, stage);
+}
+
+// Flag barrier between the shards' streams: everything every shard has enqueued before its barrier `seq` has completed
+// (kernel boundary) before anything enqueued behind it starts.  Lane r posts to / waits for shard r.
+__global__ void __launch_bounds__(64)
+k_p2p_barrier(const P2PView pv, const uint32_t seq, ControlBlock *cb, const int guarded, const int silent) {
+  __shared__ int failed;
+  if (threadIdx.x == 0) failed = 0;
+  __syncthreads();
+  if ((guarded && cb->halt) || cb->error == SABC_ERR_COMM) return;        // the same on every shard (see k_reduce_control)
+  const int r = threadIdx.x, ring = (int)(seq % kP2PRing);
+  __threadfence_system();
+  if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PBarOff + (int64_t)ring * kMaxPeers + pv.rank, ((uint64_t)seq << 32) | 1u);
+  if (r < pv.world)
+    (void)p2p_wait_word(pv.slots[pv.rank] + kP2PBarOff + (int64_t)ring * kMaxPeers + r, seq, p2p_clock(), pv.timeout_ticks, &failed);
+  __syncthreads();
+  if (threadIdx.x == 0 && failed) p2p_fail(cb, nullptr, nullptr, nullptr);
+  __threadfence_system();
+}
+
+// End of a sabc_initialize / sabc_update call over the peer-to-peer transport: every shard tells the others how the call
+// went (status 0 = fine) and -- on the success path -- learns the same of them, so that a shard whose peer gave up in the
+// call's LAST exchange does not return success on its own.  A shard that failed posts without waiting.
+__global__ void __launch_bounds__(64)
+k_p2p_commit(const P2PView pv, const uint32_t call, const int status, const int wait, ControlBlock *cb, const int silent) {
+  __shared__ int failed;
+  if (threadIdx.x == 0) failed = 0;
+  __syncthreads();
+  const int r = threadIdx.x;
+  const int mine = (status != 0 || cb->error != 0) ? 1 : 0;
+  if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PCommitOff + pv.rank, ((uint64_t)call << 32) | (uint32_t)mine);
+  if (!wait) return;
+  if (r < pv.world) {
+    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PCommitOff + r, call, p2p_clock(), pv.timeout_ticks, &failed);
+    if ((uint32_t)w != 0u) failed = 1;                                    // the peer's call failed
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && failed && cb->error == 0) p2p_fail(cb, nullptr, nullptr, nullptr);
+}
+
+// rows of known values through the slots, for sabc_comm_p2p_selftest: out[q] = sum over shards of in[q]
+__global__ void __launch_bounds__(1024)
+k_p2p_selftest(const P2PView pv, const uint32_t seq, const int np, const double *__restrict__ in, double *__restrict__ out,
+               int *__restrict__ failed_out) {
+  __shared__ int failed;
+  __shared__ double sums[kMaxPartials];
+  __shared__ uint32_t words[kMaxPeers * kP2PWords];
+  if (threadIdx.x == 0) failed = 0;
+  if ((int)threadIdx.x < np) sums[threadIdx.x] = in[threadIdx.x];
+  __syncthreads();
+  const bool ok = p2p_allreduce_rows(pv, seq, np, sums, words, &failed, 0);
+  if (ok && (int)threadIdx.x < np) out[threadIdx.x] = sums[threadIdx.x];
+  if (threadIdx.x == 0) *failed_out = ok ? 0 : 1;
 }
 
 // K3 over the shard: u = cdf(rho)  (:190-192)
@@ -636,10 +797,10 @@ k_resample_weights(const int d, const int s, const PopPtrs pp, const ControlBloc
   pp.pop[(int64_t)(d + s) * pp.cap + li] = particle_weight(d, s, pp, cb, n_global, delta, li);
 }
 
-__device__ __forceinline__ double gathered_weight(const double *g, int rows, int64_t cap, int64_t gid) {
+__device__ __forceinline__ double gathered_weight(const ShardBlocks &g, int64_t gid) {
   int64_t r, o;
-  split_index(gid, cap, r, o);
-  return g[(r * rows + (rows - 1)) * cap + o];
+  split_index(gid, g.cap, r, o);
+  return shard_block(g, r)[(int64_t)(g.rows - 1) * g.cap + o];
 }
 
 // pass 1: per-chunk sums of w and w^2.  One shard (wargs.fused): the weights are computed here from the u rows and
@@ -652,8 +813,7 @@ struct WeightArgs {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n, double *__restrict__ bs,
-            double *__restrict__ bq, const WeightArgs wa) {
+k_scan_sums(const ShardBlocks g, const int64_t n, double *__restrict__ bs, double *__restrict__ bq, const WeightArgs wa) {
   __shared__ double sm[2][kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
   double s = 0.0, q = 0.0;
@@ -666,7 +826,7 @@ k_scan_sums(const double *__restrict__ g, const int rows, const int64_t cap, con
         w = particle_weight(wa.d, wa.s, wa.pp, wa.cb, wa.n_global, wa.delta, i);
         wa.pp.pop[(int64_t)(wa.d + wa.s) * wa.pp.cap + i] = w;
       } else {
-        w = gathered_weight(g, rows, cap, i);
+        w = gathered_weight(g, i);
       }
     }
     s += w; q += w * w;
@@ -743,8 +903,8 @@ __device__ __forceinline__ int64_t guide_bucket(const double t, const double tot
 
 // pass 3: inclusive scan inside each chunk + chunk offset
 __global__ void __launch_bounds__(kBlock)
-k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, const int64_t n,
-             const double *__restrict__ bs, double *__restrict__ cum, double *__restrict__ cm, const PackArgs pa) {
+k_scan_final(const ShardBlocks g, const int64_t n, const double *__restrict__ bs, double *__restrict__ cum,
+             double *__restrict__ cm, const PackArgs pa) {
   __shared__ double sm[kBlock];
   __shared__ double scum[kScanChunk];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
@@ -753,7 +913,7 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t i = base + e;
-    w[e] = i < n ? gathered_weight(g, rows, cap, i) : 0.0;
+    w[e] = i < n ? gathered_weight(g, i) : 0.0;
     s += w[e];
   }
   sm[threadIdx.x] = s;
@@ -810,7 +970,7 @@ k_scan_final(const double *__restrict__ g, const int rows, const int64_t cap, co
     for (int q = 0; q < 16; ++q) v[q] = 0.0;
     v[0] = i < n ? scum[loc] : INFINITY;                             // empty slots of the last line never win a search
     if (i < n)
-      for (int row = 0; row < pa.row_len; ++row) v[1 + row] = g[(int64_t)row * cap + i];
+      for (int row = 0; row < pa.row_len; ++row) v[1 + row] = g.flat[(int64_t)row * g.cap + i];   // packing: one shard, its own block
     double2 *dst = reinterpret_cast<double2 *>(pa.pk + line * 16 + slot * stride);
     // (only the slot's used part: the padding behind 1 + row_len doubles is never read)
     for (int q = 0; 2 * q < stride && 2 * q < 1 + pa.row_len; ++q) dst[q] = make_double2(v[2 * q], v[2 * q + 1]);
@@ -879,8 +1039,8 @@ __device__ __forceinline__ int64_t resample_search(const double t, const double 
 // as global source indices; the rows are fetched from their owners afterwards (k_resample_serve / _scatter).
 template <bool GATHER>
 __global__ void __launch_bounds__(kBlock)
-k_resample_gather(const uint64_t seed, const int d, const int s, const double *__restrict__ g, const int rows,
-                  const int64_t cap, const int64_t n, const double *__restrict__ cum, const double *__restrict__ bs,
+k_resample_gather(const uint64_t seed, const int d, const int s, const ShardBlocks g, const int64_t n,
+                  const double *__restrict__ cum, const double *__restrict__ bs,
                   const double *__restrict__ cm, const int64_t nb, const double *__restrict__ totals, const uint64_t iter,
                   const PopPtrs dst, int64_t *__restrict__ idx_out) {
   extern __shared__ double bs_lds[];
@@ -898,9 +1058,10 @@ k_resample_gather(const uint64_t seed, const int d, const int s, const double *_
   const int64_t idx = resample_search(t, B, nb, cm, cum, n);
   if (!GATHER) { idx_out[li] = idx; return; }
   int64_t r, o;
-  split_index(idx, cap, r, o);
+  split_index(idx, g.cap, r, o);
+  const double *src = shard_block(g, r) + o;               // the drawn particle, in a gathered copy or in its owner's HBM
   for (int row = 0; row < d + s; ++row)
-    dst.pop[(int64_t)row * dst.cap + li] = g[(r * rows + row) * cap + o];
+    dst.pop[(int64_t)row * dst.cap + li] = src[(int64_t)row * g.cap];
 }
 
 // The draw on packed lines.  Chunk by the offsets `B` (as resample_search: the oracle's answer is defined per chunk); inside
@@ -1160,13 +1321,12 @@ k_cdf_index(double *__restrict__ knots, const int64_t len, const int64_t stride,
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_compact_column(const double *__restrict__ g, const int s, const int stat, const int64_t cap, const int64_t n,
-                 double *__restrict__ out) {
+k_compact_column(const ShardBlocks g, const int stat, const int64_t n, double *__restrict__ out) {
   const int64_t gid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (gid >= n) return;
   int64_t r, o;
-  split_index(gid, cap, r, o);
-  out[gid] = g[(r * s + stat) * cap + o];
+  split_index(gid, g.cap, r, o);
+  out[gid] = shard_block(g, r)[(int64_t)stat * g.cap + o];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1402,10 +1562,33 @@ int launch_reduce_partials(const double *partials, int64_t rows, int np, double 
 }
 
 int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
-                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream) {
+                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream,
+                          const P2PView *pv, uint32_t seq, bool do_control, bool silent) {
   (void)reduce_guarded;   // a guarded reduction is always paired with a guarded control step, which is what decides
-  hipLaunchKernelGGL(k_reduce_control, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb,
-                     a, hist, mbox);
+  XchgArgs x;
+  std::memset(&x, 0, sizeof(x));
+  x.do_control = do_control ? 1 : 0;
+  if (pv) {
+    x.pv = *pv; x.seq = seq; x.silent = silent ? 1 : 0;
+    hipLaunchKernelGGL(k_reduce_control<true>, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
+  } else {
+    hipLaunchKernelGGL(k_reduce_control<false>, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
+  }
+  return SABC_LAUNCH_RC();
+}
+
+int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, bool silent, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, stream, pv, seq, cb, guarded ? 1 : 0, silent ? 1 : 0);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, bool silent, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_commit, dim3(1), dim3(64), 0, stream, pv, call, status, wait ? 1 : 0, cb, silent ? 1 : 0);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(1024), 0, stream, pv, seq, np, in, out, failed);
   return SABC_LAUNCH_RC();
 }
 
@@ -1423,17 +1606,17 @@ int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *
   return SABC_LAUNCH_RC();
 }
 
-int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
+int launch_weight_scan(const ShardBlocks &gathered, int64_t n_global, double *block_sums,
                        double *cum, double *totals, double *totals_host, hipStream_t stream) {
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   double *bs = block_sums, *bq = block_sums + nb, *cm = block_sums + 2 * nb;
   WeightArgs wa;
   std::memset(&wa, 0, sizeof(wa));
-  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, bq, wa);
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
   PackArgs none;
   std::memset(&none, 0, sizeof(none));
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, rows, cap, n_global, bs, cum, cm, none);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, cum, cm, none);
   return SABC_LAUNCH_RC();
 }
 
@@ -1473,13 +1656,14 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
     pa.pk = pack; pa.ge = pack + lines * 16; pa.guide = reinterpret_cast<int32_t *>(pa.ge + pack_ge_doubles(lines));
     pa.totals = totals; pa.row_len = rl; pa.pg = pg;
   }
-  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, bq, wa);
+  const ShardBlocks own = flat_blocks(src.pop, rows, cap, 1);
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, bq, wa);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, (const double *)src.pop, rows, cap, n, bs, cum, cm, pa);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, cum, cm, pa);
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
   if (!pa.pk) {                      // a row does not fit a 128-byte line (d + s > 15): the unpacked gather, sums by the caller
-    hipLaunchKernelGGL(k_resample_gather<true>, grid, block, lds, stream, m.seed, m.d, m.s, (const double *)src.pop, rows, cap, n,
+    hipLaunchKernelGGL(k_resample_gather<true>, grid, block, lds, stream, m.seed, m.d, m.s, own, n,
                        (const double *)cum, (const double *)bs, (const double *)cm, nb, (const double *)totals, iter, dst,
                        (int64_t *)nullptr);
     return SABC_LAUNCH_RC();
@@ -1503,14 +1687,14 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
   return SABC_LAUNCH_RC();
 }
 
-int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
+int launch_resample_gather(const ModelDesc &m, const ShardBlocks &gathered, int64_t n_global,
                            const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
                            hipStream_t stream) {
   if (dst.n_local <= 0) return 0;
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
   hipLaunchKernelGGL(k_resample_gather<true>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
-                     m.s, gathered, rows, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst,
+                     m.s, gathered, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter, dst,
                      (int64_t *)nullptr);
   return SABC_LAUNCH_RC();
 }
@@ -1521,7 +1705,7 @@ int launch_resample_select(const ModelDesc &m, int64_t cap, int64_t n_global, co
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
   hipLaunchKernelGGL(k_resample_gather<false>, dim3((unsigned)n_blocks(dst.n_local)), dim3(kBlock), lds, stream, m.seed, m.d,
-                     m.s, (const double *)nullptr, 0, cap, n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter,
+                     m.s, flat_blocks(nullptr, 0, cap, 1), n_global, cum, block_sums, block_sums + 2 * nb, nb, totals, iter,
                      dst, idx_out);
   return SABC_LAUNCH_RC();
 }
@@ -1571,10 +1755,8 @@ int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, doub
   return SABC_LAUNCH_RC();
 }
 
-int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
-                          hipStream_t stream) {
-  hipLaunchKernelGGL(k_compact_column, dim3((unsigned)n_blocks(n_global)), dim3(kBlock), 0, stream, gathered, s, stat,
-                     cap, n_global, out);
+int launch_compact_column(const ShardBlocks &gathered, int stat, int64_t n_global, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(k_compact_column, dim3((unsigned)n_blocks(n_global)), dim3(kBlock), 0, stream, gathered, stat, n_global, out);
   return SABC_LAUNCH_RC();
 }
 

@@ -2,6 +2,7 @@
 // Every launcher only enqueues work on `stream` and returns the hipError_t of the launch as int.
 #pragma once
 #include "sabc_types.hpp"
+#include "p2p.hpp"
 #if !defined(__HIPCC_RTC__)     // hipRTC (rtc.cpp) compiles the device half of this header only
 #include <hip/hip_runtime_api.h>
 #include "rtc.hpp"
@@ -107,9 +108,16 @@ int launch_reduce_partials(const double *partials, int64_t rows, int np, double 
 // single-lane state hand-over (control.hpp): n_accept, Sigma / Cholesky, eps, pivot, history row
 int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, const double *sums_in,
                    hipStream_t stream);
-// both of the above in one launch (no collective in between)
+// both of the above in one launch: no collective in between (pv == nullptr), or -- several shards -- with the sum over the
+// shards taken through the peer-to-peer slots inside the same launch (p2p.hpp; seq = the exchange's sequence number).
+// rows < 0: the shard's own sums are already in `stage`.  do_control = false: the global sums into `stage`, nothing else.
 int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
-                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream);
+                          ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream,
+                          const P2PView *pv = nullptr, uint32_t seq = 0, bool do_control = true, bool silent = false);
+// flag barrier between the shards' streams / end-of-call status exchange / a row of known values through the slots
+int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, bool silent, hipStream_t stream);
+int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, bool silent, hipStream_t stream);
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, hipStream_t stream);
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
 int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
                             hipStream_t stream);
@@ -119,9 +127,10 @@ inline int64_t weight_scan_doubles(int64_t n_global) {
   const int64_t nb = (n_global + kScanChunk - 1) / kScanChunk;
   return 2 * nb + nb * (kScanChunk / 16);
 }
-// K5b: inclusive scan of the global weight vector (gathered layout [world][rows][cap]) -> cum[n_global];
+// K5b: inclusive scan of the global weight vector (last row of every shard's block: a gathered copy [world][rows][cap] or
+// the owners' own memory, ShardBlocks) -> cum[n_global];
 // totals[0] = sum w, totals[1] = sum w^2                               :129,134
-int launch_weight_scan(const double *gathered, int rows, int64_t cap, int64_t n_global, double *block_sums,
+int launch_weight_scan(const ShardBlocks &gathered, int64_t n_global, double *block_sums,
                        double *cum, double *totals, double *totals_host, hipStream_t stream);
 // K5 on one shard in four launches: weights fused into the first scan pass; the last pass also packs every particle's
 // running sum together with its (theta, u) row, 4 / 2 / 1 particles to a 128-byte line; draw + gather read ONE random line
@@ -132,7 +141,7 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
                           double *partials, int64_t *stats_rows, hipStream_t stream);
 int64_t resample_pack_doubles(int row_len, int64_t n);
 // K5c: n_local categorical draws by inverse CDF + gather of theta and u (not rho)   :129-132
-int launch_resample_gather(const ModelDesc &m, const double *gathered, int rows, int64_t cap, int64_t n_global,
+int launch_resample_gather(const ModelDesc &m, const ShardBlocks &gathered, int64_t n_global,
                            const double *cum, const double *block_sums, const double *totals, uint64_t iter, PopPtrs dst,
                            hipStream_t stream);
 // K5 on shards: the draws as global source indices (no gather); requests grouped by owner shard; rows served by the
@@ -153,8 +162,7 @@ int launch_cdf_knots(const double *sorted, int64_t n, double *knots, int64_t *me
 int launch_cdf_index(double *knots, int64_t len, int64_t stride, int shift, double *coarse, int n_coarse, double *mid,
                      int64_t mid_len, hipStream_t stream);
 // compact one statistic's column out of the gathered rho blocks [world][s][cap] into out[n_global]
-int launch_compact_column(const double *gathered, int s, int stat, int64_t cap, int64_t n_global, double *out,
-                          hipStream_t stream);
+int launch_compact_column(const ShardBlocks &gathered, int stat, int64_t n_global, double *out, hipStream_t stream);
 // ascending sort of n doubles (sort.hip: LSD radix sort, 8 passes of 8 bits); query tmp size with tmp == nullptr
 int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream);
 // host-simulator mode (SABC_MODEL_HOST): the per-particle body cut at f_dist

@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "../../include/sabc_hip.h"
-
+#include "kernels.hpp"
 
 namespace sabc {
 
@@ -32,9 +32,8 @@ struct HiprtcApi {
 
 HiprtcApi *hiprtc_api() {
   static HiprtcApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {
     const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
     for (const char *n : names) {
       api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -53,7 +52,7 @@ HiprtcApi *hiprtc_api() {
       SABC_RTC_SYM(GetLoweredName, "hiprtcGetLoweredName");
 #undef SABC_RTC_SYM
     }
-  }
+  });
   const bool ok = api.lib && api.CreateProgram && api.DestroyProgram && api.CompileProgram && api.GetProgramLogSize &&
                   api.GetProgramLog && api.GetCodeSize && api.GetCode && api.AddNameExpression && api.GetLoweredName;
   return ok ? &api : nullptr;
@@ -145,7 +144,17 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   const char *rocm = std::getenv("ROCM_PATH");
   const std::string inc_rocm = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
   const std::string inc_csrc = "-I" + csrc_dir;
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str()};
+  // the launch geometry the host library was built with (launch_update, build_coarse) must be the one the kernels are
+  // compiled for: a variant library (tools/build_variants.sh) forwards its -D overrides to the run-time compiler
+#define SABC_RTC_STR2(x) #x
+#define SABC_RTC_STR(x) SABC_RTC_STR2(x)
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str(),
+                        "-DSABC_UPDATE_BLOCK=" SABC_RTC_STR(SABC_UPDATE_BLOCK), "-DSABC_UPDATE_BLOCK_MS=" SABC_RTC_STR(SABC_UPDATE_BLOCK_MS),
+                        "-DSABC_CDF_COARSE=" SABC_RTC_STR(SABC_CDF_COARSE), "-DSABC_CDF_COARSE_MS=" SABC_RTC_STR(SABC_CDF_COARSE_MS),
+                        "-DSABC_UPDATE_MIN_WAVES=" SABC_RTC_STR(SABC_UPDATE_MIN_WAVES),
+                        "-DSABC_UPDATE_MIN_WAVES_MS=" SABC_RTC_STR(SABC_UPDATE_MIN_WAVES_MS)};
+#undef SABC_RTC_STR
+#undef SABC_RTC_STR2
   const int rc = api->CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
   size_t ls = 0;
   api->GetProgramLogSize(prog, &ls);

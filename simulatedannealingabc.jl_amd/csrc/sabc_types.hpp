@@ -18,7 +18,7 @@ struct ModelDesc {
   // the normalising constant of logpdf, once on the host: log sigma | log(b - a) | log theta | lgamma(alpha) + alpha log theta
   // | log B(alpha, beta) | log sigma + log(Phi(hi') - Phi(lo'))
   double prior_logc[kMaxPara];
-  double prior_k0[kMaxPara], prior_k1[kMaxPara];   // truncated Normal: Phi(lo'), Phi(hi') - Phi(lo') of the standardised bounds
+  double prior_k0[kMaxPara], prior_k1[kMaxPara];   // truncated Normal: Phi(lo') (lo' > 0: -Phi(-lo'), mirrored draw), Phi(hi') - Phi(lo') of the standardised bounds
   // prior_joint = 1: MvNormal(prior_a, L L'), L row-major d x d lower; logc = d/2 log(2 pi) + sum log L_kk
   int32_t prior_joint, prior_pad;
   double prior_L[kMaxPara * kMaxPara];
@@ -93,8 +93,12 @@ constexpr int kMailboxRing = 8;          // slot = seq % kMailboxRing; the host 
 inline constexpr int n_partials(int d, int s) { return 1 + 2 * s + d + d * (d + 1) / 2; }
 constexpr int kMaxPartials = 1 + 2 * kMaxStats + kMaxPara + kMaxPara * (kMaxPara + 1) / 2;
 
+// shards whose memory a kernel can address directly: the GPUs of one node (peer-mapped over xGMI, csrc/p2p.hpp)
+constexpr int kMaxPeers = 8;
+
 // Where a DifferentialEvolution / StretchMove partner (proposals.jl:105-106,141) is read from:
-// the inactive halves of all shards, laid out [world][rows][cap].
+// the inactive halves of all shards.  direct == 0: one gathered copy, laid out [world][rows][cap] from `base`;
+// direct != 0: shard r's own theta block in the OWNER's HBM, peer[r] (row stride cap, the inactive half at off_*).
 struct PartnerView {
   const double *base;
   int64_t rank_stride;           // doubles between consecutive shards
@@ -102,8 +106,25 @@ struct PartnerView {
   int64_t m_full, m_last;        // inactive-half size of a full shard / of the last shard
   int64_t off_full, off_last;    // where the inactive half starts inside a shard
   int64_t m_total;
-  int32_t world, reserved;
+  int32_t world, direct;
+  const double *peer[kMaxPeers];
 };
+
+// Where shard r's block [rows][cap] of an array that exists once per shard (population, rho) is read from:
+// a gathered copy [world][rows][cap] (direct == 0) or every owner's own memory (direct != 0, world <= kMaxPeers).
+struct ShardBlocks {
+  const double *flat;
+  const double *peer[kMaxPeers];
+  int64_t cap;
+  int32_t rows, world, direct, reserved;
+};
+inline ShardBlocks flat_blocks(const double *g, int rows, int64_t cap, int world) {
+  ShardBlocks b;
+  b.flat = g;
+  for (int r = 0; r < kMaxPeers; ++r) b.peer[r] = nullptr;
+  b.cap = cap; b.rows = rows; b.world = world; b.direct = 0; b.reserved = 0;
+  return b;
+}
 
 // Shard geometry: contiguous blocks of `cap` global ids per rank.
 struct Shard {

@@ -81,7 +81,14 @@ __device__ __forceinline__ const double *partner_ptr(const PartnerView &pv, uint
   if (r > pv.world - 1) r = pv.world - 1;
   const int64_t o = (int64_t)j - r * pv.m_full;
   const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
-  return pv.base + r * pv.rank_stride + off + o;
+  // direct: shard r's theta block in its owner's HBM (peer-mapped, p2p.hpp); else its part of the gathered copy
+  const double *b = pv.direct ? pv.peer[r] : pv.base + r * pv.rank_stride;
+  return b + off + o;
+}
+
+// block [rows][cap] of shard r
+__device__ __forceinline__ const double *shard_block(const ShardBlocks &b, int64_t r) {
+  return b.direct ? b.peer[r] : b.flat + r * (int64_t)b.rows * b.cap;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -94,7 +94,50 @@ def _all_ok(ok, device, group=None):
     return bool(t.item())
 
 
-def install_collectives(handle, device, group=None, prefer=None, alltoallv=True):
+def try_p2p(handle, device, group=None, timeout_ms=None):
+    """Switch `handle` to the peer-to-peer transport (the shards of one node exchange through each other's HBM: one launch
+    per population update instead of reduce -> allreduce -> control; partners and resampled rows read from their owners) if
+    every rank can: world <= 8, all ranks on this host, every peer's memory maps (hipIpc), and the library's self-test --
+    a row of known values through the slots with a bounded wait -- passes everywhere.  The collectives already installed
+    stay as the fallback.  Returns True when the handle now runs peer to peer (the same answer on every rank)."""
+    import socket
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ok = 2 <= world <= 8
+    desc = None
+    if ok:
+        try:
+            desc = handle.p2p_descriptor()
+        except Exception as e:
+            print(f"[sabc] peer-to-peer descriptor failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
+            ok = False
+    box = [None] * world
+    dist.all_gather_object(box, (socket.gethostname(), desc), group=group)
+    ok = ok and all(b[1] is not None for b in box) and len({b[0] for b in box}) == 1
+    if not _all_ok(ok, device, group):
+        return False
+    try:
+        if timeout_ms:
+            handle.p2p_set_timeout(timeout_ms)
+        handle.p2p_init([b[1] for b in box])
+    except Exception as e:
+        print(f"[sabc] peer-to-peer mapping failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
+        ok = False
+    if not _all_ok(ok, device, group):      # somebody could not map a peer: nobody runs the self-test (it would wait for them)
+        handle.p2p_disable()
+        return False
+    try:
+        handle.p2p_selftest()
+    except Exception as e:
+        print(f"[sabc] peer-to-peer self-test failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
+        ok = False
+    if not _all_ok(ok, device, group):
+        handle.p2p_disable()
+        return False
+    return True
+
+
+def install_collectives(handle, device, group=None, prefer=None, alltoallv=True, p2p=None):
     """Give `handle` its allreduce / allgather.
 
     prefer="rccl": RCCL bound inside the library (ncclAllReduce / ncclAllGather enqueued on the
@@ -103,8 +146,22 @@ def install_collectives(handle, device, group=None, prefer=None, alltoallv=True)
     rank fails to set it up or the self-test fails, every rank falls back to the hooks.
     prefer="hooks": torch.distributed collectives through the C-ABI hooks (the only choice for "gloo").
     alltoallv=False leaves the personalised exchange out (hooks only): the resample then allgathers the whole population.
-    Returns the transport in use: "rccl", "hooks-nccl" (device pointers, Python in the per-update path) or "hooks-gloo"
-    (host staged; for tests)."""
+    p2p (default: env SABC_P2P, else on for "nccl" groups): after the collectives are in place, try the peer-to-peer
+    transport on top of them (try_p2p); they stay installed as the fallback a failed peer-to-peer call returns to.
+    Returns the transport in use: "p2p", "rccl", "hooks-nccl" (device pointers, Python in the per-update path) or
+    "hooks-gloo" (host staged; for tests); `handle.fallback_transport` names what sits underneath "p2p"."""
+    base = _install_base(handle, device, group, prefer, alltoallv)
+    handle.fallback_transport = base
+    import os
+    import torch.distributed as dist
+    if p2p is None:
+        p2p = os.environ.get("SABC_P2P", "1" if dist.get_backend(group) == "nccl" else "0") not in ("0", "", "off")
+    if p2p and try_p2p(handle, device, group) and handle.p2p_active:    # (a host-callback simulator keeps to the collectives)
+        return "p2p"
+    return base
+
+
+def _install_base(handle, device, group=None, prefer=None, alltoallv=True):
     import os
     import torch.distributed as dist
     from .handle import rccl_unique_id

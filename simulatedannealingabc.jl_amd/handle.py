@@ -139,6 +139,42 @@ class SabcHandle:
     def comm_selftest(self):
         self._check(self._L.sabc_comm_selftest(self._h))
 
+    # ---- peer-to-peer transport: the shards of one node exchange through each other's HBM (include/sabc_hip.h) ----
+    def p2p_descriptor(self) -> bytes:
+        """What the other shards need to map this shard's slot area, populations and rho (IPC handles + pid + pointers)."""
+        buf = C.create_string_buffer(_lib.P2P_DESC_BYTES)
+        self._check(self._L.sabc_comm_p2p_descriptor(self._h, C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def p2p_init(self, all_descriptors=None):
+        """all_descriptors: the descriptors of all shards in rank order (bytes, or a list of bytes); None lets the library
+        exchange them over the collectives already installed."""
+        if all_descriptors is None:
+            self._check(self._L.sabc_comm_p2p_init(self._h, None))
+            return
+        blob = b"".join(all_descriptors) if not isinstance(all_descriptors, (bytes, bytearray)) else bytes(all_descriptors)
+        if len(blob) != self.cfg.world * _lib.P2P_DESC_BYTES:
+            raise ValueError("one descriptor per shard, in rank order")
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self._L.sabc_comm_p2p_init(self._h, C.cast(buf, C.c_void_p)))
+
+    def p2p_selftest(self):
+        self._check(self._L.sabc_comm_p2p_selftest(self._h))
+
+    def p2p_set_timeout(self, milliseconds):
+        self._check(self._L.sabc_comm_p2p_set_timeout(self._h, float(milliseconds)))
+
+    def p2p_disable(self):
+        self._check(self._L.sabc_comm_p2p_disable(self._h))
+
+    @property
+    def p2p_active(self):
+        return bool(self._L.sabc_comm_p2p_active(self._h))
+
+    def p2p_inject_silence(self, n=1):
+        """Test hook: this shard skips its next n posts, so that its peers run into the bound of their waits."""
+        self._check(self._L.sabc_comm_p2p_inject_silence(self._h, int(n)))
+
     # ---- state ----
     @property
     def n_local(self):
@@ -247,6 +283,14 @@ class SabcHandle:
     @property
     def host_syncs(self):
         return int(self._L.sabc_host_syncs(self._h))
+
+    @property
+    def kernel_launches(self):
+        return int(self._L.sabc_kernel_launches(self._h))
+
+    @property
+    def collective_calls(self):
+        return int(self._L.sabc_collective_calls(self._h))
 
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))

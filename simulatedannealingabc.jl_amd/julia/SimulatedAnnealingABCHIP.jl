@@ -275,7 +275,7 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     pd = host_prior ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
     joint, chol = host_prior ? (Int32(2), Float64[]) : prior_chol(prior)
     p = params(f_dist)
-    cfg = Ref(CConfig(3, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
+    cfg = Ref(CConfig(4, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
                       padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(getindex.(pd, 3), MAX_PARA, Float64),

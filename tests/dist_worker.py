@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--updates", type=int, default=10)
     ap.add_argument("--resample", type=float, default=0.0)
     ap.add_argument("--alltoallv", type=int, default=1, help="0: no personalised exchange (the resample allgathers the population)")
+    ap.add_argument("--p2p", type=int, default=0, help="1: the peer-to-peer transport on top of the collectives (hip engine only)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -57,8 +58,9 @@ def main():
     h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
     transport = "none"
     if world > 1:
-        transport = install_collectives(h, device, alltoallv=bool(a.alltoallv))
-        assert transport in ("rccl", "hooks-nccl", "hooks-gloo"), transport
+        transport = install_collectives(h, device, alltoallv=bool(a.alltoallv), p2p=bool(a.p2p) if a.engine == "hip" else False)
+        assert transport in ("p2p", "rccl", "hooks-nccl", "hooks-gloo"), transport
+    calls0 = h.collective_calls if a.engine == "hip" else 0       # (the self-test of the base transport used some)
     h.initialize((a.updates + 1) * a.n)
     bytes_init = h.comm_bytes
     h.update(n_simulation=a.updates * a.n, proposal=hip_proposal(S, a.prop, d),
@@ -73,7 +75,8 @@ def main():
                  rho=np.concatenate([p[3] for p in parts], 1), eps=h.eps, eps_hist=e, u_hist=uh, rho_hist=rh,
                  counters=np.array([h.counters[k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]),
                  sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]),
-                 comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]), transport=np.array(transport))
+                 comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]), transport=np.array(transport),
+                 collective_calls=np.array((h.collective_calls - calls0) if a.engine == "hip" else -1))
     dist.barrier()
     h.close()
     dist.destroy_process_group()

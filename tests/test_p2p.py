@@ -1,0 +1,183 @@
+"""The peer-to-peer transport (csrc/p2p.hpp, include/sabc_hip.h "sabc_comm_p2p_*"): the shards of one node exchange
+through each other's HBM -- reduce -> exchange -> control step in ONE launch per population update, DE / Stretch partners
+and resampled rows read from their owner's memory, every wait bounded.
+
+Every box this repository has seen has ONE MI355X, so both forms run on it:
+  * two shards in ONE process (a host thread and a stream each; the peers' memory is the pointer itself) with NO other
+    transport installed -- the peer-to-peer path carries the whole run, initialisation included;
+  * two PROCESSES sharing the GPU, the peers' slot areas / populations / rho mapped with hipIpcOpenMemHandle -- the very
+    mapping two GPUs of a node use, minus the xGMI hop (which stays unmeasured).
+Both must equal the CPU engine (engine.cpp over the oracle-backed Backend) with the same sharding.  And a shard that never
+posts makes its peers return SABC_ERR_COMM within the bound, with the state as sabc_update's error contract says."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_distributed import launch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}
+
+
+def run_shards_in_one_process(S, case, alg, prop, n, k, resample, world=2, timeout_ms=None, before_update=None, calls=1):
+    """One host thread + one stream per shard; descriptors exchanged through a Python list.  before_update(rank, handle,
+    call) may tamper with a shard; returns per-rank dicts (or the exception a shard's call raised)."""
+    import torch
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+    d = len(MODELS[case]["prior"])
+    descs, out, err = [None] * world, [None] * world, [None] * world
+    barrier = threading.Barrier(world)
+
+    def shard(rank):
+        try:
+            torch.cuda.set_device(0)
+            model, prior = hip_model_prior(S, case)
+            h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=world,
+                             algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
+
+            def setup():
+                descs[rank] = h.p2p_descriptor()
+                barrier.wait()
+                if timeout_ms:
+                    h.p2p_set_timeout(timeout_ms)
+                h.p2p_init(list(descs))
+                barrier.wait()
+                h.p2p_selftest()
+                assert h.p2p_active
+
+            setup()
+            h.initialize((calls * k + 1) * n)
+            res = dict(rank=rank, offset=h.local_offset, errors=[], seconds=[])
+            launches0, syncs0 = h.kernel_launches, h.host_syncs
+            for call in range(calls):
+                before = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.history], [a.copy() for a in h.get_population()])
+                if before_update:
+                    before_update(rank, h, call)
+                t0 = time.perf_counter()
+                try:
+                    h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=resample)
+                    res["errors"].append(None)
+                except S.SABCError as e:
+                    res["errors"].append(e)
+                    res["seconds"].append(time.perf_counter() - t0)
+                    # the error contract of sabc_update: counters, eps, histories as at entry; the handle refuses updates
+                    assert dict(h.counters) == before[0]
+                    np.testing.assert_array_equal(h.eps, before[1])
+                    for a, b in zip(h.history, before[2]):
+                        np.testing.assert_array_equal(a, b)
+                    assert not h.p2p_active                          # back on the (here: absent) fallback transport
+                    with pytest.raises(S.SABCError, match="half-updated"):
+                        h.update(n_simulation=n, proposal=hip_proposal(S, prop, d))
+                    barrier.wait()                                   # both shards are out of the failed call
+                    h.set_population(*before[3])                     # what the wrapper does from the result's own arrays
+                    setup()                                          # a fresh peer-to-peer set-up (sequence numbers start over)
+                    h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=resample)
+            th, u, rho = h.get_population()
+            res.update(theta=th, u=u, rho=rho, eps=h.eps, counters=h.counters, launches=h.kernel_launches - launches0,
+                       syncs=h.host_syncs - syncs0, collective_calls=h.collective_calls, comm=h.comm_bytes, hist=h.history)
+            out[rank] = res
+            barrier.wait()                                           # nobody frees memory a peer may still be reading
+            h.close()
+        except BaseException as e:                                   # a failing shard must not leave the other at a barrier
+            err[rank] = e
+            barrier.abort()
+
+    threads = [threading.Thread(target=shard, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert all(e is None for e in err), err
+    assert all(o is not None for o in out)
+    return out
+
+
+def check_against_cpu_engine(out, ref, prop):
+    tol = TOL[prop]
+    theta = np.concatenate([o["theta"] for o in out], 1)
+    u = np.concatenate([o["u"] for o in out], 1)
+    rho = np.concatenate([o["rho"] for o in out], 1)
+    c = out[0]["counters"]
+    assert [c[q] for q in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")] == list(ref["counters"])
+    assert all(o["counters"] == c for o in out)
+    np.testing.assert_allclose(theta, ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(u, ref["u"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(rho, ref["rho"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(out[0]["eps"], ref["eps"], rtol=tol)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o["eps"], out[0]["eps"])      # rank-order sums: bitwise the same control step everywhere
+        for a, b in zip(o["hist"], out[0]["hist"]):
+            np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 200_001), ("gauss2_2stats", "multi_eps", "de", 60_000),
+                                              ("gauss2d_cfg3", "single_eps", "stretch", 40_000),
+                                              ("gauss2_2stats", "single_eps", "de", 10_003),      # ragged last shard, odd halves
+                                              ("gk_cfg4", "multi_eps", "de", 2003), ("lv_cfg5", "single_eps", "rw", 1500)])
+def test_p2p_two_shards_in_one_process(S, gpu, tmp_path, case, alg, prop, n):
+    """No collectives installed at all: initialisation (ECDF over the owners' rho blocks), every update (one launch: reduce ->
+    exchange -> control step; DE / Stretch: a flag barrier between the half batches, partners read in place), resamples
+    firing with an update queued ahead (weights -> barrier -> scan of the owners' weight rows -> rows read from their owners)
+    all run over the mapped memory, and equal the CPU engine with the same sharding."""
+    k = 12
+    out = run_shards_in_one_process(S, case, alg, prop, n, k, resample=n // 4)
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    check_against_cpu_engine(out, ref, prop)
+    assert out[0]["counters"]["n_resampling"] >= 3
+    assert all(o["collective_calls"] == 0 for o in out)              # nothing went through a collective
+    # launches per population update: k_update (x2 + a barrier for DE / Stretch) + ONE reduce-exchange-control launch;
+    # each resample adds weights + barrier + 3 scan passes + gather + stats and its own exchange launch
+    per_update = 2 if prop == "rw" else 4
+    resamples = out[0]["counters"]["n_resampling"] - 1
+    entry = 2 if prop == "rw" else 2                                # the sums of the population at update_population! entry (:284)
+    assert out[0]["launches"] <= k * per_update + resamples * (8 + per_update) + 2 * entry + 4, out[0]["launches"]
+
+
+@pytest.mark.parametrize("case,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 20_001), ("gauss2_2stats", "multi_eps", "de", 10_000),
+                                              ("gauss2d_cfg3", "single_eps", "stretch", 10_000)])
+def test_p2p_two_processes_over_hip_ipc(S, gpu, tmp_path, case, alg, prop, n):
+    """Two processes sharing the one MI355X: each maps the other's slot area, populations and rho with
+    hipIpcOpenMemHandle (gloo only carries the descriptors and stays installed as the fallback).  Same result as the CPU
+    engine with the same sharding."""
+    k = 10
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4, p2p=1)
+    assert str(got["transport"]) == "p2p"
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    tol = TOL[prop]
+    assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["rho"], ref["rho"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)
+    assert int(got["collective_calls"]) == 0                         # the installed gloo hooks were never used by the engine
+
+
+@pytest.mark.parametrize("prop,silent_call", [("rw", 0), ("de", 0), ("rw", 1)])
+def test_p2p_a_silent_shard_fails_the_call_within_the_bound(S, gpu, tmp_path, prop, silent_call):
+    """Shard 1 skips one post in the middle of a call (test hook sabc_comm_p2p_inject_silence).  Shard 0 runs into the bound
+    of its wait, shard 1 into the bound of the NEXT one (shard 0 has stopped posting): both calls return SABC_ERR_COMM
+    within a few bounds -- nobody hangs --, counters / eps / histories are back at their values at entry, the handles
+    refuse updates until the particles are restored, and after restoring them and a fresh set-up the repeated call gives
+    exactly the uninterrupted run."""
+    case, n, k, bound_ms = "gauss1_cfg2", 20_000, 8, 300.0
+
+    def tamper_mid_call(rank, h, call):
+        if rank == 1 and call == silent_call:
+            h.p2p_inject_silence(-5)                                 # negative: 5 more posts go out, THEN one is skipped
+
+    out = run_shards_in_one_process(S, case, "single_eps", prop, n, k, resample=n // 4, timeout_ms=bound_ms,
+                                    before_update=tamper_mid_call, calls=2)
+    for o in out:
+        failed = [e for e in o["errors"] if e is not None]
+        assert len(failed) == 1 and failed[0].code == -22, o["errors"]          # SABC_ERR_COMM on BOTH shards, once
+        assert o["errors"][silent_call] is not None
+        assert o["seconds"][0] < 10 * bound_ms * 1e-3 + 2.0, o["seconds"]       # bounded: a few waits, not a hang
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop=prop, n=n,
+                 updates=2 * k, resample=n // 4)
+    # two calls of k updates == one call of 2k updates on the CPU engine (the repeated call included)
+    check_against_cpu_engine(out, ref, prop)

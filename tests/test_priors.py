@@ -21,6 +21,9 @@ FAMILIES = {
     "beta_u_shaped": (("B", 0.5, 0.7), stats.beta(0.5, 0.7)),
     "truncnormal": (("T", 1.0, 2.0, -0.5, 2.5), stats.truncnorm((-0.5 - 1.0) / 2.0, (2.5 - 1.0) / 2.0, loc=1.0, scale=2.0)),
     "truncnormal_upper_tail": (("T", 0.0, 1.0, 2.0, 6.0), stats.truncnorm(2.0, 6.0)),
+    # Phi(8) rounds to 1 - 6e-16: drawn in the mirrored lower tail, else every draw lands on a bound
+    "truncnormal_far_tail": (("T", 0.0, 1.0, 8.0, 9.0), stats.truncnorm(8.0, 9.0)),
+    "truncnormal_half_line": (("T", 1.0, 0.5, 5.5, np.inf), stats.truncnorm(9.0, np.inf, loc=1.0, scale=0.5)),
 }
 M = 40_000
 
