@@ -241,7 +241,13 @@ int Engine::sync_control() {
     case 0: return 0;
     case SABC_ERR_ZERO_MEAN_U: return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
     case SABC_ERR_NOT_POSDEF: return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
-    case SABC_ERR_COMM: return fail(SABC_ERR_COMM, "peer-to-peer exchange: a shard did not post within the bound (or reported a failed call)");
+    case SABC_ERR_COMM: {
+      static const char *kind[4] = {"?", "sums exchange", "barrier", "end-of-call status"};
+      char buf[200];
+      std::snprintf(buf, sizeof(buf), "peer-to-peer %s %d: shard %d did not post within the bound (or reported a failed call)",
+                    kind[(cb_.comm_where >> 24) & 3], cb_.comm_where & 0xFFFFF, (cb_.comm_where >> 20) & 15);
+      return fail(SABC_ERR_COMM, buf);
+    }
     default: return fail(cb_.error, "error raised by the device-side control step");
   }
 }
@@ -409,6 +415,7 @@ int Engine::initialize(int64_t n_simulation) {
   }
   const int rc = initialize_body();
   if (rc) { const std::string why = err_; p2p_abort(); err_ = why; }
+  be_->end_of_call();
   return rc;
 }
 
@@ -543,6 +550,7 @@ int Engine::update(const sabc_update_args &a) {
     p2p_abort();
     err_ = why;
   }
+  if (rc != SABC_ERR_STATE) be_->end_of_call();
   return rc;
 }
 

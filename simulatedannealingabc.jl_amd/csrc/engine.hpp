@@ -92,6 +92,8 @@ class Backend {
     return resample_draw(pop_block(), iter);
   }
   virtual double last_ess() = 0;
+  // the call's last exchange has completed on every shard: housekeeping that must not run while a peer may be waiting
+  virtual void end_of_call() {}
   // ---- peer-to-peer transport (p2p.hpp): the shards of one node exchange through each other's mapped memory.  A backend
   //      without it never reports p2p_active() and the engine keeps to the Collectives.
   virtual bool p2p_active() const { return false; }

@@ -25,10 +25,23 @@ namespace sabc {
 
 HipBackend::HipBackend(int device) : device_(device) {}
 
+// hipFree waits for EVERY stream of the process.  With several shards in one process (tests; a Julia host driving the GPUs
+// of a node from threads) a peer's kernel may be spinning for this shard's next post, which the host cannot enqueue while
+// it sits in hipFree: nothing is freed inside a call.  end_of_call() runs after the call's last exchange.
+void HipBackend::free_later(void *p) {
+  if (p) deferred_free_.push_back(p);
+}
+
+void HipBackend::end_of_call() {
+  for (void *p : deferred_free_) (void)hipFree(p);
+  deferred_free_.clear();
+}
+
 HipBackend::~HipBackend() {
   if (!stream_ && !pop_[0]) return;                // never allocated (e.g. create failed on a bad device ordinal)
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  end_of_call();
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : ev_pool_) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -145,7 +158,7 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
 double *HipBackend::gather_buffer(int64_t doubles) {
   if (doubles > gather_cap_) {
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (gather_) (void)hipFree(gather_);
+    free_later(gather_);
     gather_ = nullptr;
     gather_cap_ = 0;
     if (hipMalloc((void **)&gather_, (size_t)doubles * sizeof(double)) != hipSuccess) return nullptr;
@@ -158,7 +171,7 @@ double *HipBackend::scratch_buffer(int which, int64_t doubles) {
   if (which < 0 || which >= 4) return nullptr;
   if (doubles > scratch_cap_[which]) {
     if (stream_) (void)hipStreamSynchronize(stream_);
-    if (scratch_[which]) (void)hipFree(scratch_[which]);
+    free_later(scratch_[which]);
     scratch_[which] = nullptr;
     scratch_cap_[which] = 0;
     const int64_t want = doubles + doubles / 4 + 64;       // head room: the request count of a resample varies from one to the next
@@ -385,7 +398,7 @@ int HipBackend::build_cdf_blocks(const ShardBlocks &rho_blocks, int64_t *len_out
     if (cdf_len_[j] > 0 && build_coarse(j)) return -1;
   }
   // the sort scratch is only needed once per result
-  (void)hipFree(col_a_); (void)hipFree(col_b_); (void)hipFree(sort_tmp_);
+  free_later(col_a_); free_later(col_b_); free_later(sort_tmp_);
   col_a_ = col_b_ = nullptr; sort_tmp_ = nullptr;
   return 0;
 }
@@ -530,7 +543,7 @@ int HipBackend::history_reserve(int64_t rows) {
     int64_t cap = hist_cap_ > 0 ? 2 * hist_cap_ : 4096;
     if (cap < rows) cap = rows;
     HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    if (hist_dev_) (void)hipFree(hist_dev_);
+    free_later(hist_dev_);
     hist_dev_ = nullptr;
     HB_CHECK(hipMalloc((void **)&hist_dev_, (size_t)cap * row_len * sizeof(double)), "hipMalloc(history)");
     hist_cap_ = cap;

@@ -54,6 +54,7 @@ class HipBackend : public Backend {
   int resample_serve(const double *req_in, int64_t m, double *rows_out) override;
   int resample_scatter(const double *rows_in) override;
   double last_ess() override;
+  void end_of_call() override;
   int download(double *theta, double *u, double *rho) override;
   int upload(const double *theta, const double *u, const double *rho) override;
   int get_knots(int stat, double *out, int64_t len) override;
@@ -149,6 +150,8 @@ class HipBackend : public Backend {
   int ensure_host_buffers();
   RtcKernels rtc_;                                        // SABC_MODEL_USER: kernels compiled from the user's source
   const RtcKernels *rtc() const { return rtc_.module ? &rtc_ : nullptr; }
+  void free_later(void *p);                               // device memory released by end_of_call(), never inside a call
+  std::vector<void *> deferred_free_;
   // peer-to-peer transport
   int build_cdf_blocks(const ShardBlocks &rho_blocks, int64_t *len_out, int *any_negative);
   P2PView p2p_view() const;

@@ -577,10 +577,11 @@ __device__ __forceinline__ uint64_t p2p_load(const uint64_t *p) {
 __device__ __forceinline__ uint64_t p2p_clock() { return (uint64_t)wall_clock64(); }
 
 // spin until the word's upper half is `seq`; gives up after `ticks` (or as soon as another lane of the workgroup has)
-__device__ __forceinline__ uint64_t p2p_wait_word(const uint64_t *src, uint32_t seq, uint64_t t0, uint64_t ticks, volatile int *failed) {
+__device__ __forceinline__ uint64_t p2p_wait_word(const uint64_t *src, uint32_t seq, uint64_t t0, uint64_t ticks, volatile int *failed,
+                                                  int peer) {
   uint64_t w = p2p_load(src);
   for (uint32_t polls = 1; (uint32_t)(w >> 32) != seq; ++polls) {
-    if ((polls & 15u) == 0 && (*failed || p2p_clock() - t0 > ticks)) { *failed = 1; break; }
+    if ((polls & 15u) == 0 && (*failed || p2p_clock() - t0 > ticks)) { if (!*failed) *failed = 1 + peer; break; }
     __builtin_amdgcn_s_sleep(2);
     w = p2p_load(src);
   }
@@ -589,10 +590,12 @@ __device__ __forceinline__ uint64_t p2p_wait_word(const uint64_t *src, uint32_t 
 
 // a wait gave up: the error goes into the control block together with the halt flag (everything queued behind becomes a
 // no-op) and, if the host is waiting for this step, into the mailbox
-__device__ __forceinline__ void p2p_fail(ControlBlock *cb, ControlBlock *lcb, const ControlArgs *a, Mailbox *ring) {
+__device__ __forceinline__ void p2p_fail(ControlBlock *cb, ControlBlock *lcb, const ControlArgs *a, Mailbox *ring, int kind, int failed,
+                                         uint32_t seq) {
   cb->error = SABC_ERR_COMM;
   cb->halt = 1;
-  if (lcb) { lcb->error = SABC_ERR_COMM; lcb->halt = 1; }
+  cb->comm_where = (kind << 24) | (((failed - 1) & 15) << 20) | (int)(seq & 0xFFFFFu);
+  if (lcb) { lcb->error = SABC_ERR_COMM; lcb->halt = 1; lcb->comm_where = cb->comm_where; }
   __threadfence();
   if (lcb && a && ring && a->notify_seq != 0) mailbox_post(ring, *a, *lcb);
 }
@@ -613,7 +616,7 @@ __device__ __forceinline__ bool p2p_allreduce_rows(const P2PView &pv, const uint
   for (int i = threadIdx.x; i < W * nw; i += blockDim.x) {
     const int r = i / nw, t = i - r * nw;
     const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PSumsOff + ((int64_t)ring * kMaxPeers + r) * kP2PWords + t, seq, t0,
-                                     pv.timeout_ticks, failed);
+                                     pv.timeout_ticks, failed, r);
     words[i] = (uint32_t)w;
   }
   __syncthreads();
@@ -700,7 +703,7 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
       return;
     }
     if (!p2p_allreduce_rows(x.pv, x.seq, np, sums, words, &failed, x.silent)) {
-      if (threadIdx.x == 0) p2p_fail(cb, &lcb, x.do_control ? &a : nullptr, ring);
+      if (threadIdx.x == 0) p2p_fail(cb, &lcb, x.do_control ? &a : nullptr, ring, 1, failed, x.seq);
       return;
     }
     if (!x.do_control) {
@@ -723,9 +726,9 @@ k_p2p_barrier(const P2PView pv, const uint32_t seq, ControlBlock *cb, const int 
   __threadfence_system();
   if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PBarOff + (int64_t)ring * kMaxPeers + pv.rank, ((uint64_t)seq << 32) | 1u);
   if (r < pv.world)
-    (void)p2p_wait_word(pv.slots[pv.rank] + kP2PBarOff + (int64_t)ring * kMaxPeers + r, seq, p2p_clock(), pv.timeout_ticks, &failed);
+    (void)p2p_wait_word(pv.slots[pv.rank] + kP2PBarOff + (int64_t)ring * kMaxPeers + r, seq, p2p_clock(), pv.timeout_ticks, &failed, r);
   __syncthreads();
-  if (threadIdx.x == 0 && failed) p2p_fail(cb, nullptr, nullptr, nullptr);
+  if (threadIdx.x == 0 && failed) p2p_fail(cb, nullptr, nullptr, nullptr, 2, failed, seq);
   __threadfence_system();
 }
 
@@ -742,11 +745,11 @@ k_p2p_commit(const P2PView pv, const uint32_t call, const int status, const int 
   if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PCommitOff + pv.rank, ((uint64_t)call << 32) | (uint32_t)mine);
   if (!wait) return;
   if (r < pv.world) {
-    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PCommitOff + r, call, p2p_clock(), pv.timeout_ticks, &failed);
-    if ((uint32_t)w != 0u) failed = 1;                                    // the peer's call failed
+    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PCommitOff + r, call, p2p_clock(), pv.timeout_ticks, &failed, r);
+    if ((uint32_t)w != 0u && !failed) failed = 1 + r;                     // the peer's call failed
   }
   __syncthreads();
-  if (threadIdx.x == 0 && failed && cb->error == 0) p2p_fail(cb, nullptr, nullptr, nullptr);
+  if (threadIdx.x == 0 && failed && cb->error == 0) p2p_fail(cb, nullptr, nullptr, nullptr, 3, failed, call);
 }
 
 // rows of known values through the slots, for sabc_comm_p2p_selftest: out[q] = sum over shards of in[q]
@@ -761,7 +764,7 @@ k_p2p_selftest(const P2PView pv, const uint32_t seq, const int np, const double 
   __syncthreads();
   const bool ok = p2p_allreduce_rows(pv, seq, np, sums, words, &failed, 0);
   if (ok && (int)threadIdx.x < np) out[threadIdx.x] = sums[threadIdx.x];
-  if (threadIdx.x == 0) *failed_out = ok ? 0 : 1;
+  if (threadIdx.x == 0) *failed_out = ok ? 0 : failed;
 }
 
 // K3 over the shard: u = cdf(rho)  (:190-192)

@@ -48,7 +48,7 @@ struct ControlBlock {
   int32_t error;                         // 0 or a SABC_ERR_* raised on the device
   int32_t eps_len;
   int32_t halt;                          // set when the resample test (:340) fires: queued-ahead kernels become no-ops
-  int32_t reserved;
+  int32_t comm_where;                    // SABC_ERR_COMM: which peer-to-peer wait gave up (kind << 24 | peer << 20 | seq & 0xFFFFF)
 };
 
 // what the control kernel is asked to do after a reduction

@@ -9,6 +9,7 @@ Every box this repository has seen has ONE MI355X, so both forms run on it:
     mapping two GPUs of a node use, minus the xGMI hop (which stays unmeasured).
 Both must equal the CPU engine (engine.cpp over the oracle-backed Backend) with the same sharding.  And a shard that never
 posts makes its peers return SABC_ERR_COMM within the bound, with the state as sabc_update's error contract says."""
+import os
 import threading
 import time
 
@@ -37,6 +38,10 @@ def run_shards_in_one_process(S, case, alg, prop, n, k, resample, world=2, timeo
             model, prior = hip_model_prior(S, case)
             h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=world,
                              algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
+            if os.environ.get("SABC_TEST_STREAM_PRIO"):
+                # streams of different priorities never share a hardware queue (the runtime keeps a pool per priority)
+                keep_stream = torch.cuda.Stream(device=0, priority=-1 if rank % 2 else 0)
+                h.set_stream(keep_stream.cuda_stream)
 
             def setup():
                 descs[rank] = h.p2p_descriptor()
