@@ -84,21 +84,91 @@ def _load_traffic(workload_n):
     return None
 
 
-def load_sq_summary(workload_n, config="cfg2"):
-    """VALU busy fraction / effective clock of the update kernel from the committed SQ counter passes (tools/pmc_sq.sh)."""
+def load_from_profiles(workload_n, config="cfg2"):
+    """Numbers that do NOT come from this run: read from the rocprofv3 passes committed under profiles/ (same command, an
+    earlier box).  Kept under one key of the JSON line so that they cannot be mistaken for live measurements."""
+    out = {}
     if int(workload_n) != 1_000_000:
-        return {}
+        return out
     try:
         import csv
-        name = f"r02_pmc_sq_{config}.csv"
-        rows = {r["name"]: float(r["value"]) for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name)))}
-        return {"pmc_valu_busy_fraction": rows["valu_busy_fraction"], "pmc_effective_clock_ghz": rows["effective_clock_ghz"],
-                "pmc_cycles_per_valu_instruction": rows["cycles_per_valu_instruction"],
-                "pmc_wave_cycles_parked": rows["wave_cycles_parked_waitcnt_barrier"],
-                "pmc_note": f"rocprofv3 --pmc SQ_* passes of the same command (profiles/{name}): share of the SQ busy "
-                            "cycles in which a SIMD's VALU executes"}
+        import subprocess
+        for tag in ("r03", "r02"):
+            name = f"{tag}_pmc_sq_{config}.csv"
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                break
+        rows = {r["name"]: float(r["value"]) for r in csv.DictReader(open(path))}
+        out.update({"pmc_valu_busy_fraction": rows["valu_busy_fraction"], "pmc_effective_clock_ghz": rows["effective_clock_ghz"],
+                    "pmc_cycles_per_valu_instruction": rows["cycles_per_valu_instruction"],
+                    "pmc_wave_cycles_parked": rows["wave_cycles_parked_waitcnt_barrier"], "source": f"profiles/{name}",
+                    "note": "rocprofv3 --pmc SQ_* passes of the same command, committed; NOT measured in this run"})
+        try:
+            out["commit"] = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", path], capture_output=True,
+                                           text=True, timeout=5).stdout.strip() or None
+        except Exception:
+            out["commit"] = None
     except Exception:
-        return {}
+        pass
+    t = load_traffic(workload_n, config)
+    if t is not None:
+        out["hbm_bytes_per_launch"] = t
+        out["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE / WRITE_SIZE passes)"
+    return out
+
+
+def bench_host_path(args):
+    """`--config host`: the path every model that is not device code takes -- f_dist as a host callable
+    (SimulatedAnnealingABC.jl:315).  Per population update: callback_us = time inside the caller's
+    function(s), library_us = everything else (proposal and accept kernels, zero-copy staging over PCIe, fused sums,
+    control step, the mailbox wait).  Rows: BASELINE config 2's simulator as a vectorised NumPy callable at n = 100 (the
+    reference's default), 5 000 (the size of its documentation example, docs/src/example.md:190-198) and 1e6; and the
+    documentation's Gillespie SIR model itself (one Python call per particle) at n = 5 000."""
+    import torch
+    import sabc_amd as S
+    from sabc_amd.examples import gaussian_mean_batched, sir_gillespie
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the SABC engine has no CPU path")
+    rows = []
+
+    def run(label, model, prior, n, proposal, warm, steps):
+        h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+        h.initialize(n)
+        if warm:
+            h.update(n_simulation=warm * n, proposal=proposal)
+        torch.cuda.synchronize()
+        cb0, calls0, l0 = h.host_callback_seconds, h.host_callback_calls, h.kernel_launches
+        t0 = time.perf_counter()
+        h.update(n_simulation=steps * n, proposal=proposal)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cb = h.host_callback_seconds - cb0
+        rows.append({"model": label, "n_particles": n, "proposal": type(proposal).__name__, "updates": steps,
+                     "per_update_us": dt / steps * 1e6, "callback_us": cb / steps * 1e6, "library_us": (dt - cb) / steps * 1e6,
+                     "library_over_callback": (dt - cb) / cb if cb > 0 else None,
+                     "f_dist_calls_per_update": (h.host_callback_calls - calls0) / steps,
+                     "kernel_launches_per_update": (h.kernel_launches - l0) / steps,
+                     "particle_sims_per_s": steps * n / dt})
+        h.close()
+
+    yb = observed_mean()
+    for n, warm, steps in ((100, 20, 200), (5000, 10, 100), (1_000_000, 2, 10)):
+        fn = gaussian_mean_batched(yb, 100, seed=1)
+        model = S.HostDistance(fn, n_stats=1, n_para=1, univariate=True, batched=True)
+        for prop in (S.RandomWalk(n_para=1), S.DifferentialEvolution(n_para=1)):
+            run("cfg2 simulator, vectorised NumPy", model, S.Normal(0.0, 2.0), n, prop, warm, steps)
+    simulate, f_sir = sir_gillespie(seed=11)
+    data = simulate(0.6, 0.15)
+    model = S.HostDistance(f_sir, n_stats=1, n_para=2, univariate=False, args=(data,))
+    prior = S.product_distribution([S.Uniform(0.1, 1), S.Uniform(0.05, 0.5)])
+    run("docs SIR (Gillespie), one Python call per particle", model, prior, 5000, S.DifferentialEvolution(n_para=2), 0, args.host_sir_updates)
+    out = {"metric": "host-callback f_dist path: library microseconds per population update", "unit": "us", "n_gpus": 1,
+           "higher_is_better": False, "data": "synthetic", "dtype": "f64",
+           "config": {"workload": "f_dist as a host callable (SABC_MODEL_HOST): proposal / ECDF / accept / sums on the device, "
+                                  "simulator in the caller's Python function"},
+           "value": rows[0]["library_us"], "rows": rows,
+           "note": "value = library_us at n = 100 (RandomWalk); not the headline metric -- `python bench.py` without --config is"}
+    print(json.dumps(out), flush=True)
 
 
 def launch_ranks(n, argv, timeout_s):
@@ -114,7 +184,10 @@ def launch_ranks(n, argv, timeout_s):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+        # dmabuf IPC: this pool's host driver supports nothing else (the image exports the variable already; hipIpcGetMemHandle
+        # fails with "invalid argument" without it -- tests/test_p2p.py::test_p2p_two_processes_over_hip_ipc maps a peer's memory
+        # with it on the GPU box, profiles/README.md has the run with it switched off)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.setdefault("OMP_NUM_THREADS", "2")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
@@ -166,13 +239,17 @@ def main():
     ap.add_argument("--n-particles", type=int, default=1_000_000)
     ap.add_argument("--particles-per-gpu", type=int, default=0, help="weak scaling: this many particles per rank")
     ap.add_argument("--proposal", default="randomwalk", choices=["randomwalk", "de", "stretch"])
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--host-sir-updates", type=int, default=2, help="--config host: population updates of the Gillespie SIR row (~2 s each)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "host"],
                     help="cfg2 is the headline workload (BASELINE configs[1]); the others are secondary measurements")
     ap.add_argument("--algorithm", default="single_eps", choices=["single_eps", "multi_eps"])
     ap.add_argument("--n-obs", type=int, default=100, help="cfg2 only: draws per simulation (100 is the BASELINE workload)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) is the product path; gloo lets several ranks share one GPU to rehearse the N > 1 code path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions per process; `value` is their median")
+    ap.add_argument("--p2p", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: the peer-to-peer transport on top of the collectives (auto: on for --dist-backend nccl)")
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
     ap.add_argument("--time-every-launch", action="store_true", help="HIP events on every k_update launch instead of every second one")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events (A/B of the measurement overhead)")
@@ -189,6 +266,9 @@ def main():
     # process imports torch or touches HIP (a process that has initialised the GPU must not fork/exec workers)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
+
+    if args.config == "host":
+        return bench_host_path(args)
 
     import torch
     import torch.distributed as dist
@@ -234,64 +314,105 @@ def main():
                 "stretch": S.StretchMove()}[args.proposal]
     alg = S._lib.ALG_MULTI_EPS if args.algorithm == "multi_eps" else S._lib.ALG_SINGLE_EPS
 
-    h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank,
-                     world=world)
-    transport = "none"
-    if world > 1:
-        from sabc_amd.dist import install_collectives
-        transport = install_collectives(h, device)
-        # every rank takes the same branch (install_collectives agrees on the transport across ranks)
-        # (--dist-backend gloo is an explicit request for the host-staged rehearsal transport and says so in the line)
-        degraded = args.dist_backend == "nccl" and transport != "rccl"
-        if degraded and args.strict_transport:
-            print(f"[bench] rank {rank}: RCCL could not be bound inside the library, the collectives fell back to "
-                  f"'{transport}': --strict-transport refuses to measure that", file=sys.stderr, flush=True)
-            h.close()
-            dist.destroy_process_group()
-            raise SystemExit(3)
-        if degraded:
-            print(f"[bench] WARNING rank {rank}: RCCL could not be bound inside the library; measuring over '{transport}' "
-                  "(torch.distributed on device pointers, a Python callback per collective): the line says so in "
-                  "config.collectives and transport_degraded", file=sys.stderr, flush=True)
-    t_init0 = time.perf_counter()
-    h.initialize(n)
-    torch.cuda.synchronize()
-    t_init = time.perf_counter() - t_init0
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if W > 0:
-        h.update(n_simulation=W * n, proposal=proposal)
-    h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else (3 if args.time_every_launch else 1)))
-    barrier()
-    syncs0 = h.host_syncs
-    comm0 = h.comm_bytes
-    resampling0 = h.counters["n_resampling"]
-    t0 = time.perf_counter()
-    h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # The timed region is repeated R times in this process -- a fresh handle, the same warm-up, the same K updates (same
+    # seed: the very same trajectory) -- and `value` is the MEDIAN: one 4 ms sample says little (boxes and runs differ by
+    # a few per cent).  steps / warmup mean what they always meant.
+    samples = []
+    h = None
+    trace = os.environ.get("SABC_BENCH_TRACE")
 
-    syncs = h.host_syncs - syncs0
-    comm_bytes = h.comm_bytes - comm0
-    kern_ms, launches = h.profile_get(S._lib.KERNEL_UPDATE)
-    red_ms, red_n = h.profile_get(S._lib.KERNEL_REDUCE)
-    res_ms, res_n = h.profile_get(S._lib.KERNEL_RESAMPLE)
+    def say(what):
+        if trace:
+            print(f"[bench trace] rank {rank} {what}", file=sys.stderr, flush=True)
+
+    for rep in range(max(args.repeats, 1)):
+        if h is not None:
+            barrier()                 # nobody tears a handle down while a peer may still touch its memory
+            h.close()
+            barrier()
+        say(f"repeat {rep}: create")
+        h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank,
+                         world=world)
+        transport, fallback = "none", None
+        if world > 1:
+            from sabc_amd.dist import install_collectives
+            transport = install_collectives(h, device, p2p=None if args.p2p == "auto" else args.p2p == "on")
+            fallback = getattr(h, "fallback_transport", None)
+            # every rank takes the same branch (install_collectives agrees on the transport across ranks)
+            # (--dist-backend gloo is an explicit request for the host-staged rehearsal transport and says so in the line)
+            degraded = args.dist_backend == "nccl" and transport not in ("rccl", "p2p")
+            if degraded and args.strict_transport:
+                print(f"[bench] rank {rank}: RCCL could not be bound inside the library, the collectives fell back to "
+                      f"'{transport}': --strict-transport refuses to measure that", file=sys.stderr, flush=True)
+                h.close()
+                dist.destroy_process_group()
+                raise SystemExit(3)
+            if degraded and rep == 0:
+                print(f"[bench] WARNING rank {rank}: RCCL could not be bound inside the library; measuring over '{transport}' "
+                      "(torch.distributed on device pointers, a Python callback per collective): the line says so in "
+                      "config.collectives and transport_degraded", file=sys.stderr, flush=True)
+        say(f"repeat {rep}: transport {transport}, initialize")
+        t_init0 = time.perf_counter()
+        h.initialize(n)
+        torch.cuda.synchronize()
+        t_init = time.perf_counter() - t_init0
+        say(f"repeat {rep}: warm-up")
+        if W > 0:
+            h.update(n_simulation=W * n, proposal=proposal)
+        say(f"repeat {rep}: timed region")
+        h.profile_enable(0 if args.no_kernel_events else (2 if args.all_kernel_events else (3 if args.time_every_launch else 1)))
+        barrier()
+        syncs0, comm0, launches0, coll0 = h.host_syncs, h.comm_bytes, h.kernel_launches, h.collective_calls
+        resampling0 = h.counters["n_resampling"]
+        t0 = time.perf_counter()
+        h.update(n_simulation=K * n, proposal=proposal)          # exactly K population updates
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        say(f"repeat {rep}: done, {dt / K * 1e6:.1f} us per update")
+        kern_ms, launches = h.profile_get(S._lib.KERNEL_UPDATE)
+        samples.append({"dt": dt, "kern_ms": kern_ms, "launches": launches, "noops": h.profile_noops(S._lib.KERNEL_UPDATE),
+                        "syncs": h.host_syncs - syncs0, "comm": h.comm_bytes - comm0,
+                        "kernel_launches": h.kernel_launches - launches0, "collective_calls": h.collective_calls - coll0,
+                        "red": h.profile_get(S._lib.KERNEL_REDUCE), "res": h.profile_get(S._lib.KERNEL_RESAMPLE), "t_init": t_init})
+    order = sorted(range(len(samples)), key=lambda i: samples[i]["dt"])
+    med = samples[order[len(order) // 2]]
+    dt, kern_ms, launches = med["dt"], med["kern_ms"], med["launches"]
+    syncs, comm_bytes, t_init = med["syncs"], med["comm"], med["t_init"]
+    red_ms, red_n = med["red"]
+    res_ms, res_n = med["res"]
     c = h.counters
     th, _, _ = h.get_population(u=False, rho=False)
+    # N > 1: what one update costs between the update kernels, measured on 10 MORE updates with every kernel bracketed
+    # (level 2 adds ~4 us per bracket, so this is not part of the timed region): the reduce[-exchange]-control launch and,
+    # on the collectives transport, the allreduce between k_reduce_partials and k_control
+    exchange = None
+    if world > 1 and not args.no_kernel_events:
+        say("extra updates with every kernel bracketed")
+        h.profile_enable(2)
+        l0, c0 = h.kernel_launches, h.collective_calls
+        h.update(n_simulation=10 * n, proposal=proposal)
+        r_ms, r_n = h.profile_get(S._lib.KERNEL_REDUCE)
+        x_ms, x_n = h.profile_get(S._lib.KERNEL_COLLECTIVE)
+        exchange = {"reduce_control_us": r_ms / max(r_n, 1) * 1e3, "reduce_control_launches": r_n,
+                    "collective_us": (x_ms / x_n * 1e3) if x_n else None, "collectives_timed": x_n,
+                    "launches_per_update": (h.kernel_launches - l0) / 10.0, "collective_calls_per_update": (h.collective_calls - c0) / 10.0,
+                    "note": "10 extra updates after the timed region, every kernel bracketed by HIP events (not part of `value`)"}
 
     if rank == 0:
         bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
         # launches of the update kernel in the timed region: K (RandomWalk: one per update) or 2K; every second one carries
         # timing events (sabc_profile_enable level 1), `launches` of them came back
         real_launches = K if args.proposal == "randomwalk" else 2 * K
+        dts = sorted(x["dt"] for x in samples)
         avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
         sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
@@ -300,8 +421,8 @@ def main():
             peak = S.op_rng_peak(n_lanes=int(sims_per_launch), pairs_per_lane=max(normals_per_sim // 2, 1), repeats=10, device=device)
             in_kernel = normals_per_sim * sims_per_launch / avg_launch_s
             valu = {"bound": "valu", "achieved": in_kernel, "peak": peak, "unit": "normals/s", "frac": in_kernel / peak,
-                    "note": "peak = rate of k_rng_peak (generator only); the rest of k_update is proposal, ECDF search, accept, sums",
-                    **load_sq_summary(n, args.config)}
+                    "note": "live: peak = rate of k_rng_peak (generator only) measured in this run; the rest of k_update is "
+                            "proposal, ECDF search, accept, sums"}
         yb = observed_mean()
         post_var = 1.0 / (1.0 / 4.0 + 100.0)
         analytic = {"analytic_posterior_mean": post_var * 100.0 * yb, "analytic_posterior_var": post_var,
@@ -312,6 +433,8 @@ def main():
         out = {
             "metric": "particle-simulations/sec at n_particles=1e6" if args.config == "cfg2" else f"particle-simulations/sec ({args.config})",
             "value": K * n / dt,
+            "value_min": K * n / dts[-1], "value_max": K * n / dts[0], "repeats": len(samples),
+            "value_note": "median of `repeats` timed regions in this process (fresh handle, same warm-up, same K updates each)",
             "unit": "particle-simulations/s",
             "n_gpus": world,
             "steps": K,
@@ -328,21 +451,23 @@ def main():
                 if args.config == "cfg2" else f"{args.config} ({type(model).__name__}, d={d}, s={s}), n_particles={n}, "
                                               f"proposal={args.proposal}, {args.algorithm}",
                 "n_particles": n, "proposal": args.proposal, "algorithm": args.algorithm,
-                "particles_per_gpu": h.n_local, "seed": SEED, "collectives": transport,
+                "particles_per_gpu": h.n_local, "seed": SEED, "collectives": transport, "collectives_fallback": fallback,
             },
             # True: the library's own RCCL binding failed and torch.distributed's RCCL carried the collectives (device
             # pointers, same wires, one Python callback per collective) -- a measured but pessimistic number
-            "transport_degraded": bool(world > 1 and args.dist_backend == "nccl" and transport != "rccl"),
+            "transport_degraded": bool(world > 1 and args.dist_backend == "nccl" and transport not in ("rccl", "p2p")),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS if launches else None,
-                "traffic": load_traffic(n, args.config) if world == 1 else None,   # measured for a 1e6-particle launch
+                # HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes (profiles/, a 1e6-particle launch;
+                # NOT collected in this run -- see from_profiles)
+                "traffic": load_traffic(n, args.config) if world == 1 else None,
                 "kernel": f"k_update<{type(model).__name__},{d},{s},{args.proposal}>",
                 "avg_launch_us": avg_launch_s * 1e6 if launches else None,
-                "launches": real_launches, "timed_launches": launches,
+                "launches": real_launches, "timed_launches": launches, "noop_launches_excluded": med["noops"],
                 "algorithmic_bytes_per_sim": bytes_per_sim,
                 "note": f"not HBM-bound by construction: {normals_per_sim} f64 normals ({normals_per_sim // 2} Philox4x32-10 "
                         f"blocks + Box-Muller log/sqrt/sincos) per {bytes_per_sim} algorithmic bytes; the binding resource is VALU issue "
@@ -355,6 +480,12 @@ def main():
             # bytes landing in one shard's receive buffers per population update (allreduce of the fused sums; DE / Stretch:
             # two allgathers of the inactive halves; on resamples the weight row and the rows the shard drew)
             "comm_bytes_per_step": comm_bytes / K,
+            # kernels the library launched / collective calls it issued per population update in the timed region
+            # (resamples included), and -- N > 1 -- what the step between two update kernels costs
+            "launches_per_update": med["kernel_launches"] / K,
+            "collective_calls_per_update": med["collective_calls"] / K,
+            "exchange": exchange,
+            "from_profiles": load_from_profiles(n, args.config) if world == 1 else {},
             "kernel_time_frac": (avg_launch_s * real_launches) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
             "resamples_in_timed_region": c["n_resampling"] - resampling0,

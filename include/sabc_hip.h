@@ -166,6 +166,13 @@ SABC_API int64_t     sabc_comm_bytes(const sabc_handle *h);
 SABC_API int         sabc_set_host_simulator(sabc_handle *h, sabc_simulate_fn fn, void *ctx);   /* SABC_MODEL_HOST */
 SABC_API int         sabc_set_host_prior(sabc_handle *h, sabc_prior_sample_fn sample, sabc_prior_logpdf_fn logpdf,
                                          void *ctx);                                          /* prior_joint = 2 */
+/* SABC_MODEL_HOST: a half batch reaches f_dist in chunks of `particles` proposals (0 = automatic: an eighth of the half
+   batch, at least 4096), so that the callback of one chunk overlaps the device's work on its neighbours */
+SABC_API int         sabc_set_host_chunk(sabc_handle *h, int64_t particles);
+/* seconds spent inside the caller's callbacks (f_dist, host prior) since sabc_create, and calls of f_dist: what is left
+   of a call's wall time is the library's */
+SABC_API double      sabc_host_callback_seconds(const sabc_handle *h);
+SABC_API int64_t     sabc_host_callback_calls(const sabc_handle *h);
 /* SABC_MODEL_USER: the user's f_dist (SimulatedAnnealingABC.jl:164,175,315) as device code.  `hip_source` is HIP C++
    defining, at global scope,
        __device__ void sabc_user_simulate(const double *theta,        // the d parameters
@@ -195,8 +202,10 @@ SABC_API int         sabc_comm_selftest(sabc_handle *h);
    raw pointers for shards living in the same process); the descriptors of all shards, in rank order, go to
    sabc_comm_p2p_init -- exchanged by the caller, or (all_descs == NULL) by the library over the collectives already
    installed (sabc_set_collectives / sabc_comm_init_rccl), which also stay as the fallback transport.
-   Every wait is bounded (sabc_comm_p2p_set_timeout, default 2000 ms): a shard that gives up fails the call with
-   SABC_ERR_COMM per sabc_update's error contract and switches the handle back to the fallback transport. */
+   Every wait is bounded (sabc_comm_p2p_set_timeout, default 2000 ms).  A shard that gives up fails the call on EVERY shard
+   (the end-of-call status exchange) and switches the handle back to the collectives underneath; with such collectives
+   installed sabc_update then puts the particles back and repeats the call over them (sabc_comm_p2p_fallbacks counts),
+   without them it returns SABC_ERR_COMM per its error contract. */
 #define SABC_P2P_DESC_BYTES 384
 #define SABC_P2P_MAX_WORLD 8
 SABC_API int         sabc_comm_p2p_descriptor(sabc_handle *h, void *out_desc);
@@ -207,6 +216,9 @@ SABC_API int         sabc_comm_p2p_set_timeout(sabc_handle *h, double millisecon
 SABC_API int         sabc_comm_p2p_disable(sabc_handle *h);
 /* 1 while the handle runs over the peer-to-peer transport */
 SABC_API int         sabc_comm_p2p_active(const sabc_handle *h);
+/* sabc_update calls in which a peer-to-peer wait gave up and that were put back (device-side copy of the particles taken
+   at entry) and finished over the collectives installed underneath -- the caller sees a successful call */
+SABC_API int64_t     sabc_comm_p2p_fallbacks(const sabc_handle *h);
 /* test hook: n > 0: this shard skips its next n posts (rows of sums / barrier flags / call status), so that its peers run
    into the bound; n < 0: -n more posts go out first, then one is skipped */
 SABC_API int         sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n);
@@ -284,13 +296,18 @@ SABC_API int sabc_op_rng_peak(int32_t device, int64_t n_lanes, int32_t pairs_per
 
 /* ---- measurement ---- */
 enum { SABC_KERNEL_UPDATE = 0, SABC_KERNEL_REDUCE = 1, SABC_KERNEL_RESAMPLE = 2, SABC_KERNEL_INIT = 3,
-       SABC_KERNEL_COUNT = 4 };
+       SABC_KERNEL_COLLECTIVE = 4,   /* the allreduce of the fused sums on the collectives transport (level 2 only; on the
+                                        peer-to-peer transport the exchange is inside SABC_KERNEL_REDUCE's one launch) */
+       SABC_KERNEL_COUNT = 5 };
 /* HIP-event timing of kernels on the library's stream, accumulated since enable.
    level 0 off, 1 = every second launch of SABC_KERNEL_UPDATE (the events ride on the kernel's dispatch packet and cost
    ~4 us of queue time each: sampling halves what the measurement adds), 2 = every kernel, 3 = every launch of
    SABC_KERNEL_UPDATE.  sabc_profile_get returns the time and the number of the launches that were timed. */
 SABC_API int sabc_profile_enable(sabc_handle *h, int32_t level);
 SABC_API int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches);
+/* timed launches of `kernel` that turned out to be no-ops (queued ahead of a resample test that fired: they return at the
+   halt flag in ~2 us) -- left out of sabc_profile_get's time and count */
+SABC_API int64_t sabc_profile_noops(sabc_handle *h, int32_t kernel);
 /* how many times update()/initialize() had to wait for the device so far (run-ahead windows) */
 SABC_API int64_t sabc_host_syncs(const sabc_handle *h);
 /* kernels the library has launched on its stream so far, and collective calls it has issued (hooks / RCCL): per

@@ -22,7 +22,7 @@ MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
 ALG_SINGLE_EPS, ALG_MULTI_EPS = 0, 1
-KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT = 0, 1, 2, 3
+KERNEL_UPDATE, KERNEL_REDUCE, KERNEL_RESAMPLE, KERNEL_INIT, KERNEL_COLLECTIVE = 0, 1, 2, 3, 4
 
 ERR_NAMES = {
     -1: "NSIM_TOO_SMALL", -2: "NEG_DISTANCE", -3: "BAD_V", -4: "BAD_DELTA", -5: "BAD_ALGORITHM", -6: "BAD_BETA",
@@ -170,6 +170,10 @@ def bind(L, strict=True):
         "sabc_op_rng_peak": ([C.c_int32, C.c_int64, C.c_int32, C.c_int32, dp], C.c_int),
         "sabc_profile_enable": ([vp, C.c_int32], C.c_int),
         "sabc_profile_get": ([vp, C.c_int32, dp, ip64], C.c_int),
+        "sabc_profile_noops": ([vp, C.c_int32], C.c_int64),
+        "sabc_set_host_chunk": ([vp, C.c_int64], C.c_int),
+        "sabc_host_callback_seconds": ([vp], C.c_double),
+        "sabc_host_callback_calls": ([vp], C.c_int64),
         "sabc_host_syncs": ([vp], C.c_int64),
         "sabc_kernel_launches": ([vp], C.c_int64),
         "sabc_collective_calls": ([vp], C.c_int64),
@@ -179,6 +183,7 @@ def bind(L, strict=True):
         "sabc_comm_p2p_set_timeout": ([vp, C.c_double], C.c_int),
         "sabc_comm_p2p_disable": ([vp], C.c_int),
         "sabc_comm_p2p_active": ([vp], C.c_int),
+        "sabc_comm_p2p_fallbacks": ([vp], C.c_int64),
         "sabc_comm_p2p_inject_silence": ([vp, C.c_int32], C.c_int),
     }
     for name, (args, res) in sig.items():

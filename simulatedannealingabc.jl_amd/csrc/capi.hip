@@ -30,6 +30,7 @@ class NoCollectives : public Collectives {
   // only ever called with world > 1 (the engine skips collectives on one shard): no transport was installed
   int allreduce_sum(double *, int64_t) override { return -1; }
   int allgather(const double *, double *, int64_t) override { return -1; }
+  bool usable() const override { return false; }
 };
 
 // user-supplied hooks (torch.distributed from Python, MPI/RCCL from Julia)
@@ -295,6 +296,14 @@ int sabc_set_host_prior(sabc_handle *h, sabc_prior_sample_fn sample, sabc_prior_
   return 0;
 }
 
+int sabc_set_host_chunk(sabc_handle *h, int64_t particles) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->set_host_chunk(particles);
+  return 0;
+}
+double sabc_host_callback_seconds(const sabc_handle *h) { return h ? h->be->host_callback_seconds() : 0.0; }
+int64_t sabc_host_callback_calls(const sabc_handle *h) { return h ? h->be->host_callback_calls() : 0; }
+
 int sabc_comm_unique_id(void *out_128b) {
   RcclApi *a = rccl_api();
   if (!a) { g_err = "librccl.so could not be loaded"; return SABC_ERR_COMM; }
@@ -408,6 +417,7 @@ int sabc_comm_p2p_disable(sabc_handle *h) {
 }
 
 int sabc_comm_p2p_active(const sabc_handle *h) { return h && h->eng->p2p() ? 1 : 0; }
+int64_t sabc_comm_p2p_fallbacks(const sabc_handle *h) { return h ? h->eng->p2p_fallbacks() : 0; }
 
 int sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n) {
   if (!h) return SABC_ERR_STATE;
@@ -672,6 +682,8 @@ int sabc_profile_enable(sabc_handle *h, int32_t on) {
   h->be->profile_enable(on);
   return 0;
 }
+
+int64_t sabc_profile_noops(sabc_handle *h, int32_t kernel) { return h ? h->be->profile_noops(kernel) : 0; }
 
 int sabc_profile_get(sabc_handle *h, int32_t kernel, double *total_ms, int64_t *launches) {
   if (!h) return SABC_ERR_STATE;

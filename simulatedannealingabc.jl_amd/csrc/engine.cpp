@@ -155,8 +155,13 @@ int Engine::global_reduce(int64_t rows, bool guarded) {
     comm_bytes_ += np_ * (int64_t)sizeof(double);
     return 0;
   }
-  if (sh_.world > 1 && allreduce(be_->sums_buffer(), np_))
-    return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
+  if (sh_.world > 1) {
+    double *sums = be_->sums_buffer();
+    be_->prof_begin(SABC_KERNEL_COLLECTIVE);
+    const int rc = allreduce(sums, np_);
+    be_->prof_end(SABC_KERNEL_COLLECTIVE);
+    if (rc) return fail(SABC_ERR_COMM, "allreduce of the population sums failed");
+  }
   return 0;
 }
 
@@ -533,6 +538,27 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
 int Engine::update(const sabc_update_args &a) {
   if (!initialized_) return fail(SABC_ERR_STATE, "population is not initialized (or a failed update left it half-updated: "
                                                  "restore it with sabc_set_population)");
+  // Peer-to-peer transport with Collectives installed underneath: keep a device-side copy of the particles, so that a
+  // call in which a peer-to-peer wait gave up can be put back and finished over the Collectives (every shard's call fails
+  // with SABC_ERR_COMM then -- the end-of-call status exchange sees to that -- and every shard repeats it).
+  const bool can_retry = p2p() && coll_->usable() && be_->snapshot() == 0;
+  const bool replaced_at_entry = population_replaced_;
+  int rc = update_once(a);
+  if (rc == SABC_ERR_COMM && can_retry && !p2p()) {
+    const std::string why = err_;
+    if (be_->restore_snapshot() == 0) {
+      initialized_ = true;
+      population_replaced_ = replaced_at_entry;
+      p2p_fallbacks_ += 1;
+      rc = update_once(a);
+      if (rc) err_ = "after falling back from the peer-to-peer transport (" + why + "): " + err_;
+    }
+  }
+  if (rc != SABC_ERR_STATE) be_->end_of_call();
+  return rc;
+}
+
+int Engine::update_once(const sabc_update_args &a) {
   const ControlBlock at_entry = cb_;
   const int64_t resampling_at_entry = n_resampling_;
   const size_t hist_at_entry[3] = {eps_hist_.size(), u_hist_.size(), rho_hist_.size()};
@@ -550,7 +576,6 @@ int Engine::update(const sabc_update_args &a) {
     p2p_abort();
     err_ = why;
   }
-  if (rc != SABC_ERR_STATE) be_->end_of_call();
   return rc;
 }
 

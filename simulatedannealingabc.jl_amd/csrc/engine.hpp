@@ -23,6 +23,7 @@ class Collectives {
   // personalised exchange: send_counts[p] doubles go to rank p (consecutive segments of `send`), recv_counts[p] arrive from
   // rank p (consecutive segments of `recv`); the count arrays are host memory.  Optional: without it the resample falls
   // back to an allgather of the whole population.
+  virtual bool usable() const { return true; }      // false: the placeholder of a handle nobody gave a transport
   virtual bool has_alltoallv() const { return false; }
   virtual int alltoallv(const double *, const int64_t *, double *, const int64_t *) { return -1; }
 };
@@ -92,6 +93,9 @@ class Backend {
     return resample_draw(pop_block(), iter);
   }
   virtual double last_ess() = 0;
+  // measurement: bracket what is enqueued between the two calls with timing events (kernel = SABC_KERNEL_*)
+  virtual void prof_begin(int) {}
+  virtual void prof_end(int) {}
   // the call's last exchange has completed on every shard: housekeeping that must not run while a peer may be waiting
   virtual void end_of_call() {}
   // ---- peer-to-peer transport (p2p.hpp): the shards of one node exchange through each other's mapped memory.  A backend
@@ -105,6 +109,10 @@ class Backend {
   // end of a call: post this shard's status (0 = fine), and on the success path wait for everyone's
   virtual int p2p_commit(int, bool) { return -1; }
   virtual void p2p_disable() {}
+  // device-side copy of the particles (theta, u, rho) as they stand / put it back: what lets a call that failed over the
+  // peer-to-peer transport be repeated over the Collectives without the caller noticing
+  virtual int snapshot() { return -1; }
+  virtual int restore_snapshot() { return -1; }
   // K2 with every shard's rho block read from its owner (barrier included)
   virtual int build_cdf_p2p(int64_t *, int *) { return -1; }
   // fills pv->peer[] with every shard's theta block in its owner's memory
@@ -150,6 +158,8 @@ class Engine {
   // blocks; alltoallv: what arrived)
   int64_t comm_bytes() const { return comm_bytes_; }
   int64_t collective_calls() const { return collective_calls_; }
+  // calls that were put back and repeated over the Collectives because a peer-to-peer wait gave up
+  int64_t p2p_fallbacks() const { return p2p_fallbacks_; }
   // the peer-to-peer transport carries this handle (the backend has it mapped and the simulator is device code: a host
   // callback's duration differs from shard to shard by more than any sensible wait bound)
   bool p2p() const { return be_->p2p_active() && !host_mode_ && sh_.world > 1; }
@@ -172,6 +182,7 @@ class Engine {
   int partner_source(int inactive_half, PartnerView *pv);
   int enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded);
   int update_loop(const sabc_update_args &a);       // update() minus the error contract
+  int update_once(const sabc_update_args &a);       // update_loop + the error contract; update() adds the transport fallback
   int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
 
@@ -190,7 +201,7 @@ class Engine {
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
-  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0;
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
   void p2p_abort();                                 // ... and after a failure
   int initialize_body();

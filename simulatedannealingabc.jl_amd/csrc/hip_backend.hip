@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -54,11 +55,12 @@ HipBackend::~HipBackend() {
   if (slot_dev_) (void)hipFree(slot_dev_);
   if (bucket_dev_) (void)hipFree(bucket_dev_);
   if (bucket_host_) (void)hipHostFree(bucket_host_);
-  if (host_thp_dev_) (void)hipFree(host_thp_dev_);
-  if (host_aux_dev_) (void)hipFree(host_aux_dev_);
-  if (host_rho_dev_) (void)hipFree(host_rho_dev_);
+  double *staged[] = {host_thp_, host_aux_, host_rho_, host_cur_, host_lpcur_};
+  for (double *p : staged)
+    if (p) (void)hipHostFree(p);
+  if (host_flag_) (void)hipHostFree(host_flag_);
+  if (host_done_dev_) (void)hipFree(host_done_dev_);
   if (host_acc_dev_) (void)hipFree(host_acc_dev_);
-  if (host_lpcur_dev_) (void)hipFree(host_lpcur_dev_);
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (meta_dev_) (void)hipFree(meta_dev_);
   if (cb_dev_) (void)hipFree(cb_dev_);
@@ -213,7 +215,7 @@ void HipBackend::profile_enable(int level) {
   prof_ = level;
   prof_tick_ = 0;
   if (level)
-    for (int k = 0; k < SABC_KERNEL_COUNT; ++k) { prof_ms_[k] = 0.0; prof_n_[k] = 0; }
+    for (int k = 0; k < SABC_KERNEL_COUNT; ++k) { prof_ms_[k] = 0.0; prof_n_[k] = 0; prof_noop_[k] = 0; }
   while (level && ev_pool_.size() < 256) {       // created outside the timed region
     EvPair e;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) break;
@@ -242,7 +244,11 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   for (auto &e : ev_[kernel]) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { prof_ms_[kernel] += ms; prof_n_[kernel] += 1; }
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      // an update launch queued ahead of a resample test that fired returns at `if (cb->halt)`: not a sample of the kernel
+      if (kernel == SABC_KERNEL_UPDATE && ms < 0.004f && sh_.n_local >= 4096) prof_noop_[kernel] += 1;
+      else { prof_ms_[kernel] += ms; prof_n_[kernel] += 1; }
+    }
     ev_pool_.push_back(e);
   }
   ev_[kernel].clear();
@@ -252,15 +258,71 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
 }
 
 // ---- host-simulator mode (SABC_MODEL_HOST) ---------------------------------------------------
+// f_dist is the caller's function (SimulatedAnnealingABC.jl:315), so every half batch is cut at the host:
+//   k_host_propose (device) -> f_dist on the proposals inside the prior's support (host) -> k_host_accept (device).
+// What the library adds around the callback is kept off the critical path:
+//  * staging arrays are PINNED host memory MAPPED into the device, allocated once: the kernels write proposals and read
+//    distances in place -- no hipMemcpy call, no pageable staging, no allocation per half batch;
+//  * the propose kernel signals completion CHUNK by chunk into a pinned flag word the host polls (no stream sync): the
+//    callback for chunk c runs while the accept kernel of chunk c - 1 executes and later chunks are still being proposed;
+//  * nothing waits at the end of a half batch: the next kernel on the stream is ordered behind the accept kernels.
 int HipBackend::ensure_host_buffers() {
-  if (host_thp_dev_) return 0;
-  const size_t cap = (size_t)sh_.cap;
-  HB_CHECK(hipMalloc((void **)&host_thp_dev_, (size_t)m_.d * cap * sizeof(double)), "hipMalloc(host thp)");
-  HB_CHECK(hipMalloc((void **)&host_aux_dev_, 2 * cap * sizeof(double)), "hipMalloc(host aux)");
-  HB_CHECK(hipMalloc((void **)&host_rho_dev_, (size_t)m_.s * cap * sizeof(double)), "hipMalloc(host rho)");
+  if (host_thp_) return 0;
+  const size_t cap = (size_t)(sh_.cap > 0 ? sh_.cap : 1);
+  auto mapped = [&](double **host, double **dev, size_t doubles) -> int {
+    HB_CHECK(hipHostMalloc((void **)host, doubles * sizeof(double), hipHostMallocMapped), "hipHostMalloc(host-mode staging)");
+    HB_CHECK(hipHostGetDevicePointer((void **)dev, *host, 0), "hipHostGetDevicePointer(host-mode staging)");
+    return 0;
+  };
+  if (mapped(&host_thp_, &host_thp_dev_, (size_t)m_.d * cap)) return -1;
+  if (mapped(&host_aux_, &host_aux_dev_, 2 * cap)) return -1;
+  if (mapped(&host_rho_, &host_rho_dev_, (size_t)m_.s * cap)) return -1;
+  if (m_.prior_joint == 2) {
+    if (mapped(&host_cur_, &host_cur_dev_, (size_t)m_.d * cap)) return -1;
+    if (mapped(&host_lpcur_, &host_lpcur_dev_, cap)) return -1;
+  }
+  HB_CHECK(hipHostMalloc((void **)&host_flag_, kHostMaxChunks * sizeof(unsigned long long), hipHostMallocMapped), "hipHostMalloc(chunk flags)");
+  for (int i = 0; i < kHostMaxChunks; ++i) host_flag_[i] = 0ull;
+  HB_CHECK(hipHostGetDevicePointer((void **)&host_flag_dev_, host_flag_, 0), "hipHostGetDevicePointer(chunk flags)");
+  HB_CHECK(hipMalloc((void **)&host_done_dev_, kHostMaxChunks * sizeof(unsigned int)), "hipMalloc(chunk counters)");
+  HB_CHECK(hipMemsetAsync(host_done_dev_, 0, kHostMaxChunks * sizeof(unsigned int), stream_), "hipMemset");
   HB_CHECK(hipMalloc((void **)&host_acc_dev_, sizeof(unsigned long long)), "hipMalloc(host accept counter)");
-  if (m_.prior_joint == 2) HB_CHECK(hipMalloc((void **)&host_lpcur_dev_, cap * sizeof(double)), "hipMalloc(host log prior)");
   HB_CHECK(hipMemsetAsync(host_acc_dev_, 0, sizeof(unsigned long long), stream_), "hipMemset");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  host_ids_.reserve(cap); host_where_.reserve(cap);
+  return 0;
+}
+
+// particles per chunk of a half batch of cnt: whole workgroups, at most kHostMaxChunks chunks, and not so small that the
+// fixed cost of one callback (a ctypes / ccall transition, ~10-50 us from Python) shows: >= 4096 unless asked otherwise
+int64_t HipBackend::host_chunk_size(int64_t cnt) const {
+  int64_t chunk = host_chunk_;
+  if (chunk <= 0) {
+    int64_t pieces = cnt / 4096;                         // automatic: equal pieces of >= 4096, at most 8
+    pieces = pieces < 1 ? 1 : (pieces > 8 ? 8 : pieces);
+    chunk = (cnt + pieces - 1) / pieces;
+  }
+  const int64_t least = (cnt + kHostMaxChunks - 1) / kHostMaxChunks;
+  if (chunk < least) chunk = least;
+  chunk = ((chunk + kBlock - 1) / kBlock) * kBlock;
+  return chunk;
+}
+
+int HipBackend::wait_host_flag(int ch, unsigned long long seq) {
+  volatile unsigned long long *f = host_flag_ + ch;
+  for (uint64_t spins = 1; *f != seq; ++spins) {
+    __builtin_ia32_pause();
+    if ((spins & 0x3FFF) == 0) {
+      const hipError_t q = hipStreamQuery(stream_);
+      if (q == hipSuccess) {
+        if (*f == seq) break;
+        err_ = "the proposal kernel did not signal a chunk although the stream is idle";
+        return -1;
+      }
+      if (q != hipErrorNotReady) return check(q, "hipStreamQuery");
+    }
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   return 0;
 }
 
@@ -269,21 +331,30 @@ int HipBackend::host_prior_simulate() {
   if (ensure_host_buffers()) return -1;
   const int d = m_.d, s = m_.s;
   const int64_t n = sh_.n_local;
-  std::vector<double> th((size_t)(d * n)), rho((size_t)(s * n), 0.0);
-  std::vector<int64_t> ids((size_t)n);
-  for (int64_t i = 0; i < n; ++i) ids[(size_t)i] = sh_.gid0 + i;
+  // the staging arrays double as theta [d][n] / rho [s][n] here (one-time, synchronous: n simulations on the host follow)
+  double *th = host_thp_, *rho = host_rho_;
+  host_ids_.resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) host_ids_[(size_t)i] = sh_.gid0 + i;
   const size_t w = (size_t)n * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
   if (m_.prior_joint == 2) {                            // rand(prior) on the host (:174), theta uploaded
     if (!prior_sample_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
-    if (n > 0 && prior_sample_fn_(prior_ctx_, n, ids.data(), th.data())) { err_ = "the host prior's sample callback failed"; return -1; }
-    if (n > 0) HB_CHECK(hipMemcpy2DAsync(pop_[cur_], pitch, th.data(), w, w, (size_t)d, hipMemcpyHostToDevice, stream_), "upload theta");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = n > 0 ? prior_sample_fn_(prior_ctx_, n, host_ids_.data(), th) : 0;
+    host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) { err_ = "the host prior's sample callback failed"; return -1; }
+    if (n > 0) HB_CHECK(hipMemcpy2DAsync(pop_[cur_], pitch, th, w, w, (size_t)d, hipMemcpyHostToDevice, stream_), "upload theta");
   } else {
     HB_LAUNCH(launch_host_prior(m_, pop_ptrs(cur_), stream_), "k_host_prior");
-    if (n > 0) HB_CHECK(hipMemcpy2DAsync(th.data(), w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
+    if (n > 0) HB_CHECK(hipMemcpy2DAsync(th, w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
   }
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-  if (n > 0 && host_fn_(host_ctx_, th.data(), ids.data(), n, 0, rho.data())) { err_ = "the host simulator (f_dist) failed"; return -1; }
-  if (n > 0) HB_CHECK(hipMemcpy2DAsync(rho_, pitch, rho.data(), w, w, (size_t)s, hipMemcpyHostToDevice, stream_), "upload rho");
+  for (int64_t i = 0; i < (int64_t)s * n; ++i) rho[i] = 0.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = n > 0 ? host_fn_(host_ctx_, th, host_ids_.data(), n, 0, rho) : 0;
+  host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  host_cb_calls_ += 1;
+  if (rc) { err_ = "the host simulator (f_dist) failed"; return -1; }
+  if (n > 0) HB_CHECK(hipMemcpy2DAsync(rho_, pitch, rho, w, w, (size_t)s, hipMemcpyHostToDevice, stream_), "upload rho");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   return 0;
 }
@@ -294,45 +365,63 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
   if (cnt == 0) return 0;
   if (ensure_host_buffers()) return -1;
   const int d = m_.d, s = m_.s;
-  HB_LAUNCH(launch_host_propose(m_, c, cb_dev_, pop_ptrs(cur_), pv, lo, cnt, host_thp_dev_, host_aux_dev_, stream_), "k_host_propose");
-  std::vector<double> thp((size_t)(d * cnt)), aux((size_t)(2 * cnt));
-  HB_CHECK(hipMemcpyAsync(thp.data(), host_thp_dev_, thp.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download proposals");
-  HB_CHECK(hipMemcpyAsync(aux.data(), host_aux_dev_, aux.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "download aux");
-  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-  if (m_.prior_joint == 2) {
-    // logpdf(prior, .) on the host (:314, :318): one call for the proposals followed by the batch's current particles
-    if (!prior_logpdf_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
-    std::vector<double> both((size_t)(2 * cnt * d)), lp((size_t)(2 * cnt), -INFINITY), cur((size_t)(d * cnt));
-    const size_t w = (size_t)cnt * sizeof(double), pitch = (size_t)sh_.cap * sizeof(double);
-    HB_CHECK(hipMemcpy2DAsync(cur.data(), w, pop_[cur_] + lo, pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
-    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    for (int k = 0; k < d; ++k)
-      for (int64_t t = 0; t < cnt; ++t) {
-        both[(size_t)(k * 2 * cnt + t)] = thp[(size_t)(k * cnt + t)];
-        both[(size_t)(k * 2 * cnt + cnt + t)] = cur[(size_t)(k * cnt + t)];
+  const bool host_prior = m_.prior_joint == 2;
+  if (host_prior && !prior_logpdf_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
+  const int64_t chunk = host_chunk_size(cnt);
+  const int n_chunks = (int)((cnt + chunk - 1) / chunk);
+  const unsigned long long seq = ++host_seq_;
+  // ONE launch proposes the whole half batch (:311-314); it signals its chunks as they complete
+  HB_LAUNCH(launch_host_propose(m_, c, cb_dev_, pop_ptrs(cur_), pv, lo, cnt, host_thp_dev_, host_aux_dev_,
+                                host_prior ? host_cur_dev_ : nullptr, host_done_dev_, host_flag_dev_, seq, chunk, stream_),
+            "k_host_propose");
+  for (int ch = 0; ch < n_chunks; ++ch) {
+    const int64_t t0 = (int64_t)ch * chunk, tn = (t0 + chunk < cnt ? t0 + chunk : cnt) - t0;
+    if (wait_host_flag(ch, seq)) return -1;
+    if (host_prior) {
+      // logpdf(prior, .) on the host (:314, :318): one call for the chunk's proposals followed by its current particles
+      host_both_.resize((size_t)(2 * tn * d));
+      host_lp_.assign((size_t)(2 * tn), -INFINITY);
+      for (int k = 0; k < d; ++k)
+        for (int64_t t = 0; t < tn; ++t) {
+          host_both_[(size_t)(k * 2 * tn + t)] = host_thp_[(size_t)(k * cnt + t0 + t)];
+          host_both_[(size_t)(k * 2 * tn + tn + t)] = host_cur_[(size_t)(k * cnt + t0 + t)];
+        }
+      const auto c0 = std::chrono::steady_clock::now();
+      const int rc = prior_logpdf_fn_(prior_ctx_, 2 * tn, host_both_.data(), host_lp_.data());
+      host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+      if (rc) { err_ = "the host prior's logpdf callback failed"; return -1; }
+      for (int64_t t = 0; t < tn; ++t) {
+        const double l = host_lp_[(size_t)t];
+        host_aux_[(size_t)(t0 + t)] = l == l ? l : -INFINITY;             // NaN: outside the support
+        host_lpcur_[(size_t)(t0 + t)] = host_lp_[(size_t)(tn + t)];
       }
-    if (prior_logpdf_fn_(prior_ctx_, 2 * cnt, both.data(), lp.data())) { err_ = "the host prior's logpdf callback failed"; return -1; }
-    for (int64_t t = 0; t < cnt; ++t) aux[(size_t)t] = lp[(size_t)t] == lp[(size_t)t] ? lp[(size_t)t] : -INFINITY;   // NaN: outside
-    HB_CHECK(hipMemcpyAsync(host_aux_dev_, aux.data(), (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream_), "upload log prior");
-    HB_CHECK(hipMemcpyAsync(host_lpcur_dev_, lp.data() + cnt, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, stream_), "upload log prior");
+    }
+    // only proposals inside the prior's support are simulated (:314-315): compact them for the callback
+    host_ids_.clear(); host_where_.clear();
+    for (int64_t t = 0; t < tn; ++t)
+      if (host_aux_[(size_t)(t0 + t)] > -INFINITY) { host_ids_.push_back(sh_.gid0 + lo + t0 + t); host_where_.push_back(t0 + t); }
+    const int64_t mv = (int64_t)host_ids_.size();
+    host_thv_.resize((size_t)(d * mv)); host_rhov_.assign((size_t)(s * mv), 0.0);
+    for (int k = 0; k < d; ++k)
+      for (int64_t i = 0; i < mv; ++i) host_thv_[(size_t)(k * mv + i)] = host_thp_[(size_t)(k * cnt + host_where_[(size_t)i])];
+    if (mv > 0) {
+      const auto c0 = std::chrono::steady_clock::now();
+      const int rc = host_fn_(host_ctx_, host_thv_.data(), host_ids_.data(), mv, c.iter, host_rhov_.data());
+      host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+      host_cb_calls_ += 1;
+      if (rc) { err_ = "the host simulator (f_dist) failed"; return -1; }
+    }
+    for (int j = 0; j < s; ++j) {
+      for (int64_t t = 0; t < tn; ++t) host_rho_[(size_t)(j * cnt + t0 + t)] = 0.0;
+      for (int64_t i = 0; i < mv; ++i) host_rho_[(size_t)(j * cnt + host_where_[(size_t)i])] = host_rhov_[(size_t)(j * mv + i)];
+    }
+    // the accept step of this chunk (:316-329) reads the distances in place; it runs while the host is in the next
+    // chunk's callback.  (The launch orders the host's stores above before the kernel's loads.)
+    if (ch == 0) prof_begin(SABC_KERNEL_UPDATE);
+    HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, t0, tn, host_thp_dev_, host_aux_dev_, host_rho_dev_,
+                                 host_prior ? host_lpcur_dev_ : nullptr, host_acc_dev_, stream_), "k_host_accept");
+    if (ch == n_chunks - 1) prof_end(SABC_KERNEL_UPDATE);
   }
-  // only proposals inside the prior's support are simulated (:314-315)
-  std::vector<int64_t> ids, where;
-  for (int64_t t = 0; t < cnt; ++t)
-    if (aux[(size_t)t] > -INFINITY) { ids.push_back(sh_.gid0 + lo + t); where.push_back(t); }
-  const int64_t mv = (int64_t)ids.size();
-  std::vector<double> thv((size_t)(d * mv)), rhov((size_t)(s * mv), 0.0), rho((size_t)(s * cnt), 0.0);
-  for (int k = 0; k < d; ++k)
-    for (int64_t i = 0; i < mv; ++i) thv[(size_t)(k * mv + i)] = thp[(size_t)(k * cnt + where[(size_t)i])];
-  if (mv > 0 && host_fn_(host_ctx_, thv.data(), ids.data(), mv, c.iter, rhov.data())) { err_ = "the host simulator (f_dist) failed"; return -1; }
-  for (int j = 0; j < s; ++j)
-    for (int64_t i = 0; i < mv; ++i) rho[(size_t)(j * cnt + where[(size_t)i])] = rhov[(size_t)(j * mv + i)];
-  HB_CHECK(hipMemcpyAsync(host_rho_dev_, rho.data(), rho.size() * sizeof(double), hipMemcpyHostToDevice, stream_), "upload rho");
-  prof_begin(SABC_KERNEL_UPDATE);
-  HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, host_thp_dev_, host_aux_dev_, host_rho_dev_,
-                               m_.prior_joint == 2 ? host_lpcur_dev_ : nullptr, host_acc_dev_, stream_), "k_host_accept");
-  prof_end(SABC_KERNEL_UPDATE);
-  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");      // the staging vectors go out of scope
   return 0;
 }
 
@@ -489,8 +578,10 @@ int HipBackend::control(const ControlArgs &a) {
   if (xchg) {                   // a partial-row matrix too large for one workgroup: np workgroups reduce it first
     pending_xchg_ = false;
     if (flush_reduce()) return -1;
+    prof_begin(SABC_KERNEL_REDUCE);
     HB_LAUNCH(launch_reduce_control(partials_, -1, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_, &pv,
                                     ++xseq_, true, take_silence()), "k_reduce_control (exchange)");
+    prof_end(SABC_KERNEL_REDUCE);
     return 0;
   }
   if (flush_reduce()) return -1;
@@ -849,7 +940,9 @@ void HipBackend::p2p_close() {
   ipc_opened_.clear();
   if (slots_) (void)hipFree(slots_);
   if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
-  slots_ = nullptr; p2p_test_dev_ = nullptr;
+  if (snap_pop_) (void)hipFree(snap_pop_);
+  if (snap_rho_) (void)hipFree(snap_rho_);
+  slots_ = nullptr; p2p_test_dev_ = nullptr; snap_pop_ = snap_rho_ = nullptr;
 }
 
 // a row of known values through the slots + one barrier; the host checks the sums.  Sequence numbers advance exactly as
@@ -879,6 +972,28 @@ int HipBackend::p2p_selftest() {
     for (int r = 0; r < W; ++r) { const double x = (double)(r + 1) * (q + 1) + (q == 3 ? 0.1 : 0.0); want = r == 0 ? x : want + x; }
     if (out[q] != want) { err_ = "peer-to-peer self-test: wrong sums came back through the slots"; p2p_on_ = false; return -1; }
   }
+  return 0;
+}
+
+int HipBackend::snapshot() {
+  const size_t pop_bytes = (size_t)(m_.d + m_.s + 1) * (size_t)sh_.cap * sizeof(double), rho_bytes = (size_t)m_.s * (size_t)sh_.cap * sizeof(double);
+  if (!snap_pop_) {
+    HB_CHECK(hipMalloc((void **)&snap_pop_, pop_bytes), "hipMalloc(snapshot)");
+    HB_CHECK(hipMalloc((void **)&snap_rho_, rho_bytes), "hipMalloc(snapshot)");
+  }
+  HB_CHECK(hipMemcpyAsync(snap_pop_, pop_[cur_], pop_bytes, hipMemcpyDeviceToDevice, stream_), "snapshot");
+  HB_CHECK(hipMemcpyAsync(snap_rho_, rho_, rho_bytes, hipMemcpyDeviceToDevice, stream_), "snapshot");
+  return 0;
+}
+
+int HipBackend::restore_snapshot() {
+  if (!snap_pop_) { err_ = "no snapshot of the particles"; return -1; }
+  const size_t pop_bytes = (size_t)(m_.d + m_.s + 1) * (size_t)sh_.cap * sizeof(double), rho_bytes = (size_t)m_.s * (size_t)sh_.cap * sizeof(double);
+  pending_rows_ = -1;
+  pending_xchg_ = false;
+  HB_CHECK(hipMemcpyAsync(pop_[cur_], snap_pop_, pop_bytes, hipMemcpyDeviceToDevice, stream_), "restore");
+  HB_CHECK(hipMemcpyAsync(rho_, snap_rho_, rho_bytes, hipMemcpyDeviceToDevice, stream_), "restore");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   return 0;
 }
 

@@ -55,6 +55,9 @@ class HipBackend : public Backend {
   int resample_scatter(const double *rows_in) override;
   double last_ess() override;
   void end_of_call() override;
+  void prof_begin(int kernel) override;
+  void prof_end(int kernel) override;
+  int64_t profile_noops(int kernel) const { return kernel >= 0 && kernel < SABC_KERNEL_COUNT ? prof_noop_[kernel] : 0; }
   int download(double *theta, double *u, double *rho) override;
   int upload(const double *theta, const double *u, const double *rho) override;
   int get_knots(int stat, double *out, int64_t len) override;
@@ -69,6 +72,8 @@ class HipBackend : public Backend {
   int build_cdf_p2p(int64_t *len_out, int *any_negative) override;
   int partner_view_p2p(PartnerView *pv) override;
   int resample_p2p(double delta, uint64_t iter) override;
+  int snapshot() override;
+  int restore_snapshot() override;
   int p2p_descriptor(P2PDesc *out);                 // allocates the slot area on first use
   int p2p_init(const P2PDesc *all);                 // maps every peer's slots, populations and rho; switches the transport on
   int p2p_selftest();
@@ -76,6 +81,10 @@ class HipBackend : public Backend {
   // test hook: n > 0: the next n posts are skipped; n < 0: -n more posts go out, then one is skipped
   void p2p_inject_silence(int n) { if (n >= 0) { p2p_skip_ = 0; p2p_silent_ = n; } else { p2p_skip_ = -n; p2p_silent_ = 1; } }
   int64_t kernel_launches() const { return launches_; }
+  // host-simulator mode: seconds spent inside the caller's callbacks so far / calls of f_dist; particles per chunk
+  double host_callback_seconds() const { return host_cb_seconds_; }
+  int64_t host_callback_calls() const { return host_cb_calls_; }
+  void set_host_chunk(int64_t particles) { host_chunk_ = particles > 0 ? particles : 0; }
 
   // extras used by the C-ABI layer
   int set_stream(hipStream_t s);
@@ -95,8 +104,6 @@ class HipBackend : public Backend {
  private:
   int check(hipError_t e, const char *what);
   PopPtrs pop_ptrs(int which) const;
-  void prof_begin(int kernel);
-  void prof_end(int kernel);
 
   int device_ = 0;
   hipStream_t stream_ = nullptr;
@@ -143,11 +150,23 @@ class HipBackend : public Backend {
   sabc_prior_sample_fn prior_sample_fn_ = nullptr;      // prior_joint = 2: rand(prior) / logpdf(prior, .) on the host
   sabc_prior_logpdf_fn prior_logpdf_fn_ = nullptr;
   void *prior_ctx_ = nullptr;
-  double *host_lpcur_dev_ = nullptr;                    // log prior of the current particles of a batch (prior_joint = 2)
   void *host_ctx_ = nullptr;
-  double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr;
+  // staging of a half batch: pinned host arrays (host_x_) mapped into the device (host_x_dev_), allocated once
+  double *host_thp_ = nullptr, *host_aux_ = nullptr, *host_rho_ = nullptr, *host_cur_ = nullptr, *host_lpcur_ = nullptr;
+  double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr, *host_cur_dev_ = nullptr, *host_lpcur_dev_ = nullptr;
+  static constexpr int kHostMaxChunks = 64;
+  unsigned long long *host_flag_ = nullptr, *host_flag_dev_ = nullptr;   // per chunk: the proposal kernel posts, the host polls
+  unsigned int *host_done_dev_ = nullptr;
+  unsigned long long host_seq_ = 0;
+  int64_t host_chunk_ = 0;                                // particles per chunk; 0 = automatic (host_chunk_size)
+  std::vector<int64_t> host_ids_, host_where_;
+  std::vector<double> host_thv_, host_rhov_, host_both_, host_lp_;
+  double host_cb_seconds_ = 0.0;                          // time spent inside the caller's callbacks
+  int64_t host_cb_calls_ = 0;
   unsigned long long *host_acc_dev_ = nullptr;
   int ensure_host_buffers();
+  int64_t host_chunk_size(int64_t cnt) const;
+  int wait_host_flag(int ch, unsigned long long seq);
   RtcKernels rtc_;                                        // SABC_MODEL_USER: kernels compiled from the user's source
   const RtcKernels *rtc() const { return rtc_.module ? &rtc_ : nullptr; }
   void free_later(void *p);                               // device memory released by end_of_call(), never inside a call
@@ -171,6 +190,7 @@ class HipBackend : public Backend {
   double p2p_timeout_ms_ = 2000.0;
   int p2p_silent_ = 0, p2p_skip_ = 0;
   double *p2p_test_dev_ = nullptr;
+  double *snap_pop_ = nullptr, *snap_rho_ = nullptr;     // device-side copy of the particles at the entry of a call
   int64_t launches_ = 0;
   int prof_ = 0, prof_open_ = -1;
   unsigned prof_tick_ = 0;
@@ -179,6 +199,7 @@ class HipBackend : public Backend {
   std::vector<EvPair> ev_pool_;
   double prof_ms_[SABC_KERNEL_COUNT] = {0};
   int64_t prof_n_[SABC_KERNEL_COUNT] = {0};
+  int64_t prof_noop_[SABC_KERNEL_COUNT] = {0};
 };
 
 }  // namespace sabc

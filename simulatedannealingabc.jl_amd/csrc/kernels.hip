@@ -364,14 +364,11 @@ __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const 
     pp.pop[(int64_t)k * pp.cap + li] = prior_sample_dim(m, k, gid);
 }
 
-// thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor)
-__global__ void __launch_bounds__(kBlock)
-k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp,
-               const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ thp_out,
-               double *__restrict__ aux) {
-  rng_tables_init();
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= act_n) return;
+// one particle of the host-mode proposal step (:311-314)
+__device__ __forceinline__ void host_propose_one(const ModelDesc &m, const StepArgs &c, const ControlBlock *__restrict__ cb,
+                                                 const PopPtrs &pp, const PartnerView &pv, const int64_t act_lo, const int64_t act_n,
+                                                 double *__restrict__ thp_out, double *__restrict__ aux,
+                                                 double *__restrict__ cur_out, const int64_t t) {
   const int d = m.d;
   const int64_t li = act_lo + t;
   const uint64_t gid = (uint64_t)(pp.gid0 + li);
@@ -417,17 +414,54 @@ k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restri
   for (int k = 0; k < d; ++k) thp_out[(int64_t)k * act_n + t] = thp[k];
   aux[t] = prior_logpdf_rt(m, thp);
   aux[act_n + t] = logf;
+  if (cur_out)
+    for (int k = 0; k < d; ++k) cur_out[(int64_t)k * act_n + t] = th[k];
+}
+
+// thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor); cur_out (optional)
+// [d][act_n] = the current particles (a host-callback prior needs their log density too).  The outputs are pinned host
+// memory mapped into the device (zero copy): no D2H call follows.  The half batch is cut into chunks of `sig.chunk`
+// particles; the LAST workgroup of a chunk to finish posts `sig.seq` into the chunk's flag word in host memory, which the
+// host polls -- it starts f_dist on chunk c while the later chunks are still being proposed, without a stream sync.
+struct HostSignal {
+  unsigned int *done;            // device: workgroups of each chunk that have finished
+  unsigned long long *flag;      // mapped host memory: one word per chunk
+  unsigned long long seq;
+  int64_t chunk;                 // particles per chunk (a multiple of kBlock)
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp,
+               const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ thp_out,
+               double *__restrict__ aux, double *__restrict__ cur_out, const HostSignal sig) {
+  rng_tables_init();
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t < act_n) host_propose_one(m, c, cb, pp, pv, act_lo, act_n, thp_out, aux, cur_out, t);
+  __threadfence_system();                     // this lane's stores to host memory are out ...
+  __syncthreads();                            // ... for every lane of the workgroup
+  if (threadIdx.x == 0) {
+    const int64_t ch = ((int64_t)blockIdx.x * kBlock) / sig.chunk;
+    const int64_t first = ch * sig.chunk, last = first + sig.chunk < act_n ? first + sig.chunk : act_n;
+    const unsigned int groups = (unsigned int)((last - first + kBlock - 1) / kBlock);
+    if (atomicAdd(&sig.done[ch], 1u) == groups - 1u) {
+      sig.done[ch] = 0u;                      // ready for the next half batch
+      __threadfence_system();
+      __hip_atomic_store(&sig.flag[ch], sig.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // rho_prop [s][act_n] from the host; n_accept is counted with an integer atomic (exact, order-free)
 __global__ void __launch_bounds__(kBlock)
 k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
-              const int64_t act_lo, const int64_t act_n, const double *__restrict__ thp_in,
+              const int64_t act_lo, const int64_t act_n, const int64_t t_lo, const int64_t t_n,
+              const double *__restrict__ thp_in,
               const double *__restrict__ aux, const double *__restrict__ rho_prop, const double *__restrict__ lp_cur,
               unsigned long long *n_accept) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // one chunk [t_lo, t_lo + t_n) of the half batch; thp / aux / rho_prop / lp_cur are the host's mapped staging arrays
+  const int64_t t = t_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
   bool accepted = false;
-  if (t < act_n) {
+  if (t < t_lo + t_n) {
     const int d = m.d, s = m.s;
     const int64_t li = act_lo + t;
     const uint64_t gid = (uint64_t)(pp.gid0 + li);
@@ -1518,19 +1552,22 @@ int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
 }
 
 int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
-                        int64_t act_lo, int64_t act_n, double *thp, double *aux, hipStream_t stream) {
+                        int64_t act_lo, int64_t act_n, double *thp, double *aux, double *cur_out, unsigned int *done,
+                        unsigned long long *flag, unsigned long long seq, int64_t chunk, hipStream_t stream) {
   if (act_n <= 0) return 0;
+  HostSignal sig;
+  sig.done = done; sig.flag = flag; sig.seq = seq; sig.chunk = chunk;
   hipLaunchKernelGGL(k_host_propose, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, pv, act_lo, act_n,
-                     thp, aux);
+                     thp, aux, cur_out, sig);
   return SABC_LAUNCH_RC();
 }
 
 int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
-                       int64_t act_n, const double *thp, const double *aux, const double *rho_prop, const double *lp_cur,
-                       unsigned long long *n_accept, hipStream_t stream) {
-  if (act_n <= 0) return 0;
-  hipLaunchKernelGGL(k_host_accept, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, cdf, act_lo, act_n,
-                     thp, aux, rho_prop, lp_cur, n_accept);
+                       int64_t act_n, int64_t t_lo, int64_t t_n, const double *thp, const double *aux, const double *rho_prop,
+                       const double *lp_cur, unsigned long long *n_accept, hipStream_t stream) {
+  if (t_n <= 0) return 0;
+  hipLaunchKernelGGL(k_host_accept, dim3((unsigned)n_blocks(t_n)), dim3(kBlock), 0, stream, m, c, cb, pp, cdf, act_lo, act_n,
+                     t_lo, t_n, thp, aux, rho_prop, lp_cur, n_accept);
   return SABC_LAUNCH_RC();
 }
 

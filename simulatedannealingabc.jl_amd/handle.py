@@ -171,6 +171,11 @@ class SabcHandle:
     def p2p_active(self):
         return bool(self._L.sabc_comm_p2p_active(self._h))
 
+    @property
+    def p2p_fallbacks(self):
+        """Calls that were put back and finished over the collectives underneath because a peer-to-peer wait gave up."""
+        return int(self._L.sabc_comm_p2p_fallbacks(self._h))
+
     def p2p_inject_silence(self, n=1):
         """Test hook: this shard skips its next n posts, so that its peers run into the bound of their waits."""
         self._check(self._L.sabc_comm_p2p_inject_silence(self._h, int(n)))
@@ -284,6 +289,19 @@ class SabcHandle:
     def host_syncs(self):
         return int(self._L.sabc_host_syncs(self._h))
 
+    def set_host_chunk(self, particles):
+        """Host-callback f_dist: proposals per callback (0 = automatic)."""
+        self._check(self._L.sabc_set_host_chunk(self._h, int(particles)))
+
+    @property
+    def host_callback_seconds(self):
+        """Seconds spent inside the caller's callbacks (f_dist, host prior) since the handle was created."""
+        return float(self._L.sabc_host_callback_seconds(self._h))
+
+    @property
+    def host_callback_calls(self):
+        return int(self._L.sabc_host_callback_calls(self._h))
+
     @property
     def kernel_launches(self):
         return int(self._L.sabc_kernel_launches(self._h))
@@ -294,6 +312,10 @@ class SabcHandle:
 
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))
+
+    def profile_noops(self, kernel):
+        """Timed launches of `kernel` that were no-ops behind a fired resample test (left out of profile_get)."""
+        return int(self._L.sabc_profile_noops(self._h, int(kernel)))
 
     def profile_get(self, kernel):
         ms, cnt = C.c_double(), C.c_int64()

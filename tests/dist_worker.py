@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--resample", type=float, default=0.0)
     ap.add_argument("--alltoallv", type=int, default=1, help="0: no personalised exchange (the resample allgathers the population)")
     ap.add_argument("--p2p", type=int, default=0, help="1: the peer-to-peer transport on top of the collectives (hip engine only)")
+    ap.add_argument("--silence", type=int, default=0, help="p2p test hook: rank 1 lets this many posts go out, then skips one")
+    ap.add_argument("--p2p-timeout-ms", type=float, default=0.0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -61,8 +63,12 @@ def main():
         transport = install_collectives(h, device, alltoallv=bool(a.alltoallv), p2p=bool(a.p2p) if a.engine == "hip" else False)
         assert transport in ("p2p", "rccl", "hooks-nccl", "hooks-gloo"), transport
     calls0 = h.collective_calls if a.engine == "hip" else 0       # (the self-test of the base transport used some)
+    if a.p2p_timeout_ms > 0 and transport == "p2p":
+        h.p2p_set_timeout(a.p2p_timeout_ms)
     h.initialize((a.updates + 1) * a.n)
     bytes_init = h.comm_bytes
+    if a.silence and rank == 1 and transport == "p2p":
+        h.p2p_inject_silence(-a.silence)
     h.update(n_simulation=a.updates * a.n, proposal=hip_proposal(S, a.prop, d),
              resample=a.resample if a.resample > 0 else None)
     th, u, rho = h.get_population()
@@ -76,7 +82,9 @@ def main():
                  counters=np.array([h.counters[k] for k in ("n_simulation", "n_accept", "n_resampling", "n_population_updates")]),
                  sigma=h.proposal_sigma, offsets=np.array([p[0] for p in parts]),
                  comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]), transport=np.array(transport),
-                 collective_calls=np.array((h.collective_calls - calls0) if a.engine == "hip" else -1))
+                 collective_calls=np.array((h.collective_calls - calls0) if a.engine == "hip" else -1),
+                 p2p_fallbacks=np.array(h.p2p_fallbacks if a.engine == "hip" else 0),
+                 p2p_active_at_end=np.array(bool(h.p2p_active) if a.engine == "hip" else False))
     dist.barrier()
     h.close()
     dist.destroy_process_group()

@@ -186,3 +186,23 @@ def test_p2p_a_silent_shard_fails_the_call_within_the_bound(S, gpu, tmp_path, pr
                  updates=2 * k, resample=n // 4)
     # two calls of k updates == one call of 2k updates on the CPU engine (the repeated call included)
     check_against_cpu_engine(out, ref, prop)
+
+
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_p2p_failed_call_is_finished_over_the_collectives_underneath(S, gpu, tmp_path, prop):
+    """Two processes, gloo hooks installed underneath the peer-to-peer transport.  Rank 1 skips a post in the middle of the
+    call: every rank's peer-to-peer call fails within the bound, the engine puts the particles back (device-side copy
+    taken at entry), switches to the collectives and repeats the call -- the caller sees a successful call with the same
+    result as the CPU engine."""
+    case, n, k = "gauss2_2stats", 10_000, 10
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg="multi_eps", prop=prop, n=n, updates=k,
+                 resample=n // 4, p2p=1, silence=6, **{"p2p-timeout-ms": 300})
+    assert str(got["transport"]) == "p2p" and int(got["p2p_fallbacks"]) == 1 and not bool(got["p2p_active_at_end"])
+    assert int(got["collective_calls"]) > k                          # the repeated call went over the hooks
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="multi_eps", prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    tol = TOL[prop]
+    assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)
+    np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=tol)
