@@ -27,9 +27,10 @@ extern "C" {
 #endif
 
 #define SABC_ABI_VERSION 4      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
-                                   4: peer-to-peer transport (sabc_comm_p2p_*), launch counters */
-#define SABC_MAX_PARA 8
-#define SABC_MAX_STATS 8
+                                   4: peer-to-peer transport (sabc_comm_p2p_*), launch counters, SABC_MAX_PARA / _STATS 8 -> 16, prior_joint = 3 */
+#define SABC_MAX_PARA 16        /* host-callback and source-compiled simulators: any d, s up to these (the reference takes any */
+#define SABC_MAX_STATS 16       /* length(prior) and any number of distances, SimulatedAnnealingABC.jl:163-167,181)          */
+#define SABC_MAX_JOINT_PARA 8   /* an MvNormal prior as data: d <= 8 (its Cholesky factor travels in kernel arguments)       */
 #define SABC_MAX_MODEL_PARAMS 32
 
 #if defined(__GNUC__)
@@ -94,8 +95,10 @@ typedef struct {
   double  prior_c[SABC_MAX_PARA]; /* truncated Normal: lower bound (others: unused) */
   double  prior_d[SABC_MAX_PARA]; /* truncated Normal: upper bound (others: unused) */
   int32_t prior_joint;            /* 0: product of the univariate families above | 1: MvNormal(mu, Sigma) over all n_para
-                                     dimensions: mu = prior_a[0..d), Sigma = L L' with L = prior_chol | 2: host callbacks
-                                     (sabc_set_host_prior; SABC_MODEL_HOST only; prior_kind etc. unused) */
+                                     dimensions (d <= SABC_MAX_JOINT_PARA): mu = prior_a[0..d), Sigma = L L' with L = prior_chol | 2: host callbacks
+                                     (sabc_set_host_prior; SABC_MODEL_HOST only; prior_kind etc. unused) | 3: device code
+                                     in the simulator's HIP source (SABC_MODEL_USER only: sabc_user_prior_sample /
+                                     sabc_user_prior_logpdf next to sabc_user_simulate; prior_kind etc. unused) */
   int32_t reserved2;
   double  prior_chol[SABC_MAX_PARA * SABC_MAX_PARA];   /* prior_joint = 1: lower Cholesky factor of Sigma, row-major d x d */
   int32_t algorithm;              /* SABC_ALG_* */
@@ -180,6 +183,11 @@ SABC_API int64_t     sabc_host_callback_calls(const sabc_handle *h);
                                           sabc::NormalStream &rng,    // rng.next() / rng.pair(z0, z1): N(0,1) draws;
                                                                       // rng.uniform_pair(u0, u1): U(0,1) draws
                                           double *rho_out);           // the s non-negative distances
+   With sabc_config::prior_joint = 3 the same source also defines the PRIOR -- any distribution, evaluated inside the fused
+   kernel (SimulatedAnnealingABC.jl:151 takes any Distributions.Distribution):
+       __device__ void   sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);
+       __device__ double sabc_user_prior_logpdf(const double *theta, const double *params);   // -INFINITY outside the support
+   (`rng`: the particle's prior stream.)
    It is compiled with hipRTC for gfx950 against csrc/update_kernel.hpp -- the same propose -> simulate -> ECDF -> accept
    kernel, reductions and Philox streams as the built-in simulators -- and must be registered before sabc_initialize.
    On failure sabc_last_error(h) holds the compiler log. */
@@ -188,6 +196,9 @@ SABC_API int         sabc_register_device_simulator(sabc_handle *h, const char *
    the compiler log is copied into log_out (may be NULL) */
 SABC_API int         sabc_op_compile_device_simulator(const char *hip_source, int32_t d, int32_t s, char *log_out,
                                                       int64_t log_cap);
+/* the same for a source that also carries the prior (prior_joint = 3) */
+SABC_API int         sabc_op_compile_device_simulator_with_prior(const char *hip_source, int32_t d, int32_t s, char *log_out,
+                                                                 int64_t log_cap);
 SABC_API int         sabc_comm_init_rccl(sabc_handle *h, const void *unique_id_128b);
 SABC_API int         sabc_comm_unique_id(void *out_128b);
 /* one allreduce + one allgather through the installed collectives, checked on the host */

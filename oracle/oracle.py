@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsabc_oracle.so")
 
-MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
+MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))

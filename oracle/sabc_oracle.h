@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define ORC_MAX_PARA 8
-#define ORC_MAX_STATS 8
+#define ORC_MAX_PARA 16
+#define ORC_MAX_STATS 16
 #define ORC_MAX_MODEL_PARAMS 32
 
 /* model ids (device-coded simulators; see DESIGN.md "Simulators") */

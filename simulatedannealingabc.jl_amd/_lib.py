@@ -17,7 +17,8 @@ HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
 ABI_VERSION = 4
 P2P_DESC_BYTES, P2P_MAX_WORLD = 384, 8
-MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
+MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
+MAX_JOINT_PARA = 8
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
 PROP_RANDOMWALK, PROP_DIFFEVO, PROP_STRETCH = 0, 1, 2
@@ -133,6 +134,7 @@ def bind(L, strict=True):
         "sabc_set_host_prior": ([vp, PRIOR_SAMPLE_FN, PRIOR_LOGPDF_FN, vp], C.c_int),
         "sabc_register_device_simulator": ([vp, C.c_char_p], C.c_int),
         "sabc_op_compile_device_simulator": ([C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64], C.c_int),
+        "sabc_op_compile_device_simulator_with_prior": ([C.c_char_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64], C.c_int),
         "sabc_comm_init_rccl": ([vp, vp], C.c_int),
         "sabc_comm_unique_id": ([vp], C.c_int),
         "sabc_comm_selftest": ([vp], C.c_int),

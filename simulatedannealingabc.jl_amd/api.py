@@ -213,6 +213,8 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     if getattr(prior, "host_prior", False) and isinstance(f_dist, DeviceDistance) and not isinstance(f_dist, HostDistance):
         raise TypeError("a host-callback prior (HostPrior / scipy.stats) needs a host-callable f_dist: a device-coded simulator "
                         "evaluates the prior inside its fused kernel and needs it as data")
+    if getattr(prior, "source_prior", False) and getattr(f_dist, "model_id", None) != _lib.MODEL_USER:
+        raise TypeError("a SourcePrior is device code inside the simulator's HIP source: f_dist must be a DeviceSource")
     if not isinstance(f_dist, DeviceDistance):
         if not callable(f_dist):
             raise TypeError("f_dist must be a DeviceDistance or a callable f_dist(θ, *args, **kwargs)")
@@ -276,7 +278,9 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         prior = res._prior
     if f_dist is not res._model or prior is not res._prior:
         if type(f_dist) is not type(res._model) or list(f_dist.params) != list(res._model.params) or \
-                prior.descriptors() != res._prior.descriptors() or \
+                getattr(f_dist, "source", None) != getattr(res._model, "source", None) or \
+                getattr(f_dist, "fn", None) is not getattr(res._model, "fn", None) or \
+                prior.descriptors() != res._prior.descriptors() or type(prior) is not type(res._prior) or \
                 not np.array_equal(np.asarray(getattr(prior, "chol", 0.0)), np.asarray(getattr(res._prior, "chol", 0.0))):
             raise ValueError("f_dist / prior differ from the ones this SABCresult was initialised with")
     h = res._handle

@@ -265,11 +265,20 @@ int sabc_set_alltoallv(sabc_handle *h, sabc_alltoallv_fn fn) {
 
 int64_t sabc_comm_bytes(const sabc_handle *h) { return h ? h->eng->comm_bytes() : 0; }
 
+static int compile_only(const char *hip_source, int32_t d, int32_t s, char *log_out, int64_t log_cap, bool user_prior);
+
 int sabc_op_compile_device_simulator(const char *hip_source, int32_t d, int32_t s, char *log_out, int64_t log_cap) {
+  return compile_only(hip_source, d, s, log_out, log_cap, false);
+}
+int sabc_op_compile_device_simulator_with_prior(const char *hip_source, int32_t d, int32_t s, char *log_out, int64_t log_cap) {
+  return compile_only(hip_source, d, s, log_out, log_cap, true);
+}
+
+static int compile_only(const char *hip_source, int32_t d, int32_t s, char *log_out, int64_t log_cap, bool user_prior) {
   if (!hip_source) { g_err = "null device simulator source"; return SABC_ERR_BAD_CONFIG; }
   std::string log;
   size_t cs = 0;
-  const int rc = rtc_compile(hip_source, d, s, rtc_default_csrc_dir(), nullptr, &log, &cs);
+  const int rc = rtc_compile(hip_source, d, s, rtc_default_csrc_dir(), nullptr, &log, &cs, user_prior);
   if (log_out && log_cap > 0) { std::snprintf(log_out, (size_t)log_cap, "%s", log.c_str()); }
   if (rc) { g_err = "compiling the device simulator failed:\n" + log; return SABC_ERR_BAD_CONFIG; }
   return 0;

@@ -99,7 +99,7 @@ __device__ __forceinline__ double prior_sample_dim(const ModelDesc &m, int k, ui
 // MvNormal(mu, L L'): logpdf = -1/2 |L^-1 (x - mu)|^2 - (d/2 log 2 pi + sum log L_kk) by forward substitution;
 // rand = mu + L z with z_k the first normal of block k of the PRIOR stream (a diagonal L gives the product of Normals)
 __device__ __forceinline__ double mvnormal_logpdf(const ModelDesc &m, int d, const double *th) {
-  double y[kMaxPara], q = 0.0;
+  double y[kMaxJointPara], q = 0.0;
   for (int k = 0; k < d; ++k) {
     double r = th[k] - m.prior_a[k];
     for (int l = 0; l < k; ++l) r -= m.prior_L[k * d + l] * y[l];
@@ -110,7 +110,7 @@ __device__ __forceinline__ double mvnormal_logpdf(const ModelDesc &m, int d, con
 }
 
 __device__ __forceinline__ void mvnormal_sample(const ModelDesc &m, int d, uint64_t pid, double *th) {
-  double z[kMaxPara];
+  double z[kMaxJointPara];
   for (int k = 0; k < d; ++k) {
     double z1;
     box_muller(stream_block(m.seed, pid, PURPOSE_PRIOR, 0, (uint32_t)k), z[k], z1);
@@ -122,8 +122,25 @@ __device__ __forceinline__ void mvnormal_sample(const ModelDesc &m, int d, uint6
   }
 }
 
+}  // namespace sabc
+// SABC_USER_PRIOR (set by rtc.cpp when the handle's prior_joint is 3): the prior comes with the user's simulator source --
+// ANY distribution next to a device-coded f_dist, evaluated inside the fused kernel like the built-in families (the
+// reference takes any Distributions.Distribution at SimulatedAnnealingABC.jl:151,174,314,318).  The source defines, at
+// global scope, next to sabc_user_simulate:
+//   __device__ void   sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);   // rand(prior)
+//   __device__ double sabc_user_prior_logpdf(const double *theta, const double *params);    // -INFINITY outside the support
+// `rng` is the particle's PRIOR stream (rng.next(): N(0,1); rng.uniform_pair(u0, u1): U(0,1)).
+#if defined(SABC_USER_PRIOR)
+__device__ void sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);
+__device__ double sabc_user_prior_logpdf(const double *theta, const double *params);
+#endif
+namespace sabc {
+
 template <int D>
 __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double *th) {
+#if defined(SABC_USER_PRIOR)
+  if (m.prior_joint == 3) return ::sabc_user_prior_logpdf(th, m.p);
+#endif
   if (D > 1 && m.prior_joint == 1) return mvnormal_logpdf(m, D, th);
   double lp = 0.0;
 #pragma unroll
@@ -137,6 +154,13 @@ __device__ __forceinline__ double prior_logpdf(const ModelDesc &m, const double 
 // rand(prior) at :174
 template <int D>
 __device__ __forceinline__ void prior_sample(const ModelDesc &m, uint64_t pid, double *th) {
+#if defined(SABC_USER_PRIOR)
+  if (m.prior_joint == 3) {
+    NormalStream ns(m.seed, pid, PURPOSE_PRIOR, 0);
+    ::sabc_user_prior_sample(m.p, ns, th);
+    return;
+  }
+#endif
   if (D > 1 && m.prior_joint == 1) { mvnormal_sample(m, D, pid, th); return; }
 #pragma unroll
   for (int k = 0; k < D; ++k) th[k] = prior_sample_dim(m, k, pid);

@@ -21,6 +21,22 @@ enum : uint32_t { PURPOSE_PRIOR = 0, PURPOSE_SIM = 1, PURPOSE_PROP = 2, PURPOSE_
 
 struct u32x4 { uint32_t x, y, z, w; };
 
+// a ^ b ^ c: one v_bitop3_b32 (truth table 0x96, new on gfx950) where the compiler in use knows the builtin -- hipcc of
+// ROCm 7.x does; a hipRTC whose clang is older (the GPU box's run-time compiler once lacked a builtin hipcc had) falls
+// back to two v_xor_b32.  Same bits either way (the Random123 known answers run through both, tests/test_user_simulator.py).
+#if defined(__has_builtin)
+#if __has_builtin(__builtin_amdgcn_bitop3_b32) && !defined(SABC_NO_BITOP3)
+#define SABC_HAVE_BITOP3 1
+#endif
+#endif
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(SABC_HAVE_BITOP3)
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 __device__ __forceinline__ u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                                uint32_t c3) {
 #pragma unroll
@@ -28,9 +44,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_
     // one v_mad_u64_u32 per product: hi and lo halves come from the same instruction
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-    // three-input XOR in one instruction (v_bitop3_b32, truth table 0x96), new on gfx950
-    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96);
-    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c3, k1, 0x96);
+    // three-input XOR in one instruction where available (xor3)
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;

@@ -44,8 +44,8 @@ Engine::Engine(const sabc_config &cfg, Backend *backend, Collectives *coll) : cf
   }
   m_.prior_joint = cfg.prior_joint;
   m_.prior_joint_logc = 0.5 * (double)cfg.n_para * 1.8378770664093454835606594728112;   // d/2 log(2 pi)
-  for (int i = 0; i < kMaxPara * kMaxPara; ++i) m_.prior_L[i] = 0.0;
-  if (cfg.prior_joint == 1 && cfg.n_para >= 1 && cfg.n_para <= kMaxPara)
+  for (int i = 0; i < kMaxJointPara * kMaxJointPara; ++i) m_.prior_L[i] = 0.0;
+  if (cfg.prior_joint == 1 && cfg.n_para >= 1 && cfg.n_para <= kMaxJointPara)
     for (int k = 0; k < cfg.n_para; ++k) {
       for (int l = 0; l <= k; ++l) m_.prior_L[k * cfg.n_para + l] = cfg.prior_chol[k * cfg.n_para + l];
       const double lkk = cfg.prior_chol[k * cfg.n_para + k];
@@ -94,14 +94,17 @@ int Engine::validate() {
       ok = false;
   }
   if (!ok) return fail(SABC_ERR_BAD_CONFIG, "unknown model id or model parameters inconsistent with n_para / n_stats");
-  if (cfg_.prior_joint < 0 || cfg_.prior_joint > 2) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
+  if (cfg_.prior_joint < 0 || cfg_.prior_joint > 3) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
+  if (cfg_.prior_joint == 3 && cfg_.model_id != SABC_MODEL_USER)
+    return fail(SABC_ERR_BAD_CONFIG, "a prior from device source travels in the simulator's source (SABC_MODEL_USER)");
   if (cfg_.prior_joint == 2 && cfg_.model_id != SABC_MODEL_HOST)
     return fail(SABC_ERR_BAD_CONFIG, "a host-callback prior needs a host-callback simulator (SABC_MODEL_HOST)");
   if (cfg_.prior_joint == 1) {
+    if (d > kMaxJointPara) return fail(SABC_ERR_BAD_CONFIG, "an MvNormal prior as data takes at most 8 parameters");
     for (int k = 0; k < d; ++k)
       if (!(cfg_.prior_chol[k * d + k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "MvNormal prior needs a Cholesky factor with a positive diagonal");
   }
-  for (int k = 0; k < d && cfg_.prior_joint == 0; ++k) {
+  for (int k = 0; k < d && cfg_.prior_joint == 0; ++k) {          // (joint priors carry no per-dimension descriptors)
     if (cfg_.prior_kind[k] == SABC_PRIOR_NORMAL) {
       if (!(cfg_.prior_b[k] > 0)) return fail(SABC_ERR_BAD_CONFIG, "Normal prior needs sigma > 0");
     } else if (cfg_.prior_kind[k] == SABC_PRIOR_UNIFORM) {

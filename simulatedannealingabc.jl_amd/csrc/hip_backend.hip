@@ -438,7 +438,7 @@ int HipBackend::register_device_simulator(const char *hip_source) {
   if (stream_) HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   rtc_release(&rtc_);
   std::string log;
-  if (rtc_build(hip_source, m_.d, m_.s, rtc_default_csrc_dir(), &rtc_, &log)) {
+  if (rtc_build(hip_source, m_.d, m_.s, rtc_default_csrc_dir(), &rtc_, &log, m_.prior_joint == 3)) {
     err_ = "compiling the device simulator failed:\n" + log;
     return -1;
   }
@@ -805,12 +805,13 @@ int HipBackend::cdf_apply_host(const double *rho, int64_t m, double *u_out) {
 
 int HipBackend::prior_host(uint64_t pid0, int64_t n, double *theta_out, double *logpdf_out) {
   if (m_.prior_joint == 2) { err_ = "sabc_op_prior: the prior of this handle lives in host callbacks"; return -1; }
+  if (m_.prior_joint == 3 && !(rtc() && rtc()->prior_op)) { err_ = "sabc_op_prior: no device simulator source (with its prior) registered"; return -1; }
   if (n <= 0) return 0;
   double *d_th = nullptr, *d_lp = nullptr;
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
   HB_CHECK(hipMalloc((void **)&d_th, (size_t)n * m_.d * sizeof(double)), "hipMalloc");
   HB_CHECK(hipMalloc((void **)&d_lp, (size_t)n * sizeof(double)), "hipMalloc");
-  int rc = check((hipError_t)launch_prior_op(m_, pid0, n, d_th, d_lp, stream_), "k_prior_op");
+  int rc = check((hipError_t)launch_prior_op(m_, pid0, n, d_th, d_lp, stream_, m_.prior_joint == 3 ? rtc() : nullptr), "k_prior_op");
   if (!rc) rc = check(hipMemcpyAsync(theta_out, d_th, (size_t)n * m_.d * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
   if (!rc) rc = check(hipMemcpyAsync(logpdf_out, d_lp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream_), "memcpy");
   if (!rc) rc = check(hipStreamSynchronize(stream_), "hipStreamSynchronize");

@@ -1832,8 +1832,13 @@ int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, ui
   return SABC_LAUNCH_RC();
 }
 
-int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream) {
+int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream,
+                    const RtcKernels *rtc) {
   if (n <= 0) return 0;
+  if (rtc) {                                   // a prior that lives in the run-time compiled unit
+    if (!rtc->prior_op) return (int)hipErrorInvalidValue;
+    return module_launch(rtc->prior_op, (unsigned)n_blocks(n), kBlock, stream, nullptr, nullptr, m, pid0, n, theta, lp);
+  }
   hipLaunchKernelGGL(k_prior_op, dim3((unsigned)n_blocks(n)), dim3(kBlock), 0, stream, m, pid0, n, theta, lp);
   return SABC_LAUNCH_RC();
 }

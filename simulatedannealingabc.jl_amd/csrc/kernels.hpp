@@ -38,7 +38,8 @@ struct PopPtrs {
 #define SABC_UPDATE_BLOCK_MS 512
 #endif
 constexpr int kCdfCoarseMax = SABC_CDF_COARSE > SABC_CDF_COARSE_MS ? SABC_CDF_COARSE : SABC_CDF_COARSE_MS;
-constexpr int cdf_coarse_entries(int s) { return s <= 1 ? SABC_CDF_COARSE : SABC_CDF_COARSE_MS; }
+// (more than 8 statistics -- source-compiled simulators only --: half the entries, or the index alone would not fit the LDS)
+constexpr int cdf_coarse_entries(int s) { return s <= 1 ? SABC_CDF_COARSE : s <= 8 ? SABC_CDF_COARSE_MS : SABC_CDF_COARSE_MS / 2; }
 
 struct CdfPtrs {
   const double *knots;   // [s][stride]; stride is a multiple of 16 (each table starts on a 128-byte line), +inf behind len
@@ -183,7 +184,8 @@ int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m
 int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
                           double *rho_out, hipStream_t stream, const RtcKernels *rtc = nullptr);
-int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream);
+int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream,
+                    const RtcKernels *rtc = nullptr);
 int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,
                         hipStream_t stream);
 int launch_rng_peak(uint64_t seed, int pairs, int64_t n, double *out, hipStream_t stream);

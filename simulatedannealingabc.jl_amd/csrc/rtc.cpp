@@ -64,7 +64,7 @@ void anchor() {}
 // sabc() call makes one) loads the module without paying the ~2 s of compilation again
 struct CachedModule {
   std::vector<char> code;
-  std::string lowered[6];
+  std::string lowered[7];
 };
 std::mutex g_cache_mutex;
 std::map<std::string, CachedModule> g_cache;
@@ -86,13 +86,15 @@ void rtc_release(RtcKernels *k) {
   if (k) *k = RtcKernels();
 }
 
-int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log) {
-  return rtc_compile(user_source, d, s, csrc_dir, out, log, nullptr);
+int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
+              bool user_prior) {
+  return rtc_compile(user_source, d, s, csrc_dir, out, log, nullptr, user_prior);
 }
 
 // out == nullptr: compile only (needs no device); code_size (optional) receives the size of the code object
 int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-                size_t *code_size) {
+                size_t *code_size, bool user_prior) {
+  constexpr int kKernels = 7;
   HiprtcApi *api = hiprtc_api();
   if (!api) { *log = "libhiprtc.so could not be loaded: simulators from source need the hipRTC of ROCm"; return -1; }
   if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_STATS) { *log = "n_para / n_stats out of range"; return -1; }
@@ -112,13 +114,17 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   src += user_source;
   src += tail;
 
-  char name[8][96];
+  char name[8][96];   // kKernels <= 8
   std::snprintf(name[0], sizeof(name[0]), "sabc::k_prior_simulate<%d, %d, %d>", SABC_MODEL_USER, d, s);
   for (int p = 0; p < 3; ++p) std::snprintf(name[1 + p], sizeof(name[1 + p]), "sabc::k_update<%d, %d, %d, %d>", SABC_MODEL_USER, d, s, p);
   std::snprintf(name[4], sizeof(name[4]), "sabc::k_simulate_batch<%d, %d, %d>", SABC_MODEL_USER, d, s);
   std::snprintf(name[5], sizeof(name[5]), "sabc::k_stats<%d, %d>", d, s);
+  std::snprintf(name[6], sizeof(name[6]), "sabc::k_prior_op_t<%d>", d);
+  // extra compiler flags (e.g. -DSABC_NO_BITOP3: the two-instruction form of the Philox round's three-input XOR)
+  const char *extra_env = std::getenv("SABC_RTC_EXTRA_FLAGS");
+  const std::string extra = extra_env ? extra_env : "";
 
-  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + "\n" + user_source;
+  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + "," + extra + "\n" + user_source;
   if (out) {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto hit = g_cache.find(cache_key);
@@ -126,8 +132,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       RtcKernels k;
       k.d = d; k.s = s;
       if (hipModuleLoadData(&k.module, hit->second.code.data()) != hipSuccess) { *log = "hipModuleLoadData of the cached simulator failed"; return -1; }
-      hipFunction_t *slots[6] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats};
-      for (int i = 0; i < 6; ++i)
+      hipFunction_t *slots[kKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op};
+      for (int i = 0; i < kKernels; ++i)
         if (hipModuleGetFunction(slots[i], k.module, hit->second.lowered[i].c_str()) != hipSuccess) {
           *log = std::string("kernel not found in the cached module: ") + name[i];
           rtc_release(&k);
@@ -140,7 +146,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   }
   void *prog = nullptr;
   if (api->CreateProgram(&prog, src.c_str(), "sabc_user_simulator.hip", 0, nullptr, nullptr)) { *log = "hiprtcCreateProgram failed"; return -1; }
-  for (int i = 0; i < 6; ++i) api->AddNameExpression(prog, name[i]);
+  for (int i = 0; i < kKernels; ++i) api->AddNameExpression(prog, name[i]);
   const char *rocm = std::getenv("ROCM_PATH");
   const std::string inc_rocm = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
   const std::string inc_csrc = "-I" + csrc_dir;
@@ -148,14 +154,24 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   // compiled for: a variant library (tools/build_variants.sh) forwards its -D overrides to the run-time compiler
 #define SABC_RTC_STR2(x) #x
 #define SABC_RTC_STR(x) SABC_RTC_STR2(x)
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str(),
+  std::vector<const char *> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc_csrc.c_str(), inc_rocm.c_str(),
                         "-DSABC_UPDATE_BLOCK=" SABC_RTC_STR(SABC_UPDATE_BLOCK), "-DSABC_UPDATE_BLOCK_MS=" SABC_RTC_STR(SABC_UPDATE_BLOCK_MS),
                         "-DSABC_CDF_COARSE=" SABC_RTC_STR(SABC_CDF_COARSE), "-DSABC_CDF_COARSE_MS=" SABC_RTC_STR(SABC_CDF_COARSE_MS),
                         "-DSABC_UPDATE_MIN_WAVES=" SABC_RTC_STR(SABC_UPDATE_MIN_WAVES),
                         "-DSABC_UPDATE_MIN_WAVES_MS=" SABC_RTC_STR(SABC_UPDATE_MIN_WAVES_MS)};
 #undef SABC_RTC_STR
 #undef SABC_RTC_STR2
-  const int rc = api->CompileProgram(prog, (int)(sizeof(opts) / sizeof(opts[0])), opts);
+  if (user_prior) opts.push_back("-DSABC_USER_PRIOR=1");
+  std::vector<std::string> extra_words;
+  for (size_t i = 0; i < extra.size();) {
+    while (i < extra.size() && extra[i] == ' ') ++i;
+    size_t j = i;
+    while (j < extra.size() && extra[j] != ' ') ++j;
+    if (j > i) extra_words.push_back(extra.substr(i, j - i));
+    i = j;
+  }
+  for (const std::string &w : extra_words) opts.push_back(w.c_str());
+  const int rc = api->CompileProgram(prog, (int)opts.size(), opts.data());
   size_t ls = 0;
   api->GetProgramLogSize(prog, &ls);
   if (ls > 1) { log->assign(ls, '\0'); api->GetProgramLog(prog, &(*log)[0]); }
@@ -168,7 +184,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   api->GetCodeSize(prog, &cs);
   if (code_size) *code_size = cs;
   if (!out) {                                         // compile-only check: every kernel must be there by name
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < kKernels; ++i) {
       const char *lowered = nullptr;
       if (api->GetLoweredName(prog, name[i], &lowered) || !lowered) {
         *log = std::string("kernel missing from the compiled module: ") + name[i];
@@ -188,9 +204,9 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
     api->DestroyProgram(&prog);
     return -1;
   }
-  hipFunction_t *slots[6] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats};
+  hipFunction_t *slots[kKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op};
   CachedModule entry;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < kKernels; ++i) {
     const char *lowered = nullptr;
     if (api->GetLoweredName(prog, name[i], &lowered) || !lowered ||
         hipModuleGetFunction(slots[i], k.module, lowered) != hipSuccess) {

@@ -12,6 +12,7 @@ struct RtcKernels {
   hipFunction_t update[3] = {nullptr, nullptr, nullptr};   // k_update<USER, D, S, PROP>
   hipFunction_t simulate_batch = nullptr;      // k_simulate_batch<USER, D, S>
   hipFunction_t stats = nullptr;               // k_stats<D, S>
+  hipFunction_t prior_op = nullptr;            // k_prior_op_t<D>
   int d = 0, s = 0;
 };
 
@@ -19,10 +20,12 @@ struct RtcKernels {
 //     __device__ void sabc_user_simulate(const double *theta, const double *params, sabc::NormalStream &rng, double *rho_out);
 // ) for gfx950 and loads the kernels for (d, s).  `csrc_dir` holds update_kernel.hpp and what it includes.
 // Returns 0 or -1 with the compiler log / error text in `log`.
-int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log);
+// user_prior: the source also defines sabc_user_prior_sample / sabc_user_prior_logpdf (sabc_config::prior_joint = 3).
+int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
+              bool user_prior = false);
 // the same with out == nullptr stopping after the compiler (no device needed): a syntax / interface check of a source
 int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-                size_t *code_size);
+                size_t *code_size, bool user_prior = false);
 void rtc_release(RtcKernels *k);
 // directory of this shared library + "/csrc" (the headers ship next to the library)
 std::string rtc_default_csrc_dir();

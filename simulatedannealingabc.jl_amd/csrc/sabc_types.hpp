@@ -8,6 +8,7 @@ namespace sabc {
 
 constexpr int kMaxPara = SABC_MAX_PARA;
 constexpr int kMaxStats = SABC_MAX_STATS;
+constexpr int kMaxJointPara = SABC_MAX_JOINT_PARA;   // MvNormal prior as data
 
 // What f_dist and prior are, as data (the sabc() arguments of SimulatedAnnealingABC.jl:451).
 struct ModelDesc {
@@ -21,7 +22,7 @@ struct ModelDesc {
   double prior_k0[kMaxPara], prior_k1[kMaxPara];   // truncated Normal: Phi(lo') (lo' > 0: -Phi(-lo'), mirrored draw), Phi(hi') - Phi(lo') of the standardised bounds
   // prior_joint = 1: MvNormal(prior_a, L L'), L row-major d x d lower; logc = d/2 log(2 pi) + sum log L_kk
   int32_t prior_joint, prior_pad;
-  double prior_L[kMaxPara * kMaxPara];
+  double prior_L[kMaxJointPara * kMaxJointPara];
   double prior_joint_logc;
   uint64_t seed;
 };

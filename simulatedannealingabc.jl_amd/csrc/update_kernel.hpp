@@ -257,6 +257,21 @@ __global__ void __launch_bounds__(kBlock) k_prior_simulate(const ModelDesc m, co
   for (int j = 0; j < S; ++j) pp.rho[(int64_t)j * pp.cap + li] = rho[j];
 }
 
+// rand(prior) and its log density for particle ids pid0.. (sabc_op_prior), for a prior that lives in the run-time compiled
+// unit (prior_joint = 3); the built-in families go through kernels.hip's run-time-d version
+template <int D>
+__global__ void __launch_bounds__(kBlock)
+k_prior_op_t(const ModelDesc m, const uint64_t pid0, const int64_t n, double *__restrict__ theta, double *__restrict__ lp) {
+  rng_tables_init();
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double th[D];
+  prior_sample<D>(m, pid0 + (uint64_t)i, th);
+#pragma unroll
+  for (int k = 0; k < D; ++k) theta[(int64_t)k * n + i] = th[k];
+  lp[i] = prior_logpdf<D>(m, th);
+}
+
 template <int MODEL, int D, int S>
 __global__ void __launch_bounds__(kBlock)
 k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,

@@ -182,8 +182,8 @@ class MvNormal(Distribution):
         d = len(self.μ)
         if self.Σ.shape != (d, d) or not np.allclose(self.Σ, self.Σ.T):
             raise ValueError("MvNormal: Σ must be a symmetric d × d matrix")
-        if d > _lib.MAX_PARA:
-            raise ValueError(f"at most {_lib.MAX_PARA} parameters are supported")
+        if d > _lib.MAX_JOINT_PARA:
+            raise ValueError(f"MvNormal as data: at most {_lib.MAX_JOINT_PARA} parameters are supported")
         try:
             self.chol = np.linalg.cholesky(self.Σ)
         except np.linalg.LinAlgError as e:
@@ -250,6 +250,36 @@ class HostPrior(Distribution):
 
     def __repr__(self):
         return f"HostPrior(n_para={self.n_para})"
+
+
+class SourcePrior(Distribution):
+    """ANY prior next to a simulator given as HIP source (`DeviceSource`): the same source defines
+
+        __device__ void   sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);
+        __device__ double sabc_user_prior_logpdf(const double *theta, const double *params);   // -INFINITY outside the support
+
+    and both are compiled into the fused update kernel (sabc_config::prior_joint = 3): rand(prior) and logpdf(prior, .)
+    of SimulatedAnnealingABC.jl:174,314,318 run on the device, no host round trip.  `params` is the simulator's list."""
+    source_prior = True
+
+    def __init__(self, n_para, univariate=None):
+        self.n_para = int(n_para)
+        if not 1 <= self.n_para <= _lib.MAX_PARA:
+            raise ValueError(f"1 to {_lib.MAX_PARA} parameters are supported")
+        self._univariate = (self.n_para == 1) if univariate is None else bool(univariate)
+
+    @property
+    def univariate(self):
+        return self._univariate
+
+    def __len__(self):
+        return self.n_para
+
+    def descriptors(self):
+        return [(_lib.PRIOR_NORMAL, 0.0, 1.0)] * self.n_para          # placeholders: the library never reads them
+
+    def __repr__(self):
+        return f"SourcePrior(n_para={self.n_para})"
 
 
 def from_scipy(dist, seed=None):

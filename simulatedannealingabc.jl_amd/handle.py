@@ -42,6 +42,8 @@ class SabcHandle:
                     cfg.prior_chol[k * d + l] = float(L[k, l])
         if getattr(prior, "host_prior", False):     # any prior, as host callbacks (sabc_set_host_prior)
             cfg.prior_joint = 2
+        if getattr(prior, "source_prior", False):   # any prior, as device code in the simulator's HIP source
+            cfg.prior_joint = 3
         cfg.algorithm = int(algorithm)
         cfg.rank, cfg.world = int(rank), int(world)
         cfg.v, cfg.delta, cfg.seed = float(v), float(delta), int(seed)

@@ -23,7 +23,7 @@ export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
 
 const libsabc = get(ENV, "SABC_HIP_LIB", joinpath(@__DIR__, "..", "libsabc_hip.so"))
 
-const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 8, 8, 32
+const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
 const MAX_PARA2 = MAX_PARA * MAX_PARA      # the row-major Cholesky factor of an MvNormal prior
 
 # ---- C structs (must match include/sabc_hip.h field for field) ----

@@ -155,11 +155,13 @@ class DeviceSource(DeviceDistance):
     def params(self):
         return list(self._params)
 
-    def compile_check(self):
-        """Run the compiler stage only (no GPU needed); raises SABCError with the compiler log on failure."""
+    def compile_check(self, with_prior=False):
+        """Run the compiler stage only (no GPU needed); raises SABCError with the compiler log on failure.
+        with_prior: the source also defines the prior (SourcePrior)."""
         import ctypes as C
         log = C.create_string_buffer(1 << 16)
-        rc = _lib.lib().sabc_op_compile_device_simulator(self.source.encode(), self.n_para[0], self.n_stats, log, len(log))
+        fn = _lib.lib().sabc_op_compile_device_simulator_with_prior if with_prior else _lib.lib().sabc_op_compile_device_simulator
+        rc = fn(self.source.encode(), self.n_para[0], self.n_stats, log, len(log))
         if rc:
             raise _lib.SABCError(rc, "compiling the device simulator failed:\n" + log.value.decode("utf-8", "replace"))
         return True

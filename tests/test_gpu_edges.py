@@ -92,7 +92,37 @@ def test_maximum_shapes_in_host_mode(S, O, gpu):
             np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
             np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
     with pytest.raises(S.SABCError):
-        S.sabc(lambda θ: np.zeros(9) + 1, prior, n_particles=100, n_simulation=1000)      # s = 9 > SABC_MAX_STATS
+        S.sabc(lambda θ: np.zeros(17) + 1, prior, n_particles=100, n_simulation=1000)     # s = 17 > SABC_MAX_STATS
+
+
+def test_beyond_eight_dimensions_in_host_mode(S, O, gpu):
+    """d = 12 parameters, s = 10 statistics (the reference takes any length(prior) and any number of distances,
+    SimulatedAnnealingABC.jl:163-167,181; here up to 16 x 16 for host-callback and source-compiled simulators): a 12 x 12
+    RandomWalk covariance and its Cholesky factor in the control step, 145 sum columns per particle, rows of d + s = 22
+    doubles in the resample (no packed line).  Against the oracle driven by the same id-keyed host simulator."""
+    d, s = 12, 10
+    truth = np.linspace(-1, 1, d)
+    def f_dist(θ, pid, it):
+        z = np.array([O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b) for b in range(5)]).ravel()
+        return np.abs(θ[:s] + 0.5 * θ[(np.arange(s) + 3) % d] + 0.1 * z - truth[:s])
+    prior = S.product_distribution([S.Normal(0.0, 2.0)] * 6 + [S.Uniform(-3.0, 3.0)] * 6)
+    opri = [(O.PRIOR_NORMAL, 0.0, 2.0)] * 6 + [(O.PRIOR_UNIFORM, -3.0, 3.0)] * 6
+    n, k = 300, 8
+    for alg, prop in (("single_eps", "rw"), ("multi_eps", "de"), ("single_eps", "stretch")):
+        hd = S.HostDistance(f_dist, n_stats=s, n_para=d, univariate=False, with_ids=True)
+        res = S.sabc(hd, prior, n_particles=n, n_simulation=n * (k + 1), algorithm=alg, proposal=hip_proposal(S, prop, d),
+                     resample=n // 2, seed=SEED)
+        cfg = O.make_config(n_particles=n, n_para=d, n_stats=s, model_id=O.MODEL_HOST, model_params=[], prior=opri, seed=SEED,
+                            algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS, host_fn=O.host_simulator(f_dist, d, s))
+        run = O.OracleRun(cfg)
+        run.initialize(n * (k + 1))
+        run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=n // 2))
+        assert res.population.shape == (n, d) and res.u.shape == (n, s) and len(res.state.ϵ) == (s if alg == "multi_eps" else 1)
+        assert res.state.n_accept == run.counters["n_accept"] and res.state.n_resampling == run.counters["n_resampling"] >= 2
+        tol = {"rw": 1e-8, "stretch": 1e-6, "de": 1e-5}[prop]
+        np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+        np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
+        np.testing.assert_allclose(res.ρ.T, run.rho, rtol=tol, atol=tol)
 
 
 def test_resample_disabled_and_every_update(S, O, gpu):

@@ -169,3 +169,179 @@ def test_unregistered_or_broken_source_fails_loudly(S, gpu):
     with pytest.raises(S.SABCError) as e:
         S.sabc(S.DeviceSource("__device__ void sabc_user_simulate() {}", 1, 1), S.Normal(0, 1), n_particles=256, n_simulation=512)
     assert "compiling the device simulator failed" in str(e.value)
+
+
+# ---- the shapes the path advertises (any d, s within the maxima): a generic simulator parametrised by (d, s) ----
+SHAPE_SRC = r"""
+__device__ void sabc_user_simulate(const double *theta, const double *p, sabc::NormalStream &rng, double *rho) {
+  const int d = (int)p[0], s = (int)p[1];
+  for (int j = 0; j < s; ++j) {
+    const double z = rng.next();
+    rho[j] = fabs(theta[j % d] + 0.5 * theta[(j + 1) % d] + p[2] * z - p[3 + j]);
+  }
+}
+"""
+
+
+def shape_params(d, s):
+    return [d, s, 0.4] + [0.3 * ((j % 5) - 2) for j in range(s)]
+
+
+def test_source_compiles_at_the_corner_shapes(S):
+    """The compiler stage for the corners of (d, s) in 1..8 x 1..8 (the full grid: test below, opt-in -- ~4 s per shape)
+    and for the maxima (16, 16): 128 KB of LDS index, 185 sum columns per particle."""
+    for d, s in ((1, 1), (8, 8), (1, 8), (8, 1), (16, 16)):
+        assert S.DeviceSource(SHAPE_SRC, d, s, shape_params(d, s)).compile_check(), (d, s)
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("SABC_RTC_FULL_GRID"), reason="64 compilations, ~4 min: set SABC_RTC_FULL_GRID=1")
+def test_source_compiles_for_every_shape(S):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(ds):
+        try:
+            return S.DeviceSource(SHAPE_SRC, ds[0], ds[1], shape_params(*ds)).compile_check()
+        except S.SABCError as e:
+            return str(e)
+    shapes = [(d, s) for d in range(1, 9) for s in range(1, 9)]
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, shapes))
+    assert all(r is True for r in res), [(sh, r) for sh, r in zip(shapes, res) if r is not True]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,s,alg", [(8, 8, "multi_eps"), (4, 8, "single_eps"), (8, 1, "single_eps"), (5, 3, "multi_eps"),
+                                     (12, 10, "single_eps")])
+def test_source_simulator_at_the_advertised_shapes(S, O, gpu, d, s, alg):
+    """(d, s) up to (8, 8): 128 KB of LDS index, 61 sum columns per particle, an 8 x 8 Cholesky in the control step.  Against
+    the oracle's host-callback model driving the same arithmetic from Python with the same Philox blocks."""
+    n, k = 1500, 5
+    params = shape_params(d, s)
+
+    def f(θ, pid, it):
+        th = np.atleast_1d(θ)
+        out = []
+        for j in range(s):
+            z = O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, j // 2)[j % 2]
+            out.append(abs(th[j % d] + 0.5 * th[(j + 1) % d] + params[2] * z - params[3 + j]))
+        return tuple(out)
+
+    prior = S.product_distribution([S.Normal(0.0, 1.0)] * d) if d > 1 else S.Normal(0.0, 1.0)
+    res = S.sabc(S.DeviceSource(SHAPE_SRC, d, s, params), prior, n_particles=n, n_simulation=(k + 1) * n,
+                 proposal=S.RandomWalk(n_para=d), resample=n // 2, algorithm=alg, seed=SEED)
+    cfg = O.make_config(n_particles=n, n_para=d, n_stats=s, model_id=O.MODEL_HOST, model_params=[], seed=SEED,
+                        prior=[(O.PRIOR_NORMAL, 0.0, 1.0)] * d, host_fn=O.host_simulator(f, d, s),
+                        algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS)
+    run = O.OracleRun(cfg)
+    run.initialize((k + 1) * n)
+    run.update(O.make_update_args(n_simulation=k * n, proposal=oracle_proposal(O, "rw", d), n_para=d, n_particles=n, resample=n // 2))
+    c = run.counters
+    assert (res.state.n_accept, res.state.n_resampling) == (c["n_accept"], c["n_resampling"])
+    pop = res.population.reshape(n, -1)
+    np.testing.assert_allclose(pop.T, run.theta, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res.ρ.T, run.rho, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=1e-8)
+
+
+@pytest.mark.gpu
+def test_philox_round_without_the_three_input_xor_is_bit_identical(S, gpu, monkeypatch):
+    """csrc/device_rng.hpp uses v_bitop3_b32 (new on gfx950) where the compiler knows the builtin and two v_xor_b32 otherwise.
+    The run-time compiled unit built WITHOUT it (-DSABC_NO_BITOP3) must reproduce the compiled-in kernels, which use it,
+    bit for bit: same Philox words, hence the same run."""
+    n, k, ybar = 20_000, 6, 1.4
+    monkeypatch.setenv("SABC_RTC_EXTRA_FLAGS", "-DSABC_NO_BITOP3")
+    prior = S.Normal(0.0, 2.0)
+    a = S.sabc(S.GaussianIID(n_obs=100, sd=1.0, obs_mean=ybar), prior, n_particles=n, n_simulation=(k + 1) * n,
+               proposal=hip_proposal(S, "de", 1), resample=n // 2, seed=SEED)
+    b = S.sabc(S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, ybar, 0.0]), prior, n_particles=n, n_simulation=(k + 1) * n,
+               proposal=hip_proposal(S, "de", 1), resample=n // 2, seed=SEED)
+    assert a.state.n_accept == b.state.n_accept
+    np.testing.assert_array_equal(a.population, b.population)
+    np.testing.assert_array_equal(a.ρ, b.ρ)
+
+
+# ---- the prior, too, as device code in the same source (sabc_config::prior_joint = 3; Python: SourcePrior) ----
+W_MIX = 0.35
+MIX_SRC = r"""
+// simulator: y_1..10 ~ N(theta_0, theta_1), distance of the sample mean to p[0]
+__device__ void sabc_user_simulate(const double *theta, const double *p, sabc::NormalStream &rng, double *rho) {
+  double sz = 0.0;
+  for (int k = 0; k < 5; ++k) { double z0, z1; rng.pair(z0, z1); sz += z0; sz += z1; }
+  rho[0] = fabs(p[0] - (theta[0] + theta[1] * sz / 10.0));
+}
+// prior: theta_0 ~ w Gamma(2, scale 0.5) + (1 - w) Gamma(3, scale 1) (integer shapes: sums of exponentials), theta_1 ~ Uniform(0.5, 2)
+__device__ void sabc_user_prior_sample(const double *p, sabc::NormalStream &rng, double *th) {
+  double u0, u1, u2, u3, u4, u5;
+  rng.uniform_pair(u0, u1);
+  rng.uniform_pair(u2, u3);
+  rng.uniform_pair(u4, u5);
+  th[0] = u0 < p[1] ? -0.5 * (log(u1) + log(u2)) : -(log(u1) + log(u2) + log(u3));
+  th[1] = 0.5 + 1.5 * u4;
+}
+__device__ double sabc_user_prior_logpdf(const double *th, const double *p) {
+  const double x = th[0], y = th[1];
+  if (!(x > 0.0) || !(y >= 0.5 && y <= 2.0)) return -INFINITY;
+  const double g2 = x * exp(-x / 0.5) / 0.25, g3 = x * x * exp(-x) / 2.0;
+  return log(p[1] * g2 + (1.0 - p[1]) * g3) - log(1.5);
+}
+"""
+
+
+def test_source_with_its_prior_compiles_without_a_device(S):
+    assert S.DeviceSource(MIX_SRC, 2, 1, [1.2, W_MIX]).compile_check(with_prior=True)
+    with pytest.raises(S.SABCError):                       # the prior functions are missing: the link of the unit fails
+        S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, 1.5, 0.0]).compile_check(with_prior=True)
+    with pytest.raises(TypeError):
+        S.sabc(S.GaussianIID(n_obs=10), S.SourcePrior(1), n_particles=100, n_simulation=200)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_prior_from_source_equals_the_same_prior_as_host_callbacks(S, O, gpu, prop):
+    """A Gamma-mixture x Uniform prior that is none of the built-in families, (A) as device code next to the simulator
+    (SourcePrior: rand and logpdf run inside the fused kernel) and (B) as host callbacks next to the same simulator as a
+    host callable (HostPrior + HostDistance), both drawing the same Philox blocks: particle for particle the same run."""
+    from scipy import stats
+    n, k, center = 3000, 8, 1.2
+    params = [center, W_MIX]
+    res_a = S.sabc(S.DeviceSource(MIX_SRC, 2, 1, params), S.SourcePrior(2), n_particles=n, n_simulation=(k + 1) * n,
+                   proposal=hip_proposal(S, prop, 2), resample=n // 2, seed=SEED)
+
+    def f(θ, pid, it):
+        sz = 0.0
+        for b in range(5):
+            z0, z1 = O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b)
+            sz += z0
+            sz += z1
+        return abs(center - (θ[0] + θ[1] * sz / 10.0))
+
+    def sample(ids):
+        out = np.empty((len(ids), 2))
+        for r, pid in enumerate(ids):
+            w = [O.stream_block(SEED, int(pid), O.PURPOSE_PRIOR, 0, b) for b in range(3)]
+            u = [O.u52(w[b][0], w[b][1]) for b in range(3)] + [O.u52(w[b][2], w[b][3]) for b in range(3)]
+            u0, u2, u4, u1, u3, _ = u
+            out[r, 0] = -0.5 * (np.log(u1) + np.log(u2)) if u0 < W_MIX else -(np.log(u1) + np.log(u2) + np.log(u3))
+            out[r, 1] = 0.5 + 1.5 * u4
+        return out
+
+    def logpdf(th):
+        x, y = th[:, 0], th[:, 1]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            g2, g3 = x * np.exp(-x / 0.5) / 0.25, x * x * np.exp(-x) / 2.0
+            lp = np.log(W_MIX * g2 + (1.0 - W_MIX) * g3) - np.log(1.5)
+        return np.where((x > 0) & (y >= 0.5) & (y <= 2.0), lp, -np.inf)
+
+    hd = S.HostDistance(f, n_stats=1, n_para=2, univariate=False, with_ids=True)
+    res_b = S.sabc(hd, S.HostPrior(sample, logpdf, 2), n_particles=n, n_simulation=(k + 1) * n,
+                   proposal=hip_proposal(S, prop, 2), resample=n // 2, seed=SEED)
+    assert (res_a.state.n_accept, res_a.state.n_resampling) == (res_b.state.n_accept, res_b.state.n_resampling)
+    tol = {"rw": 1e-9, "de": 1e-6}[prop]
+    np.testing.assert_allclose(res_a.population, res_b.population, rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(res_a.ρ, res_b.ρ, rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(res_a.state.ϵ, res_b.state.ϵ, rtol=tol)
+    # the device draws of the prior follow the mixture (sabc_op_prior through the run-time compiled unit)
+    th, lp = res_a._handle.prior(0, 20_000)
+    mix_cdf = lambda x: W_MIX * stats.gamma(2, scale=0.5).cdf(x) + (1 - W_MIX) * stats.gamma(3, scale=1.0).cdf(x)
+    assert stats.kstest(th[0], mix_cdf).pvalue > 1e-3 and stats.kstest(th[1], stats.uniform(0.5, 1.5).cdf).pvalue > 1e-3
+    np.testing.assert_allclose(lp, logpdf(th.T), rtol=1e-12, atol=1e-12)

@@ -12,6 +12,7 @@ for step in "$@"; do
     trace2) SABC_BENCH_TRACE=1 timeout -k 10 200 python bench.py --gpus 2 --dist-backend gloo --p2p on --no-cpu-baseline --repeats 2 --steps 20 > gpurun_out/r03_trace2.json 2> gpurun_out/r03_trace2.err; echo "trace2 rc=$?"; grep -v amdgpu.ids gpurun_out/r03_trace2.err | tail -30 ;;
     hosttests) timeout -k 10 600 python -m pytest tests/test_gpu_host_fdist.py tests/test_host_prior.py -q -m gpu -x > gpurun_out/r03_hosttests.log 2>&1; echo "hosttests rc=$?"; tail -5 gpurun_out/r03_hosttests.log ;;
     benchhost) timeout -k 10 300 python bench.py --config host > gpurun_out/r03_bench_host.json 2> gpurun_out/r03_bench_host.err; echo "benchhost rc=$?"; tail -3 gpurun_out/r03_bench_host.err ;;
+    rtc) timeout -k 10 900 python -m pytest tests/test_user_simulator.py -q -m gpu -x > gpurun_out/r03_rtc.log 2>&1; echo "rtc rc=$?"; tail -15 gpurun_out/r03_rtc.log ;;
     gpu) timeout -k 10 1100 python -m pytest tests -q -m gpu -x > gpurun_out/r03_gpu_tests.log 2>&1; echo "gpu rc=$?"; tail -5 gpurun_out/r03_gpu_tests.log ;;
   esac
 done
