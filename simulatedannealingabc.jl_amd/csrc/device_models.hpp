@@ -12,6 +12,10 @@
 #ifndef SABC_SIM_UNROLL
 #define SABC_SIM_UNROLL 2
 #endif
+// g-and-k: order statistics at multiples of 16 from block maxima instead of the last four steps of the sort (A/B switch)
+#ifndef SABC_GK_BLOCKMAX
+#define SABC_GK_BLOCKMAX 1
+#endif
 
 namespace sabc {
 
@@ -503,6 +507,31 @@ __device__ __forceinline__ void bitonic_sort128_x2(double &a0, double &a1, doubl
   bitonic_merge_x2<K, K / 2>(a0, a1, b0, b1);
 }
 
+// Only ORDER STATISTICS are wanted, and when every wanted rank is a multiple of 16 (BASELINE config 4: 16, 48, 80, 112 of
+// 128) the last four steps of the final merge can go: after its steps at element distance 64, 32 and 16 every aligned block
+// of 16 elements (8 lanes) holds exactly the ranks 16 b + 1 .. 16 b + 16 (as a bitonic sequence), so the order statistic
+// of rank 16 (b + 1) is the block's MAXIMUM -- one value per lane through three exchanges (lane distance 1, 2, 4) instead
+// of two values through three exchanges and a local step, each with a compare and two selects.  Bit-identical: the
+// maximum of the block is the element the full sort would have put at its end.
+template <int K, int J, int JMIN>
+__device__ __forceinline__ void bitonic_merge_until_x2(double &a0, double &a1, double &b0, double &b1) {
+  bitonic_step<K, J>(a0, a1);
+  bitonic_step<K, J>(b0, b1);
+  if constexpr (J > JMIN) bitonic_merge_until_x2<K, J / 2, JMIN>(a0, a1, b0, b1);
+}
+__device__ __forceinline__ double block16_max(double v0, double v1) {
+  double v = v1 > v0 ? v1 : v0;
+  double p = xor_lane<1>(v); v = p > v ? p : v;
+  p = xor_lane<2>(v); v = p > v ? p : v;
+  p = xor_lane<4>(v); v = p > v ? p : v;
+  return v;
+}
+// value held by lane `l` (uniform over the wave), as a uniform value: v_readlane_b32 x 2, no trip through the LDS crossbar
+__device__ __forceinline__ double read_lane(double v, int l) {
+  const int ul = __builtin_amdgcn_readfirstlane(l);
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), ul), __builtin_amdgcn_readlane(__double2loint(v), ul));
+}
+
 // The quantile function is INCREASING in z when B > 0, k >= 0 and 0 <= c <= 0.83: d/dz of z (1 + c tanh(g z / 2)) (1 + z^2)^k
 // is (1 + z^2)^k [(1 + c t)(1 + 2 k z^2 / (1 + z^2)) + c w sech^2 w] with w = g z / 2, t = tanh w, and
 // tanh a + a sech^2 a <= 1.1997, so the bracket is >= 1 - 1.1997 c > 0 for every g.  Then the order statistics of the
@@ -540,9 +569,8 @@ __device__ __forceinline__ void gk_simulate_wave_ranks(const ModelDesc &m, const
   bitonic_sort128<kGkMaxDraws>(v0, v1);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
-    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
-    const double lo = __shfl(v0, want >> 1, 64), hi = __shfl(v1, want >> 1, 64);
-    const double v = (want & 1) ? hi : lo;
+    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index (uniform)
+    const double v = read_lane((want & 1) ? v1 : v0, want >> 1);
     out[j] = inc ? v : finite_or_big(fabs(v - m.p[2 + S + j]));
   }
 }
@@ -563,13 +591,28 @@ __device__ __forceinline__ void gk_simulate_wave_ranks_x2(const ModelDesc &m, co
   const bool in0 = 2 * lane < n_draws, in1 = 2 * lane + 1 < n_draws;
   a0 = in0 ? a0 : INFINITY; a1 = in1 ? a1 : INFINITY;
   b0 = in0 ? b0 : INFINITY; b1 = in1 ? b1 : INFINITY;
+  bool ranks_are_block_ends = true;                     // uniform: every wanted rank is a multiple of 16
+#pragma unroll
+  for (int j = 0; j < S; ++j) ranks_are_block_ends = ranks_are_block_ends && (((int)m.p[2 + j]) & 15) == 0;
+  if (SABC_GK_BLOCKMAX && ranks_are_block_ends) {
+    static_assert(kGkMaxDraws == 128, "the final merge is the one over 128 elements");
+    bitonic_sort128_x2<kGkMaxDraws / 2>(a0, a1, b0, b1);                    // runs of 64, ascending | descending
+    bitonic_merge_until_x2<kGkMaxDraws, kGkMaxDraws / 2, 16>(a0, a1, b0, b1);   // element distance 64, 32, 16
+    const double ma = block16_max(a0, a1), mb = block16_max(b0, b1);
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int lane_of_block = (((int)m.p[2 + j] >> 4) - 1) * 8;           // rank 16 (b + 1): block b = lanes 8 b .. 8 b + 7
+      const double va = read_lane(ma, lane_of_block), vb = read_lane(mb, lane_of_block);
+      outA[j] = incA ? va : finite_or_big(fabs(va - m.p[2 + S + j]));
+      outB[j] = incB ? vb : finite_or_big(fabs(vb - m.p[2 + S + j]));
+    }
+    return;
+  }
   bitonic_sort128_x2<kGkMaxDraws>(a0, a1, b0, b1);
 #pragma unroll
   for (int j = 0; j < S; ++j) {
-    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index
-    const double alo = __shfl(a0, want >> 1, 64), ahi = __shfl(a1, want >> 1, 64);
-    const double blo = __shfl(b0, want >> 1, 64), bhi = __shfl(b1, want >> 1, 64);
-    const double va = (want & 1) ? ahi : alo, vb = (want & 1) ? bhi : blo;
+    const int want = (int)m.p[2 + j] - 1;               // 1-based order statistic -> sorted index (uniform)
+    const double va = read_lane((want & 1) ? a1 : a0, want >> 1), vb = read_lane((want & 1) ? b1 : b0, want >> 1);
     outA[j] = incA ? va : finite_or_big(fabs(va - m.p[2 + S + j]));
     outB[j] = incB ? vb : finite_or_big(fabs(vb - m.p[2 + S + j]));
   }

@@ -19,7 +19,7 @@ import Dates
 import Base: show
 
 export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
-       DeviceDistance, GaussianIID, Gaussian2D, GandK, LotkaVolterra, comm_unique_id
+       DeviceDistance, GaussianIID, Gaussian2D, GandK, LotkaVolterra, DeviceSource, SourcePrior, comm_unique_id
 
 const libsabc = get(ENV, "SABC_HIP_LIB", joinpath(@__DIR__, "..", "libsabc_hip.so"))
 
@@ -134,6 +134,29 @@ struct HostDistance{F} <: DeviceDistance
     kwargs::NamedTuple
 end
 model_id(::HostDistance) = Int32(0)
+
+# ---- f_dist as HIP source, compiled at run time into the fused update kernel (include/sabc_hip.h:
+#      sabc_register_device_simulator); with a SourcePrior the same source also defines the prior (prior_joint = 3) ----
+struct DeviceSource <: DeviceDistance
+    source::String
+    n_para::Int
+    n_stats::Int
+    params::Vector{Float64}
+end
+DeviceSource(source, n_para, n_stats; params=Float64[]) = DeviceSource(source, n_para, n_stats, collect(Float64, params))
+model_id(::DeviceSource) = Int32(5)
+n_stats(m::DeviceSource) = m.n_stats
+params(m::DeviceSource) = m.params
+"""
+    SourcePrior(d)
+
+ANY prior of `d` parameters next to a `DeviceSource`: its HIP source defines `sabc_user_prior_sample` / `sabc_user_prior_logpdf`
+(include/sabc_hip.h), and rand / logpdf of SimulatedAnnealingABC.jl:174,314,318 run inside the fused kernel.
+"""
+struct SourcePrior <: ContinuousMultivariateDistribution
+    d::Int
+end
+Base.length(p::SourcePrior) = p.d
 n_stats(m::HostDistance) = m.n_stats
 params(::HostDistance) = Float64[]
 
@@ -268,12 +291,14 @@ function comm_unique_id()
 end
 
 function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v, δ, seed, device=0, rank=0, world=1,
-                       comm_id=nothing)
-    host_prior = !is_data_prior(prior)
+                       comm_id=nothing, p2p=true)
+    source_prior = prior isa SourcePrior
+    source_prior && !(f_dist isa DeviceSource) && error("a SourcePrior is device code inside the HIP source of a DeviceSource")
+    host_prior = !source_prior && !is_data_prior(prior)
     host_prior && !(f_dist isa HostDistance) &&
         error("a prior that is not Normal / Uniform / Exponential / LogNormal / Gamma / Beta / truncated(Normal) / a product of those / MvNormal needs a Julia function as f_dist")
-    pd = host_prior ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
-    joint, chol = host_prior ? (Int32(2), Float64[]) : prior_chol(prior)
+    pd = (host_prior || source_prior) ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
+    joint, chol = host_prior ? (Int32(2), Float64[]) : source_prior ? (Int32(3), Float64[]) : prior_chol(prior)
     p = params(f_dist)
     cfg = Ref(CConfig(4, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
@@ -296,6 +321,18 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
             error("world > 1 needs `comm_id`: the 128 bytes of comm_unique_id() from rank 0")
         GC.@preserve comm_id check(h[], ccall((:sabc_comm_init_rccl, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm_id))
         check(h[], ccall((:sabc_comm_selftest, libsabc), Cint, (Ptr{Cvoid},), h[]))
+        # on top of RCCL: the peer-to-peer transport (the shards of one node exchange through each other's HBM: one launch per
+        # population update instead of reduce -> allreduce -> control).  The descriptors travel over the RCCL allgather just
+        # installed; a rank that cannot map a peer or fails the bounded self-test stays on RCCL -- should the ranks then
+        # disagree, the peer-to-peer ranks' first call times out once and sabc_update repeats it over RCCL by itself.
+        if p2p && world <= 8 && !(f_dist isa HostDistance)
+            rc = ccall((:sabc_comm_p2p_init, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], C_NULL)
+            rc == 0 && (rc = ccall((:sabc_comm_p2p_selftest, libsabc), Cint, (Ptr{Cvoid},), h[]))
+            rc == 0 || ccall((:sabc_comm_p2p_disable, libsabc), Cint, (Ptr{Cvoid},), h[])
+        end
+    end
+    if f_dist isa DeviceSource
+        check(h[], ccall((:sabc_register_device_simulator, libsabc), Cint, (Ptr{Cvoid}, Cstring), h[], f_dist.source))
     end
     if f_dist isa HostDistance
         cb = host_callback(f_dist)

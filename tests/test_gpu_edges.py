@@ -111,12 +111,12 @@ def test_beyond_eight_dimensions_in_host_mode(S, O, gpu):
     for alg, prop in (("single_eps", "rw"), ("multi_eps", "de"), ("single_eps", "stretch")):
         hd = S.HostDistance(f_dist, n_stats=s, n_para=d, univariate=False, with_ids=True)
         res = S.sabc(hd, prior, n_particles=n, n_simulation=n * (k + 1), algorithm=alg, proposal=hip_proposal(S, prop, d),
-                     resample=n // 2, seed=SEED)
+                     resample=40, seed=SEED)
         cfg = O.make_config(n_particles=n, n_para=d, n_stats=s, model_id=O.MODEL_HOST, model_params=[], prior=opri, seed=SEED,
                             algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS, host_fn=O.host_simulator(f_dist, d, s))
         run = O.OracleRun(cfg)
         run.initialize(n * (k + 1))
-        run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=n // 2))
+        run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=40))
         assert res.population.shape == (n, d) and res.u.shape == (n, s) and len(res.state.ϵ) == (s if alg == "multi_eps" else 1)
         assert res.state.n_accept == run.counters["n_accept"] and res.state.n_resampling == run.counters["n_resampling"] >= 2
         tol = {"rw": 1e-8, "stretch": 1e-6, "de": 1e-5}[prop]
