@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -124,9 +125,12 @@ RcclApi *rccl_api() {
 class RcclCollectives : public Collectives {
  public:
   RcclCollectives(HipBackend *be, void *comm, int world) : be_(be), comm_(comm), world_(world) {}
+  // (the grouped send / recv exchange has not run between two GPUs yet: SABC_RCCL_ALLTOALLV=0 keeps the sharded resample
+  // on the allgather of the whole population, which needs nothing but ncclAllGather)
   bool has_alltoallv() const override {
+    static const bool allowed = [] { const char *e = std::getenv("SABC_RCCL_ALLTOALLV"); return !(e && e[0] == '0'); }();
     RcclApi *a = rccl_api();
-    return a && a->Send && a->Recv && a->GroupStart && a->GroupEnd;
+    return allowed && a && a->Send && a->Recv && a->GroupStart && a->GroupEnd;
   }
   // grouped ncclSend / ncclRecv, one pair per peer with a non-empty segment (ncclFloat64 = 8)
   int alltoallv(const double *send, const int64_t *sc, double *recv, const int64_t *rc) override {

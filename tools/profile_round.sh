@@ -13,13 +13,13 @@ cd /tmp
 for cfg in cfg2 cfg3 cfg4 cfg5; do
   steps=30; [ $cfg = cfg2 ] && steps=50
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_${tag}_$cfg" -- \
-    python3 "$root/bench.py" --config $cfg --steps $steps --warmup 5 --no-cpu-baseline --repeats 1 --repeats 1 \
+    python3 "$root/bench.py" --config $cfg --steps $steps --warmup 5 --no-cpu-baseline --repeats 1 \
     > "$out/prof_${tag}_$cfg.json" 2> "$out/prof_${tag}_$cfg.err"
   echo "profiled $cfg"
 done
 for pmc in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d "$out/pmc_${tag}_$pmc" -- \
-    python3 "$root/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --repeats 1 --repeats 1 \
+    python3 "$root/bench.py" --steps 50 --warmup 5 --no-cpu-baseline --repeats 1 \
     > "$out/pmc_${tag}_$pmc.json" 2> "$out/pmc_${tag}_$pmc.err"
   echo "counted $pmc"
 done
