@@ -33,13 +33,13 @@ def _env():
 
 def test_launcher_without_a_device_exits_cleanly():
     """No GPU here: every rank refuses (the engine has no CPU path); the launcher reports it and exits non-zero."""
+    import torch
+    if torch.cuda.is_available():            # (checked first: with a GPU the command below would be a full two-rank bench)
+        pytest.skip("a GPU is visible: covered by test_launcher_two_ranks_on_one_gpu")
     marker = "31337"
     t0 = time.time()
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0",
                         "--cpu-updates", marker], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    import torch
-    if torch.cuda.is_available():
-        pytest.skip("a GPU is visible: covered by test_launcher_two_ranks_on_one_gpu")
     assert r.returncode not in (0, 124), (r.returncode, r.stderr[-2000:])
     assert "needs an MI355X" in r.stderr
     assert not r.stdout.strip().startswith("{")
@@ -80,3 +80,20 @@ def test_launcher_two_ranks_on_one_gpu(gpu):
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0
     assert out["config"]["collectives"] == "hooks-gloo"
     assert out["comm_bytes_per_step"] >= 5 * 8
+
+
+@pytest.mark.gpu
+def test_launcher_two_ranks_peer_to_peer(gpu):
+    """The same with the peer-to-peer transport on top of the gloo hooks (two processes mapping each other's memory with
+    hipIpc): the line says so, counts no collective call in the timed region and one reduce-exchange-control launch per update."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--p2p", "on", "--steps", "6", "--warmup", "2",
+                        "--n-particles", "200000", "--no-cpu-baseline", "--repeats", "2"], env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["repeats"] == 2 and out["value_min"] <= out["value"] <= out["value_max"]
+    assert out["config"]["collectives"] == "p2p" and out["config"]["collectives_fallback"] == "hooks-gloo"
+    assert out["collective_calls_per_update"] == 0 and not out["transport_degraded"]
+    ex = out["exchange"]
+    assert ex["collective_calls_per_update"] == 0 and ex["reduce_control_launches"] >= 10 and ex["collectives_timed"] == 0
+    assert 2.0 <= ex["launches_per_update"] <= 4.0            # k_update + ONE reduce-exchange-control launch (+ a resample's share)

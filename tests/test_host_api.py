@@ -123,3 +123,14 @@ def test_bench_refuses_to_run_without_a_device():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+def test_star_import_exposes_the_public_names():
+    """`from sabc_amd import *` (`from_scipy` was listed in __all__ but never imported)."""
+    ns = {}
+    exec("from sabc_amd import *", ns)
+    import sabc_amd
+    for name in sabc_amd.__all__:
+        assert name in ns, name
+    for name in ("sabc", "update_population_", "from_scipy", "SourcePrior", "HostPrior", "DeviceSource", "RandomWalk"):
+        assert callable(ns[name])
