@@ -918,6 +918,14 @@ int HipBackend::p2p_init(const P2PDesc *all) {
       peer_rho_[r] = (double *)(uintptr_t)d.ptr_rho;
       continue;
     }
+    if (d.device != device_) {                          // another GPU of the node: kernels here must be able to reach it
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device_, d.device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        err_ = "no peer access between the devices of two shards (is the peer on this node?)";
+        return -1;
+      }
+    }
     const unsigned char *from[4] = {d.ipc_slots, d.ipc_pop[0], d.ipc_pop[1], d.ipc_rho};
     void *got[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i) {

@@ -134,3 +134,13 @@ def test_star_import_exposes_the_public_names():
         assert name in ns, name
     for name in ("sabc", "update_population_", "from_scipy", "SourcePrior", "HostPrior", "DeviceSource", "RandomWalk"):
         assert callable(ns[name])
+
+
+def test_p2p_descriptor_size_matches_the_header():
+    import re
+    import sabc_amd
+    hdr = open(sabc_amd._lib.HEADER).read()
+    assert int(re.search(r"#define SABC_P2P_DESC_BYTES (\d+)", hdr).group(1)) == sabc_amd._lib.P2P_DESC_BYTES
+    assert int(re.search(r"#define SABC_P2P_MAX_WORLD (\d+)", hdr).group(1)) == sabc_amd._lib.P2P_MAX_WORLD
+    assert int(re.search(r"#define SABC_MAX_PARA (\d+)", hdr).group(1)) == sabc_amd._lib.MAX_PARA
+    assert int(re.search(r"#define SABC_MAX_JOINT_PARA (\d+)", hdr).group(1)) == sabc_amd._lib.MAX_JOINT_PARA

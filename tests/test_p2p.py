@@ -206,3 +206,31 @@ def test_p2p_failed_call_is_finished_over_the_collectives_underneath(S, gpu, tmp
     np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
     np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)
     np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=tol)
+
+
+@pytest.mark.parametrize("prop,n", [("rw", 9001), ("de", 6000)])
+def test_p2p_three_shards_in_one_process(S, gpu, tmp_path, prop, n):
+    """Three shards (an odd world: rank-order sums over three rows, lanes 0..2 of the barrier and status kernels, a ragged
+    last shard) in one process, nothing but the peer-to-peer transport."""
+    k, case = 10, "gauss2_2stats"
+    out = run_shards_in_one_process(S, case, "multi_eps", prop, n, k, resample=n // 4, world=3)
+    ref = launch(3, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="multi_eps", prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    check_against_cpu_engine(out, ref, prop)
+    assert out[0]["counters"]["n_resampling"] >= 2 and all(o["collective_calls"] == 0 for o in out)
+
+
+@pytest.mark.parametrize("prop", ["rw", "stretch"])
+def test_p2p_four_processes_over_hip_ipc(S, gpu, tmp_path, prop):
+    """Four processes sharing the one MI355X, every one mapping the other three (12 slot areas, 24 population buffers
+    opened with hipIpcOpenMemHandle): the geometry of half a node."""
+    case, n, k = "gauss2d_cfg3", 12_002, 8
+    got = launch(4, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg="single_eps", prop=prop, n=n, updates=k,
+                 resample=n // 4, p2p=1)
+    assert str(got["transport"]) == "p2p" and int(got["collective_calls"]) == 0 and int(got["p2p_fallbacks"]) == 0
+    ref = launch(4, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    tol = TOL[prop]
+    assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)

@@ -13,6 +13,8 @@ for step in "$@"; do
     hosttests) timeout -k 10 600 python -m pytest tests/test_gpu_host_fdist.py tests/test_host_prior.py -q -m gpu -x > gpurun_out/r03_hosttests.log 2>&1; echo "hosttests rc=$?"; tail -5 gpurun_out/r03_hosttests.log ;;
     benchhost) timeout -k 10 300 python bench.py --config host > gpurun_out/r03_bench_host.json 2> gpurun_out/r03_bench_host.err; echo "benchhost rc=$?"; tail -3 gpurun_out/r03_bench_host.err ;;
     rtc) timeout -k 10 900 python -m pytest tests/test_user_simulator.py -q -m gpu -x > gpurun_out/r03_rtc.log 2>&1; echo "rtc rc=$?"; tail -15 gpurun_out/r03_rtc.log ;;
+    benchdriver) timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench_driver.json 2> gpurun_out/r03_bench_driver.err; echo "benchdriver rc=$?" ;;
+    smoke) timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/r03_smoke.log ;;
     gpu) timeout -k 10 1100 python -m pytest tests -q -m gpu -x > gpurun_out/r03_gpu_tests.log 2>&1; echo "gpu rc=$?"; tail -5 gpurun_out/r03_gpu_tests.log ;;
   esac
 done
