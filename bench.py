@@ -507,8 +507,10 @@ def main():
                     "n_accept_equal": same["n_accept"] == c["n_accept"], "updates": same["updates"],
                     "note": "same seed, same calls on the CPU restatement (oracle); the north star asks for moments within 1 %"}
         print(json.dumps(out), flush=True)
+    barrier()                         # handles that map each other's memory are torn down together
     h.close()
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 

@@ -213,7 +213,7 @@ SABC_API int         sabc_comm_selftest(sabc_handle *h);
    raw pointers for shards living in the same process); the descriptors of all shards, in rank order, go to
    sabc_comm_p2p_init -- exchanged by the caller, or (all_descs == NULL) by the library over the collectives already
    installed (sabc_set_collectives / sabc_comm_init_rccl), which also stay as the fallback transport.
-   Every wait is bounded (sabc_comm_p2p_set_timeout, default 2000 ms).  A shard that gives up fails the call on EVERY shard
+   Every wait is bounded (sabc_comm_p2p_set_timeout, default 5000 ms).  A shard that gives up fails the call on EVERY shard
    (the end-of-call status exchange) and switches the handle back to the collectives underneath; with such collectives
    installed sabc_update then puts the particles back and repeats the call over them (sabc_comm_p2p_fallbacks counts),
    without them it returns SABC_ERR_COMM per its error contract. */

@@ -125,10 +125,11 @@ RcclApi *rccl_api() {
 class RcclCollectives : public Collectives {
  public:
   RcclCollectives(HipBackend *be, void *comm, int world) : be_(be), comm_(comm), world_(world) {}
-  // (the grouped send / recv exchange has not run between two GPUs yet: SABC_RCCL_ALLTOALLV=0 keeps the sharded resample
-  // on the allgather of the whole population, which needs nothing but ncclAllGather)
+  // The grouped send / recv exchange has not run between two GPUs yet (every box so far had one): it is OFF unless
+  // SABC_RCCL_ALLTOALLV=1, and the sharded resample on this transport allgathers the whole population -- more bytes, but
+  // nothing beyond ncclAllGather.  (Inside a node the peer-to-peer transport carries the resample anyway.)
   bool has_alltoallv() const override {
-    static const bool allowed = [] { const char *e = std::getenv("SABC_RCCL_ALLTOALLV"); return !(e && e[0] == '0'); }();
+    static const bool allowed = [] { const char *e = std::getenv("SABC_RCCL_ALLTOALLV"); return e && e[0] == '1'; }();
     RcclApi *a = rccl_api();
     return allowed && a && a->Send && a->Recv && a->GroupStart && a->GroupEnd;
   }

@@ -421,8 +421,17 @@ int Engine::initialize(int64_t n_simulation) {
                   (long long)sh_.n_global);
     return fail(SABC_ERR_NSIM_TOO_SMALL, buf);
   }
-  const int rc = initialize_body();
+  const bool can_retry = p2p() && coll_->usable();
+  int rc = initialize_body();
   if (rc) { const std::string why = err_; p2p_abort(); err_ = why; }
+  if (rc == SABC_ERR_COMM && can_retry && !p2p()) {
+    // a peer-to-peer wait gave up (on every shard: the status exchange sees to that): initialization starts from nothing,
+    // so it is simply run again over the collectives underneath
+    const std::string why = err_;
+    p2p_fallbacks_ += 1;
+    rc = initialize_body();
+    if (rc) err_ = "after falling back from the peer-to-peer transport (" + why + "): " + err_;
+  }
   be_->end_of_call();
   return rc;
 }
@@ -430,7 +439,7 @@ int Engine::initialize(int64_t n_simulation) {
 int Engine::initialize_body() {
   const int s = m_.s;
   for (int k = 0; k < kMaxPara; ++k) cb_.pivot[k] = 0.0;
-  cb_.n_accept = 0; cb_.hist_rows = 0; cb_.error = 0; cb_.eps_len = eps_len_;
+  cb_.n_accept = 0; cb_.hist_rows = 0; cb_.error = 0; cb_.halt = 0; cb_.eps_len = eps_len_;
   hist_capacity_ = 4;
   if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
   if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");

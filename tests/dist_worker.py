@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--alltoallv", type=int, default=1, help="0: no personalised exchange (the resample allgathers the population)")
     ap.add_argument("--p2p", type=int, default=0, help="1: the peer-to-peer transport on top of the collectives (hip engine only)")
     ap.add_argument("--silence", type=int, default=0, help="p2p test hook: rank 1 lets this many posts go out, then skips one")
+    ap.add_argument("--silence-init", type=int, default=0, help="the same inside sabc_initialize")
     ap.add_argument("--p2p-timeout-ms", type=float, default=0.0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -65,6 +66,8 @@ def main():
     calls0 = h.collective_calls if a.engine == "hip" else 0       # (the self-test of the base transport used some)
     if a.p2p_timeout_ms > 0 and transport == "p2p":
         h.p2p_set_timeout(a.p2p_timeout_ms)
+    if a.silence_init and rank == 1 and transport == "p2p":
+        h.p2p_inject_silence(-a.silence_init)
     h.initialize((a.updates + 1) * a.n)
     bytes_init = h.comm_bytes
     if a.silence and rank == 1 and transport == "p2p":

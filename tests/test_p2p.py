@@ -134,6 +134,9 @@ def test_p2p_two_shards_in_one_process(S, gpu, tmp_path, case, alg, prop, n):
     check_against_cpu_engine(out, ref, prop)
     assert out[0]["counters"]["n_resampling"] >= 3
     assert all(o["collective_calls"] == 0 for o in out)              # nothing went through a collective
+    # the host waits once per update (a mailbox poll, no stream sync) and once at the end of the call: the sharded
+    # resample adds NO host round trip on this transport (two per resample over the collectives)
+    assert all(o["syncs"] == k + 1 for o in out), [o["syncs"] for o in out]
     # launches per population update: k_update (x2 + a barrier for DE / Stretch) + ONE reduce-exchange-control launch;
     # each resample adds weights + barrier + 3 scan passes + gather + stats and its own exchange launch
     per_update = 2 if prop == "rw" else 4
@@ -186,6 +189,20 @@ def test_p2p_a_silent_shard_fails_the_call_within_the_bound(S, gpu, tmp_path, pr
                  updates=2 * k, resample=n // 4)
     # two calls of k updates == one call of 2k updates on the CPU engine (the repeated call included)
     check_against_cpu_engine(out, ref, prop)
+
+
+def test_p2p_failed_initialization_is_repeated_over_the_collectives_underneath(S, gpu, tmp_path):
+    """The same inside sabc_initialize (rank 1 skips its third post: the exchange after the ECDF build): initialization starts
+    from nothing, so it is run again over the hooks, and the updates that follow stay on them."""
+    case, n, k = "gauss1_cfg2", 8000, 6
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg="single_eps", prop="rw", n=n, updates=k,
+                 resample=n // 4, p2p=1, **{"silence-init": 2, "p2p-timeout-ms": 300})
+    assert str(got["transport"]) == "p2p" and int(got["p2p_fallbacks"]) == 1 and not bool(got["p2p_active_at_end"])
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop="rw", n=n, updates=k,
+                 resample=n // 4)
+    assert list(got["counters"]) == list(ref["counters"])
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("prop", ["rw", "de"])
