@@ -195,12 +195,14 @@ int Engine::p2p_commit_ok() {
 }
 // ... and after a failure: tell the peers (no wait) and go back to the installed Collectives -- the wrapper restores the
 // particles and repeats the call over them.
-void Engine::p2p_abort() {
+void Engine::p2p_abort(int rc) {
   if (!p2p()) return;
   (void)be_->p2p_commit(1, false);
   ControlBlock scratch;
   (void)be_->read_control(&scratch);      // the post has left before the call returns (a later set-up wipes the slots)
-  be_->p2p_disable();
+  // an error of the algorithm (zero mean u, a covariance that is not positive definite, a failing callback) is the same
+  // on every shard and says nothing about the transport: only a wait that gave up switches it off
+  if (rc == SABC_ERR_COMM || rc == SABC_ERR_HIP) be_->p2p_disable();
 }
 
 int Engine::stats_reduce() {
@@ -423,7 +425,7 @@ int Engine::initialize(int64_t n_simulation) {
   }
   const bool can_retry = p2p() && coll_->usable();
   int rc = initialize_body();
-  if (rc) { const std::string why = err_; p2p_abort(); err_ = why; }
+  if (rc) { const std::string why = err_; p2p_abort(rc); err_ = why; }
   if (rc == SABC_ERR_COMM && can_retry && !p2p()) {
     // a peer-to-peer wait gave up (on every shard: the status exchange sees to that): initialization starts from nothing,
     // so it is simply run again over the collectives underneath
@@ -585,7 +587,7 @@ int Engine::update_once(const sabc_update_args &a) {
     eps_hist_.resize(hist_at_entry[0]); u_hist_.resize(hist_at_entry[1]); rho_hist_.resize(hist_at_entry[2]);
     (void)be_->write_control(cb_);
     initialized_ = false;
-    p2p_abort();
+    p2p_abort(rc);
     err_ = why;
   }
   return rc;

@@ -203,7 +203,7 @@ class Engine {
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
   int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0;
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
-  void p2p_abort();                                 // ... and after a failure
+  void p2p_abort(int rc);                           // ... and after a failure (rc: what the call returns)
   int initialize_body();
   std::vector<double> eps_hist_, u_hist_, rho_hist_;
 };
