@@ -839,9 +839,7 @@ P2PView HipBackend::p2p_view() const {
   for (int r = 0; r < kMaxPeers; ++r) v.slots[r] = peer_slots_[r];
   v.rank = sh_.rank;
   v.world = sh_.world;
-  int khz = 0;
-  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz
-  v.timeout_ticks = (uint64_t)(p2p_timeout_ms_ * (double)khz);
+  v.timeout_ticks = (uint64_t)(p2p_timeout_ms_ * (double)wall_clock_khz_);
   return v;
 }
 
@@ -895,6 +893,9 @@ int HipBackend::p2p_init(const P2PDesc *all) {
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
   const int W = sh_.world;
   p2p_on_ = false;
+  int khz = 0;                                          // rate of the constant wall clock the waits are bounded by
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) == hipSuccess && khz > 0) wall_clock_khz_ = khz;
+  else (void)hipGetLastError();
   for (int r = 0; r < W; ++r) {
     const P2PDesc &d = all[r];
     if (d.magic != kP2PMagic || d.rank != r || d.world != W || d.cap != sh_.cap || d.n_global != sh_.n_global || d.d != m_.d || d.s != m_.s) {

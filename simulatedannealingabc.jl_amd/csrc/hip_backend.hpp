@@ -188,6 +188,7 @@ class HipBackend : public Backend {
   bool p2p_on_ = false, pending_xchg_ = false;
   uint32_t xseq_ = 0, bseq_ = 0, call_ = 0;               // exchange / barrier / call sequence numbers (the same on every shard)
   double p2p_timeout_ms_ = 5000.0;
+  int wall_clock_khz_ = 100000;                           // s_memrealtime: 100 MHz unless the device says otherwise
   int p2p_silent_ = 0, p2p_skip_ = 0;
   double *p2p_test_dev_ = nullptr;
   double *snap_pop_ = nullptr, *snap_rho_ = nullptr;     // device-side copy of the particles at the entry of a call
