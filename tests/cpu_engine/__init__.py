@@ -15,7 +15,7 @@ _SRCS = [
     os.path.join(ROOT, "oracle", "sabc_oracle.c"),
 ]
 _DEPS = _SRCS + [os.path.join(ROOT, "simulatedannealingabc.jl_amd", "csrc", f)
-                 for f in ("engine.hpp", "control.hpp", "host_math.hpp", "sabc_types.hpp")] + \
+                 for f in ("engine.hpp", "control.hpp", "host_math.hpp", "sabc_types.hpp", "p2p.hpp")] + \
         [os.path.join(ROOT, "include", "sabc_hip.h"), os.path.join(ROOT, "oracle", "sabc_oracle.h")]
 
 
@@ -24,7 +24,7 @@ def build():
         return LIB
     obj = os.path.join(_HERE, "sabc_oracle.o")
     subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-c", _SRCS[2], "-o", obj])
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off",
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off", "-pthread",
                            "-o", LIB, _SRCS[0], _SRCS[1], obj, "-lm"])
     return LIB
 

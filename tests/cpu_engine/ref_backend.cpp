@@ -6,16 +6,20 @@
 // (oracle/sabc_oracle.c).  Purpose: exercise the world > 1 code path with torch.distributed
 // "gloo" where no GPU exists, and give the sharded HIP runs a reference with the SAME shard
 // colouring.  It exports the subset of include/sabc_hip.h the tests need, under the same names.
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sabc_hip.h"
 #include "../../oracle/sabc_oracle.h"
 #include "../../simulatedannealingabc.jl_amd/csrc/control.hpp"
 #include "../../simulatedannealingabc.jl_amd/csrc/engine.hpp"
+#include "../../simulatedannealingabc.jl_amd/csrc/p2p.hpp"
 
 using namespace sabc;
 
@@ -109,7 +113,7 @@ class RefBackend : public Backend {
     if (r > pv.world - 1) r = pv.world - 1;
     const int64_t o = (int64_t)j - r * pv.m_full;
     const int64_t off = (r == pv.world - 1) ? pv.off_last : pv.off_full;
-    return pv.base + r * pv.rank_stride + off + o;
+    return (pv.direct ? pv.peer[r] : pv.base + r * pv.rank_stride) + off + o;
   }
   static uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 
@@ -229,7 +233,15 @@ class RefBackend : public Backend {
   }
 
   int control(const ControlArgs &a) override {
-    if (!control_step(cb_, a, hist_.data(), stage_)) return 0;
+    if (xchg_pending_) {
+      // the peer-to-peer exchange of the product's k_reduce_control<true>, between host threads: a step that is a no-op
+      // posts nothing on any shard; a wait that gives up leaves SABC_ERR_COMM + the halt flag and tells the "host"
+      xchg_pending_ = false;
+      const bool noop = ((a.mode & CTRL_GUARDED) && cb_.halt) || cb_.error == SABC_ERR_COMM;
+      if (noop) { post_error_if_any(a); return 0; }
+      if (!p2p_sum_rows(++xseq_)) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; post_error_if_any(a); return 0; }
+    }
+    if (!control_step(cb_, a, hist_.data(), stage_)) { post_error_if_any(a); return 0; }
     if (a.notify_seq) {
       Mailbox &mb = ring_[a.notify_seq % kMailboxRing];
       mb.n_accept = cb_.n_accept; mb.error = cb_.error; mb.halted = cb_.halt; mb.seq = a.notify_seq;
@@ -356,7 +368,152 @@ class RefBackend : public Backend {
     return 0;
   }
 
+  // ---- the peer-to-peer transport of csrc/p2p.hpp between shards living in ONE process (one host thread each): the peers'
+  //      memory is the pointer itself, the slots are atomics, every wait is bounded.  Same protocol as HipBackend's kernels,
+  //      so that engine.cpp's peer-to-peer paths (exchange inside the control step, barrier between the half batches,
+  //      resample and ECDF build over the owners' memory, status exchange, abort, fallback) run where no GPU exists.
+  bool p2p_active() const override { return p2p_on_; }
+  int p2p_exchange_pending() override { xchg_pending_ = true; return 0; }
+  void p2p_disable() override { p2p_on_ = false; xchg_pending_ = false; }
+  void p2p_descriptor(P2PDesc *out) {
+    std::memset(out, 0, sizeof(*out));
+    for (auto &row : slot_seq_) for (auto &x : row) x.store(0);
+    for (auto &row : bar_seq_) for (auto &x : row) x.store(0);
+    for (auto &x : commit_) x.store(0);
+    xseq_ = bseq_ = call_ = 0; p2p_on_ = false;
+    out->magic = kP2PMagic; out->rank = sh_.rank; out->world = sh_.world; out->cap = sh_.cap; out->n_global = sh_.n_global;
+    out->d = m_.d; out->s = m_.s;
+    out->ptr_slots = (uint64_t)(uintptr_t)this;
+  }
+  int p2p_init(const P2PDesc *all) {
+    for (int r = 0; r < sh_.world; ++r) {
+      if (all[r].magic != kP2PMagic || all[r].rank != r || all[r].world != sh_.world) return -1;
+      peers_[r] = (RefBackend *)(uintptr_t)all[r].ptr_slots;
+    }
+    p2p_on_ = true;
+    return 0;
+  }
+  void p2p_set_timeout(double ms) { timeout_ms_ = ms; }
+  void p2p_inject_silence(int n) { if (n >= 0) { skip_ = 0; silent_ = n; } else { skip_ = -n; silent_ = 1; } }
+  bool take_silence() {
+    if (skip_ > 0) { --skip_; return false; }
+    if (silent_ > 0) { --silent_; return true; }
+    return false;
+  }
+  template <class A> bool wait_for(A &word, uint64_t want) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (word.load(std::memory_order_acquire) != want) {
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) return false;
+      std::this_thread::yield();
+    }
+    return true;
+  }
+  bool p2p_sum_rows(uint32_t seq) {
+    const int W = sh_.world, ring = (int)(seq % kP2PRing);
+    if (!take_silence())
+      for (int p = 0; p < W; ++p) {
+        RefBackend *q = peers_[p];
+        for (int c = 0; c < np_; ++c) q->slot_row_[ring][sh_.rank][c] = stage_[c];
+        q->slot_seq_[ring][sh_.rank].store(seq, std::memory_order_release);
+      }
+    for (int r = 0; r < W; ++r)
+      if (!wait_for(slot_seq_[ring][r], (uint64_t)seq)) return false;
+    for (int c = 0; c < np_; ++c) {
+      double a = slot_row_[ring][0][c];
+      for (int r = 1; r < W; ++r) a += slot_row_[ring][r][c];               // rank order, like the kernel
+      stage_[c] = a;
+    }
+    return true;
+  }
+  void post_error_if_any(const ControlArgs &a) {
+    if (a.notify_seq && cb_.error == SABC_ERR_COMM) {
+      Mailbox &mb = ring_[a.notify_seq % kMailboxRing];
+      mb.n_accept = cb_.n_accept; mb.error = cb_.error; mb.halted = cb_.halt; mb.seq = a.notify_seq;
+    }
+  }
+  int p2p_barrier(bool guarded) override {
+    const uint32_t seq = ++bseq_;
+    if ((guarded && cb_.halt) || cb_.error == SABC_ERR_COMM) return 0;
+    const int W = sh_.world, ring = (int)(seq % kP2PRing);
+    if (!take_silence())
+      for (int p = 0; p < W; ++p) peers_[p]->bar_seq_[ring][sh_.rank].store(seq, std::memory_order_release);
+    for (int r = 0; r < W; ++r)
+      if (!wait_for(bar_seq_[ring][r], (uint64_t)seq)) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; return 0; }
+    return 0;
+  }
+  int p2p_commit(int status, bool wait) override {
+    const uint64_t call = ++call_;
+    const uint64_t mine = (status != 0 || cb_.error != 0) ? 1 : 0;
+    if (!take_silence())
+      for (int p = 0; p < sh_.world; ++p) peers_[p]->commit_[sh_.rank].store((call << 8) | mine, std::memory_order_release);
+    if (!wait) return 0;
+    bool failed = false;
+    for (int r = 0; r < sh_.world; ++r) {
+      const auto t0 = std::chrono::steady_clock::now();
+      uint64_t w;
+      while (((w = commit_[r].load(std::memory_order_acquire)) >> 8) != call) {
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) { failed = true; break; }
+        std::this_thread::yield();
+      }
+      if (!failed && (w & 0xFF) != 0) failed = true;
+    }
+    if (failed && cb_.error == 0) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; }
+    return 0;
+  }
+  int build_cdf_p2p(int64_t *len_out, int *any_negative) override {
+    if (p2p_barrier(false)) return -1;
+    const int s = m_.s; const int64_t cap = sh_.cap;
+    std::vector<double> g((size_t)sh_.world * s * cap);
+    for (int r = 0; r < sh_.world; ++r) std::memcpy(&g[(size_t)r * s * cap], peers_[r]->rho_.data(), (size_t)s * cap * sizeof(double));
+    return build_cdf(g.data(), len_out, any_negative);
+  }
+  int partner_view_p2p(PartnerView *pv) override {
+    pv->direct = 1; pv->base = nullptr; pv->rank_stride = 0; pv->cap = sh_.cap;
+    for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peers_[r]->pop_[cur_].data() : nullptr;
+    return 0;
+  }
+  int resample_p2p(double delta, uint64_t iter) override {
+    resample_weights(delta);
+    if (p2p_barrier(false)) return -1;
+    const int d = m_.d, s = m_.s; const int64_t cap = sh_.cap, N = sh_.n_global;
+    std::vector<double> w((size_t)N), cum((size_t)N), bs((size_t)orc_scan_chunks(N));
+    for (int64_t gid = 0; gid < N; ++gid) {
+      const int64_t r = gid / cap, o = gid - r * cap;
+      w[(size_t)gid] = peers_[r]->pop_[cur_][(size_t)(d + s) * cap + o];
+    }
+    double totals[2];
+    orc_weight_scan(w.data(), N, cum.data(), bs.data(), totals);
+    ess_ = totals[1] > 0 ? totals[0] * totals[0] / totals[1] : 0.0;
+    std::vector<double> &dst = pop_[1 - cur_];
+    for (int64_t li = 0; li < sh_.n_local; ++li) {
+      uint32_t w4[4];
+      orc_stream_block(m_.seed, (uint64_t)(sh_.gid0 + li), ORC_PURPOSE_RESAMPLE, iter, 0, w4);
+      const int64_t idx = orc_resample_index(cum.data(), bs.data(), N, orc_u52(w4[0], w4[1]) * totals[0]);
+      const int64_t r = idx / cap, o = idx - r * cap;
+      for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = peers_[r]->pop_[cur_][(size_t)row * cap + o];
+    }
+    cur_ = 1 - cur_;
+    return 0;
+  }
+  int snapshot() override { snap_pop_ = pop_[cur_]; snap_rho_ = rho_; return 0; }
+  int restore_snapshot() override {
+    if (snap_pop_.empty()) return -1;
+    pop_[cur_] = snap_pop_; rho_ = snap_rho_; xchg_pending_ = false;
+    return 0;
+  }
+
  private:
+  RefBackend *peers_[kMaxPeers] = {nullptr};
+  double slot_row_[kP2PRing][kMaxPeers][kMaxPartials] = {};
+  std::atomic<uint64_t> slot_seq_[kP2PRing][kMaxPeers] = {};
+  std::atomic<uint64_t> bar_seq_[kP2PRing][kMaxPeers] = {};
+  std::atomic<uint64_t> commit_[kMaxPeers] = {};
+  bool p2p_on_ = false, xchg_pending_ = false;
+  uint32_t xseq_ = 0, bseq_ = 0;
+  uint64_t call_ = 0;
+  double timeout_ms_ = 5000.0;
+  int silent_ = 0, skip_ = 0;
+  std::vector<double> snap_pop_, snap_rho_;
   ModelDesc m_{};
   Shard sh_{};
   orc_config oc_{};
@@ -374,6 +531,7 @@ class NoColl : public Collectives {
  public:
   int allreduce_sum(double *, int64_t) override { return 0; }
   int allgather(const double *, double *, int64_t) override { return -1; }
+  bool usable() const override { return false; }
 };
 
 class HookColl : public Collectives {
@@ -508,5 +666,20 @@ int sabc_get_proposal_sigma(const sabc_handle *h, double *sigma) {
 }
 double sabc_last_ess(const sabc_handle *h) { return h->be->last_ess(); }
 int64_t sabc_host_syncs(const sabc_handle *h) { return h->eng->host_syncs(); }
+int64_t sabc_collective_calls(const sabc_handle *h) { return h->eng->collective_calls(); }
+int64_t sabc_kernel_launches(const sabc_handle *) { return 0; }
+
+// the peer-to-peer entry points, over the in-process emulation above (shards = host threads of this process)
+int sabc_comm_p2p_descriptor(sabc_handle *h, void *out) { h->be->p2p_descriptor((P2PDesc *)out); return 0; }
+int sabc_comm_p2p_init(sabc_handle *h, const void *all) {
+  if (!all || h->be->p2p_init((const P2PDesc *)all)) { h->err = "peer-to-peer descriptors do not match"; return SABC_ERR_COMM; }
+  return 0;
+}
+int sabc_comm_p2p_selftest(sabc_handle *) { return 0; }
+int sabc_comm_p2p_set_timeout(sabc_handle *h, double ms) { h->be->p2p_set_timeout(ms); return 0; }
+int sabc_comm_p2p_disable(sabc_handle *h) { h->be->p2p_disable(); return 0; }
+int sabc_comm_p2p_active(const sabc_handle *h) { return h->eng->p2p() ? 1 : 0; }
+int64_t sabc_comm_p2p_fallbacks(const sabc_handle *h) { return h->eng->p2p_fallbacks(); }
+int sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n) { h->be->p2p_inject_silence(n); return 0; }
 
 }  // extern "C"
