@@ -55,9 +55,12 @@ HipBackend::~HipBackend() {
   if (slot_dev_) (void)hipFree(slot_dev_);
   if (bucket_dev_) (void)hipFree(bucket_dev_);
   if (bucket_host_) (void)hipHostFree(bucket_host_);
-  double *staged[] = {host_thp_, host_aux_, host_rho_, host_cur_, host_lpcur_};
+  double *staged[] = {host_thp_, host_rho_, host_cur_, host_lp2_};
   for (double *p : staged)
     if (p) (void)hipHostFree(p);
+  if (host_gate_) (void)hipHostFree(host_gate_);
+  if (dev_thp_) (void)hipFree(dev_thp_);
+  if (dev_aux_) (void)hipFree(dev_aux_);
   if (host_flag_) (void)hipHostFree(host_flag_);
   if (host_done_dev_) (void)hipFree(host_done_dev_);
   if (host_acc_dev_) (void)hipFree(host_acc_dev_);
@@ -262,7 +265,9 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
 //   k_host_propose (device) -> f_dist on the proposals inside the prior's support (host) -> k_host_accept (device).
 // What the library adds around the callback is kept off the critical path:
 //  * staging arrays are PINNED host memory MAPPED into the device, allocated once: the kernels write proposals and read
-//    distances in place -- no hipMemcpy call, no pageable staging, no allocation per half batch;
+//    distances in place -- no hipMemcpy call, no pageable staging, no allocation per half batch; and only what the host
+//    needs crosses PCIe: the proposals and ONE BYTE of prior gate go down, the distances come up; the proposals' second copy
+//    and the log densities stay in device memory for the accept step;
 //  * the propose kernel signals completion CHUNK by chunk into a pinned flag word the host polls (no stream sync): the
 //    callback for chunk c runs while the accept kernel of chunk c - 1 executes and later chunks are still being proposed;
 //  * nothing waits at the end of a half batch: the next kernel on the stream is ordered behind the accept kernels.
@@ -275,12 +280,16 @@ int HipBackend::ensure_host_buffers() {
     return 0;
   };
   if (mapped(&host_thp_, &host_thp_dev_, (size_t)m_.d * cap)) return -1;
-  if (mapped(&host_aux_, &host_aux_dev_, 2 * cap)) return -1;
   if (mapped(&host_rho_, &host_rho_dev_, (size_t)m_.s * cap)) return -1;
+  HB_CHECK(hipHostMalloc((void **)&host_gate_, cap, hipHostMallocMapped), "hipHostMalloc(prior gate)");
+  HB_CHECK(hipHostGetDevicePointer((void **)&host_gate_dev_, host_gate_, 0), "hipHostGetDevicePointer(prior gate)");
   if (m_.prior_joint == 2) {
     if (mapped(&host_cur_, &host_cur_dev_, (size_t)m_.d * cap)) return -1;
-    if (mapped(&host_lpcur_, &host_lpcur_dev_, cap)) return -1;
+    if (mapped(&host_lp2_, &host_lp2_dev_, 2 * cap)) return -1;
   }
+  // what only the device reads again: the proposals and (log prior, log factor) of the half batch in flight
+  HB_CHECK(hipMalloc((void **)&dev_thp_, (size_t)m_.d * cap * sizeof(double)), "hipMalloc(proposals)");
+  HB_CHECK(hipMalloc((void **)&dev_aux_, 2 * cap * sizeof(double)), "hipMalloc(log prior, log factor)");
   HB_CHECK(hipHostMalloc((void **)&host_flag_, kHostMaxChunks * sizeof(unsigned long long), hipHostMallocMapped), "hipHostMalloc(chunk flags)");
   for (int i = 0; i < kHostMaxChunks; ++i) host_flag_[i] = 0ull;
   HB_CHECK(hipHostGetDevicePointer((void **)&host_flag_dev_, host_flag_, 0), "hipHostGetDevicePointer(chunk flags)");
@@ -371,7 +380,7 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
   const int n_chunks = (int)((cnt + chunk - 1) / chunk);
   const unsigned long long seq = ++host_seq_;
   // ONE launch proposes the whole half batch (:311-314); it signals its chunks as they complete
-  HB_LAUNCH(launch_host_propose(m_, c, cb_dev_, pop_ptrs(cur_), pv, lo, cnt, host_thp_dev_, host_aux_dev_,
+  HB_LAUNCH(launch_host_propose(m_, c, cb_dev_, pop_ptrs(cur_), pv, lo, cnt, dev_thp_, dev_aux_, host_thp_dev_, host_gate_dev_,
                                 host_prior ? host_cur_dev_ : nullptr, host_done_dev_, host_flag_dev_, seq, chunk, stream_),
             "k_host_propose");
   for (int ch = 0; ch < n_chunks; ++ch) {
@@ -392,34 +401,54 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
       if (rc) { err_ = "the host prior's logpdf callback failed"; return -1; }
       for (int64_t t = 0; t < tn; ++t) {
         const double l = host_lp_[(size_t)t];
-        host_aux_[(size_t)(t0 + t)] = l == l ? l : -INFINITY;             // NaN: outside the support
-        host_lpcur_[(size_t)(t0 + t)] = host_lp_[(size_t)(tn + t)];
+        host_lp2_[(size_t)(t0 + t)] = l == l ? l : -INFINITY;             // NaN: outside the support
+        host_lp2_[(size_t)(cnt + t0 + t)] = host_lp_[(size_t)(tn + t)];
+        host_gate_[(size_t)(t0 + t)] = host_lp2_[(size_t)(t0 + t)] > -INFINITY ? 1 : 0;
       }
     }
     // only proposals inside the prior's support are simulated (:314-315): compact them for the callback
-    host_ids_.clear(); host_where_.clear();
-    for (int64_t t = 0; t < tn; ++t)
-      if (host_aux_[(size_t)(t0 + t)] > -INFINITY) { host_ids_.push_back(sh_.gid0 + lo + t0 + t); host_where_.push_back(t0 + t); }
-    const int64_t mv = (int64_t)host_ids_.size();
-    host_thv_.resize((size_t)(d * mv)); host_rhov_.assign((size_t)(s * mv), 0.0);
-    for (int k = 0; k < d; ++k)
-      for (int64_t i = 0; i < mv; ++i) host_thv_[(size_t)(k * mv + i)] = host_thp_[(size_t)(k * cnt + host_where_[(size_t)i])];
+    host_ids_.resize((size_t)tn); host_where_.resize((size_t)tn);
+    int64_t mv = 0;
+    {
+      const unsigned char *gate = host_gate_ + t0;
+      int64_t *ids = host_ids_.data(), *where = host_where_.data();
+      const int64_t gid_first = sh_.gid0 + lo + t0;
+      for (int64_t t = 0; t < tn; ++t)
+        if (gate[t]) { ids[mv] = gid_first + t; where[mv] = t0 + t; ++mv; }
+    }
+    // every proposal of the chunk passed and the chunk's rows are contiguous (one parameter / statistic, or the chunk is the
+    // whole half batch): f_dist reads the proposals and writes the distances IN the staging arrays, nothing is copied
+    const bool direct = mv == tn && (d == 1 || tn == cnt) && (s == 1 || tn == cnt);
+    const double *th_arg = host_thp_ + t0;
+    double *rho_arg = host_rho_ + t0;
+    if (!direct) {
+      host_thv_.resize((size_t)(d * mv)); host_rhov_.assign((size_t)(s * mv), 0.0);
+      for (int k = 0; k < d; ++k) {
+        const double *src = host_thp_ + (size_t)k * cnt;
+        double *dst = host_thv_.data() + (size_t)k * mv;
+        for (int64_t i = 0; i < mv; ++i) dst[i] = src[host_where_[(size_t)i]];
+      }
+      th_arg = host_thv_.data(); rho_arg = host_rhov_.data();
+    }
     if (mv > 0) {
       const auto c0 = std::chrono::steady_clock::now();
-      const int rc = host_fn_(host_ctx_, host_thv_.data(), host_ids_.data(), mv, c.iter, host_rhov_.data());
+      const int rc = host_fn_(host_ctx_, th_arg, host_ids_.data(), mv, c.iter, rho_arg);
       host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
       host_cb_calls_ += 1;
       if (rc) { err_ = "the host simulator (f_dist) failed"; return -1; }
     }
-    for (int j = 0; j < s; ++j) {
-      for (int64_t t = 0; t < tn; ++t) host_rho_[(size_t)(j * cnt + t0 + t)] = 0.0;
-      for (int64_t i = 0; i < mv; ++i) host_rho_[(size_t)(j * cnt + host_where_[(size_t)i])] = host_rhov_[(size_t)(j * mv + i)];
-    }
+    if (!direct)
+      for (int j = 0; j < s; ++j) {
+        double *dst = host_rho_ + (size_t)j * cnt;
+        for (int64_t t = 0; t < tn; ++t) dst[t0 + t] = 0.0;
+        const double *src = host_rhov_.data() + (size_t)j * mv;
+        for (int64_t i = 0; i < mv; ++i) dst[host_where_[(size_t)i]] = src[i];
+      }
     // the accept step of this chunk (:316-329) reads the distances in place; it runs while the host is in the next
     // chunk's callback.  (The launch orders the host's stores above before the kernel's loads.)
     if (ch == 0) prof_begin(SABC_KERNEL_UPDATE);
-    HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, t0, tn, host_thp_dev_, host_aux_dev_, host_rho_dev_,
-                                 host_prior ? host_lpcur_dev_ : nullptr, host_acc_dev_, stream_), "k_host_accept");
+    HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, t0, tn, dev_thp_, dev_aux_, host_rho_dev_,
+                                 host_prior ? host_lp2_dev_ : nullptr, host_acc_dev_, stream_), "k_host_accept");
     if (ch == n_chunks - 1) prof_end(SABC_KERNEL_UPDATE);
   }
   return 0;

@@ -152,8 +152,10 @@ class HipBackend : public Backend {
   void *prior_ctx_ = nullptr;
   void *host_ctx_ = nullptr;
   // staging of a half batch: pinned host arrays (host_x_) mapped into the device (host_x_dev_), allocated once
-  double *host_thp_ = nullptr, *host_aux_ = nullptr, *host_rho_ = nullptr, *host_cur_ = nullptr, *host_lpcur_ = nullptr;
-  double *host_thp_dev_ = nullptr, *host_aux_dev_ = nullptr, *host_rho_dev_ = nullptr, *host_cur_dev_ = nullptr, *host_lpcur_dev_ = nullptr;
+  double *host_thp_ = nullptr, *host_rho_ = nullptr, *host_cur_ = nullptr, *host_lp2_ = nullptr;
+  double *host_thp_dev_ = nullptr, *host_rho_dev_ = nullptr, *host_cur_dev_ = nullptr, *host_lp2_dev_ = nullptr;
+  unsigned char *host_gate_ = nullptr, *host_gate_dev_ = nullptr;      // one byte per proposal: inside the prior's support?
+  double *dev_thp_ = nullptr, *dev_aux_ = nullptr;                     // device memory: proposals, (log prior, log factor)
   static constexpr int kHostMaxChunks = 64;
   unsigned long long *host_flag_ = nullptr, *host_flag_dev_ = nullptr;   // per chunk: the proposal kernel posts, the host polls
   unsigned int *host_done_dev_ = nullptr;

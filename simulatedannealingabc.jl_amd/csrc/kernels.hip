@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(kBlock) k_host_prior(const ModelDesc m, const 
 __device__ __forceinline__ void host_propose_one(const ModelDesc &m, const StepArgs &c, const ControlBlock *__restrict__ cb,
                                                  const PopPtrs &pp, const PartnerView &pv, const int64_t act_lo, const int64_t act_n,
                                                  double *__restrict__ thp_out, double *__restrict__ aux,
+                                                 double *__restrict__ thp_host, unsigned char *__restrict__ gate_host,
                                                  double *__restrict__ cur_out, const int64_t t) {
   const int d = m.d;
   const int64_t li = act_lo + t;
@@ -411,16 +412,21 @@ __device__ __forceinline__ void host_propose_one(const ModelDesc &m, const StepA
     }
     logf = log(z) * (double)(d - 1);
   }
-  for (int k = 0; k < d; ++k) thp_out[(int64_t)k * act_n + t] = thp[k];
-  aux[t] = prior_logpdf_rt(m, thp);
+  // the proposal stays in device memory for the accept step AND goes to the host for f_dist; of the prior gate the host
+  // needs one byte (simulate or not), the log densities stay on the device
+  const double lpp = prior_logpdf_rt(m, thp);
+  for (int k = 0; k < d; ++k) { thp_out[(int64_t)k * act_n + t] = thp[k]; thp_host[(int64_t)k * act_n + t] = thp[k]; }
+  aux[t] = lpp;
   aux[act_n + t] = logf;
+  gate_host[t] = lpp > -INFINITY ? 1 : 0;
   if (cur_out)
     for (int k = 0; k < d; ++k) cur_out[(int64_t)k * act_n + t] = th[k];
 }
 
-// thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor); cur_out (optional)
-// [d][act_n] = the current particles (a host-callback prior needs their log density too).  The outputs are pinned host
-// memory mapped into the device (zero copy): no D2H call follows.  The half batch is cut into chunks of `sig.chunk`
+// thp [d][act_n] = proposals, aux [2][act_n] = (log prior of the proposal or -inf, log_factor): device memory, read again by
+// k_host_accept.  What the HOST needs goes to pinned host memory mapped into the device (zero copy, no D2H call follows):
+// thp_host = the proposals, gate_host [act_n] = one byte per proposal (inside the prior's support?), cur_out (optional,
+// [d][act_n]) = the current particles (a host-callback prior needs their log density too).  The half batch is cut into chunks of `sig.chunk`
 // particles; the LAST workgroup of a chunk to finish posts `sig.seq` into the chunk's flag word in host memory, which the
 // host polls -- it starts f_dist on chunk c while the later chunks are still being proposed, without a stream sync.
 struct HostSignal {
@@ -433,10 +439,11 @@ struct HostSignal {
 __global__ void __launch_bounds__(kBlock)
 k_host_propose(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp,
                const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ thp_out,
-               double *__restrict__ aux, double *__restrict__ cur_out, const HostSignal sig) {
+               double *__restrict__ aux, double *__restrict__ thp_host, unsigned char *__restrict__ gate_host,
+               double *__restrict__ cur_out, const HostSignal sig) {
   rng_tables_init();
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t < act_n) host_propose_one(m, c, cb, pp, pv, act_lo, act_n, thp_out, aux, cur_out, t);
+  if (t < act_n) host_propose_one(m, c, cb, pp, pv, act_lo, act_n, thp_out, aux, thp_host, gate_host, cur_out, t);
   __threadfence_system();                     // this lane's stores to host memory are out ...
   __syncthreads();                            // ... for every lane of the workgroup
   if (threadIdx.x == 0) {
@@ -456,16 +463,17 @@ __global__ void __launch_bounds__(kBlock)
 k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
               const int64_t act_lo, const int64_t act_n, const int64_t t_lo, const int64_t t_n,
               const double *__restrict__ thp_in,
-              const double *__restrict__ aux, const double *__restrict__ rho_prop, const double *__restrict__ lp_cur,
+              const double *__restrict__ aux, const double *__restrict__ rho_prop, const double *__restrict__ lp_host,
               unsigned long long *n_accept) {
-  // one chunk [t_lo, t_lo + t_n) of the half batch; thp / aux / rho_prop / lp_cur are the host's mapped staging arrays
+  // one chunk [t_lo, t_lo + t_n) of the half batch; thp / aux: device memory (k_host_propose); rho_prop: the host's mapped
+  // staging array; lp_host (a host-callback prior only, mapped): [2][act_n] = log prior of the proposals | of the current particles
   const int64_t t = t_lo + (int64_t)blockIdx.x * kBlock + threadIdx.x;
   bool accepted = false;
   if (t < t_lo + t_n) {
     const int d = m.d, s = m.s;
     const int64_t li = act_lo + t;
     const uint64_t gid = (uint64_t)(pp.gid0 + li);
-    const double lpp = aux[t], logf = aux[act_n + t];
+    const double lpp = lp_host ? lp_host[t] : aux[t], logf = aux[act_n + t];
     double log_accept = -INFINITY;
     double up[kMaxStats];
     if (lpp > -INFINITY) {
@@ -478,7 +486,7 @@ k_host_accept(const ModelDesc m, const StepArgs c, const ControlBlock *__restric
         const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
         a += (pp.pop[(int64_t)(d + j) * pp.cap + li] - up[j]) / e;
       }
-      log_accept = lpp - (lp_cur ? lp_cur[t] : prior_logpdf_rt(m, th)) + a + logf;   // (lp_cur: host-callback prior)
+      log_accept = lpp - (lp_host ? lp_host[act_n + t] : prior_logpdf_rt(m, th)) + a + logf;   // (lp_host: host-callback prior)
     }
     const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
     accepted = log_fast(u52(wa.x, wa.y)) < log_accept;
@@ -1552,22 +1560,23 @@ int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream) {
 }
 
 int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
-                        int64_t act_lo, int64_t act_n, double *thp, double *aux, double *cur_out, unsigned int *done,
-                        unsigned long long *flag, unsigned long long seq, int64_t chunk, hipStream_t stream) {
+                        int64_t act_lo, int64_t act_n, double *thp, double *aux, double *thp_host, unsigned char *gate_host,
+                        double *cur_out, unsigned int *done, unsigned long long *flag, unsigned long long seq, int64_t chunk,
+                        hipStream_t stream) {
   if (act_n <= 0) return 0;
   HostSignal sig;
   sig.done = done; sig.flag = flag; sig.seq = seq; sig.chunk = chunk;
   hipLaunchKernelGGL(k_host_propose, dim3((unsigned)n_blocks(act_n)), dim3(kBlock), 0, stream, m, c, cb, pp, pv, act_lo, act_n,
-                     thp, aux, cur_out, sig);
+                     thp, aux, thp_host, gate_host, cur_out, sig);
   return SABC_LAUNCH_RC();
 }
 
 int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
                        int64_t act_n, int64_t t_lo, int64_t t_n, const double *thp, const double *aux, const double *rho_prop,
-                       const double *lp_cur, unsigned long long *n_accept, hipStream_t stream) {
+                       const double *lp_host, unsigned long long *n_accept, hipStream_t stream) {
   if (t_n <= 0) return 0;
   hipLaunchKernelGGL(k_host_accept, dim3((unsigned)n_blocks(t_n)), dim3(kBlock), 0, stream, m, c, cb, pp, cdf, act_lo, act_n,
-                     t_lo, t_n, thp, aux, rho_prop, lp_cur, n_accept);
+                     t_lo, t_n, thp, aux, rho_prop, lp_host, n_accept);
   return SABC_LAUNCH_RC();
 }
 

@@ -168,15 +168,19 @@ int launch_compact_column(const ShardBlocks &gathered, int stat, int64_t n_globa
 int sort_f64(const double *in, double *out, int64_t n, void *tmp, size_t *tmp_bytes, hipStream_t stream);
 // host-simulator mode (SABC_MODEL_HOST): the per-particle body cut at f_dist
 int launch_host_prior(const ModelDesc &m, PopPtrs pp, hipStream_t stream);
-// thp / aux / cur_out (optional) / rho_prop / lp_cur are pinned host arrays mapped into the device (zero copy).  The
+// thp / aux: device memory (proposals, log prior + log factor), written by the proposal step, read by the accept step.
+// thp_host / gate_host / cur_out (optional) / rho_prop / lp_host (optional) are pinned host arrays mapped into the device
+// (zero copy): what the host needs of a proposal (the proposal itself, one byte of prior gate, for a host-callback prior
+// the current particle) and what it hands back (the distances; for a host-callback prior the two log densities).  The
 // proposals of a half batch are signalled chunk by chunk: flag[ch] = seq once chunk ch (`chunk` particles, a multiple of
 // kBlock) is complete (`done`: device counters, zero between launches).  The accept step runs per chunk [t_lo, t_lo + t_n).
 int launch_host_propose(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, PartnerView pv,
-                        int64_t act_lo, int64_t act_n, double *thp, double *aux, double *cur_out, unsigned int *done,
-                        unsigned long long *flag, unsigned long long seq, int64_t chunk, hipStream_t stream);
+                        int64_t act_lo, int64_t act_n, double *thp, double *aux, double *thp_host, unsigned char *gate_host,
+                        double *cur_out, unsigned int *done, unsigned long long *flag, unsigned long long seq, int64_t chunk,
+                        hipStream_t stream);
 int launch_host_accept(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, int64_t act_lo,
                        int64_t act_n, int64_t t_lo, int64_t t_n, const double *thp, const double *aux, const double *rho_prop,
-                       const double *lp_cur, unsigned long long *n_accept, hipStream_t stream);
+                       const double *lp_host, unsigned long long *n_accept, hipStream_t stream);
 int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, double *partials, unsigned long long *n_accept,
                     hipStream_t stream);
 // operators
