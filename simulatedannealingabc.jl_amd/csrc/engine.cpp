@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "control.hpp"
@@ -240,6 +241,7 @@ int Engine::wait_step(int64_t seq, int64_t *n_accept, int *halted) {
     return fail(SABC_ERR_HIP, "waiting for the control step failed");
   }
   host_syncs_ += 1;
+  if (std::getenv("SABC_DEBUG_SYNCS")) std::fprintf(stderr, "[sabc rank %d] wait_step seq %lld halted %d err %d -> %lld\n", sh_.rank, (long long)seq, *halted, err, (long long)host_syncs_);
   if (err) { cb_.error = err; return sync_control(); }
   return 0;
 }
@@ -247,6 +249,7 @@ int Engine::wait_step(int64_t seq, int64_t *n_accept, int *halted) {
 int Engine::sync_control() {
   if (be_->read_control(&cb_)) return fail(SABC_ERR_HIP, "reading the control block failed");
   host_syncs_ += 1;
+  if (std::getenv("SABC_DEBUG_SYNCS")) std::fprintf(stderr, "[sabc rank %d] sync_control error %d -> %lld\n", sh_.rank, cb_.error, (long long)host_syncs_);
   switch (cb_.error) {
     case 0: return 0;
     case SABC_ERR_ZERO_MEAN_U: return fail(SABC_ERR_ZERO_MEAN_U, "Division by zero - Mean u for a statistic is <= eps()");   // :107-109
@@ -293,8 +296,9 @@ int Engine::resample(double delta, uint64_t iter) {
     // weights -> barrier -> every shard scans the owners' weight rows and reads the rows it drew from their owners: nothing
     // is gathered, no host round trip (host_syncs unchanged)
     if (be_->resample_p2p(delta, iter)) return fail(SABC_ERR_HIP, "peer-to-peer resample kernels failed");
-    // what crosses: the other shards' weights, read twice by the scan, and the drawn rows that live elsewhere
-    comm_bytes_ += (2 * (sh_.n_global - sh_.n_local) + sh_.n_local * (int64_t)(d + s) * (sh_.world - 1) / sh_.world) * (int64_t)sizeof(double);
+    // what crosses: the other shards' weights (read once: the scan's first pass parks them locally) and the drawn rows
+    // that live elsewhere
+    comm_bytes_ += ((sh_.n_global - sh_.n_local) + sh_.n_local * (int64_t)(d + s) * (sh_.world - 1) / sh_.world) * (int64_t)sizeof(double);
     return stats_reduce();
   }
   if (be_->resample_weights(delta)) return fail(SABC_ERR_HIP, "resample weights kernel failed");   // :126-127

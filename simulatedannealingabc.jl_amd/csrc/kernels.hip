@@ -858,7 +858,8 @@ struct WeightArgs {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_scan_sums(const ShardBlocks g, const int64_t n, double *__restrict__ bs, double *__restrict__ bq, const WeightArgs wa) {
+k_scan_sums(const ShardBlocks g, const int64_t n, double *__restrict__ bs, double *__restrict__ bq, const WeightArgs wa,
+            double *__restrict__ wcopy) {
   __shared__ double sm[2][kBlock / 64];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
   double s = 0.0, q = 0.0;
@@ -872,6 +873,7 @@ k_scan_sums(const ShardBlocks g, const int64_t n, double *__restrict__ bs, doubl
         wa.pp.pop[(int64_t)(wa.d + wa.s) * wa.pp.cap + i] = w;
       } else {
         w = gathered_weight(g, i);
+        if (wcopy) wcopy[i] = w;       // weights read from their owners (peer-mapped): the last pass finds them here, not over xGMI again
       }
     }
     s += w; q += w * w;
@@ -949,7 +951,7 @@ __device__ __forceinline__ int64_t guide_bucket(const double t, const double tot
 // pass 3: inclusive scan inside each chunk + chunk offset
 __global__ void __launch_bounds__(kBlock)
 k_scan_final(const ShardBlocks g, const int64_t n, const double *__restrict__ bs, double *__restrict__ cum,
-             double *__restrict__ cm, const PackArgs pa) {
+             double *__restrict__ cm, const PackArgs pa, const int w_in_cum) {
   __shared__ double sm[kBlock];
   __shared__ double scum[kScanChunk];
   const int64_t base = (int64_t)blockIdx.x * kScanChunk + (int64_t)threadIdx.x * 4;
@@ -958,7 +960,8 @@ k_scan_final(const ShardBlocks g, const int64_t n, const double *__restrict__ bs
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int64_t i = base + e;
-    w[e] = i < n ? gathered_weight(g, i) : 0.0;
+    // w_in_cum: the first pass left the weights in `cum` (each element is read here before this thread overwrites it below)
+    w[e] = i < n ? (w_in_cum ? cum[i] : gathered_weight(g, i)) : 0.0;
     s += w[e];
   }
   sm[threadIdx.x] = s;
@@ -1661,11 +1664,13 @@ int launch_weight_scan(const ShardBlocks &gathered, int64_t n_global, double *bl
   double *bs = block_sums, *bq = block_sums + nb, *cm = block_sums + 2 * nb;
   WeightArgs wa;
   std::memset(&wa, 0, sizeof(wa));
-  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, bq, wa);
+  // blocks that live in other shards' memory are read ONCE: the first pass parks the weights in `cum`
+  const int park = gathered.direct ? 1 : 0;
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, bq, wa, park ? cum : (double *)nullptr);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
   PackArgs none;
   std::memset(&none, 0, sizeof(none));
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, cum, cm, none);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, gathered, n_global, bs, cum, cm, none, park);
   return SABC_LAUNCH_RC();
 }
 
@@ -1706,9 +1711,9 @@ int launch_resample_local(const ModelDesc &m, PopPtrs src, PopPtrs dst, const Co
     pa.totals = totals; pa.row_len = rl; pa.pg = pg;
   }
   const ShardBlocks own = flat_blocks(src.pop, rows, cap, 1);
-  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, bq, wa);
+  hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, bq, wa, (double *)nullptr);
   hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, stream, bs, bq, nb, totals, totals_host);
-  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, cum, cm, pa);
+  hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nb), dim3(kBlock), 0, stream, own, n, bs, cum, cm, pa, 0);
   const size_t lds = nb <= kGatherCoarseMax ? (size_t)nb * sizeof(double) : 0;
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
   if (!pa.pk) {                      // a row does not fit a 128-byte line (d + s > 15): the unpacked gather, sums by the caller
