@@ -463,6 +463,10 @@ def main():
             # True: the library's own RCCL binding failed and torch.distributed's RCCL carried the collectives (device
             # pointers, same wires, one Python callback per collective) -- a measured but pessimistic number
             "transport_degraded": bool(world > 1 and args.dist_backend == "nccl" and transport not in ("rccl", "p2p")),
+            # peer-to-peer transport: calls in which a wait ran into its bound and that the engine finished over the
+            # collectives underneath (0 = the whole run went peer to peer), and whether it is still on at the end
+            "p2p_fallbacks": h.p2p_fallbacks if world > 1 else 0,
+            "p2p_active_at_end": bool(h.p2p_active) if world > 1 else False,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

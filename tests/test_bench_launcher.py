@@ -94,6 +94,7 @@ def test_launcher_two_ranks_peer_to_peer(gpu):
     assert out["n_gpus"] == 2 and out["repeats"] == 2 and out["value_min"] <= out["value"] <= out["value_max"]
     assert out["config"]["collectives"] == "p2p" and out["config"]["collectives_fallback"] == "hooks-gloo"
     assert out["collective_calls_per_update"] == 0 and not out["transport_degraded"]
+    assert out["p2p_fallbacks"] == 0 and out["p2p_active_at_end"]
     ex = out["exchange"]
     assert ex["collective_calls_per_update"] == 0 and ex["reduce_control_launches"] >= 10 and ex["collectives_timed"] == 0
     assert 2.0 <= ex["launches_per_update"] <= 4.0            # k_update + ONE reduce-exchange-control launch (+ a resample's share)
