@@ -326,27 +326,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The timed region is repeated R times in this process -- a fresh handle, the same warm-up, the same K updates (same
-    # seed: the very same trajectory) -- and `value` is the MEDIAN: one 4 ms sample says little (boxes and runs differ by
-    # a few per cent).  steps / warmup mean what they always meant.
+    # The timed region is repeated R times in this process -- the population initialised again (sabc_initialize on the
+    # same handle: same seed, the very same trajectory as a fresh handle's), the same warm-up, the same K updates -- and
+    # `value` is the MEDIAN: one 4 ms sample says little (boxes and runs differ by a few per cent).  steps / warmup mean what
+    # they always meant.  The handle and its transport are set up ONCE: N ranks that map each other's memory (and an RCCL
+    # communicator each) are not torn down and rebuilt between the samples.
     samples = []
-    h = None
     trace = os.environ.get("SABC_BENCH_TRACE")
 
     def say(what):
         if trace:
             print(f"[bench trace] rank {rank} {what}", file=sys.stderr, flush=True)
 
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
+    transport, fallback = "none", None
     for rep in range(max(args.repeats, 1)):
-        if h is not None:
-            barrier()                 # nobody tears a handle down while a peer may still touch its memory
-            h.close()
-            barrier()
-        say(f"repeat {rep}: create")
-        h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank,
-                         world=world)
-        transport, fallback = "none", None
-        if world > 1:
+        say(f"repeat {rep}")
+        if world > 1 and rep == 0:
             from sabc_amd.dist import install_collectives
             transport = install_collectives(h, device, p2p=None if args.p2p == "auto" else args.p2p == "on")
             fallback = getattr(h, "fallback_transport", None)
@@ -359,7 +355,7 @@ def main():
                 h.close()
                 dist.destroy_process_group()
                 raise SystemExit(3)
-            if degraded and rep == 0:
+            if degraded:
                 print(f"[bench] WARNING rank {rank}: RCCL could not be bound inside the library; measuring over '{transport}' "
                       "(torch.distributed on device pointers, a Python callback per collective): the line says so in "
                       "config.collectives and transport_degraded", file=sys.stderr, flush=True)
@@ -441,7 +437,7 @@ def main():
             "metric": "particle-simulations/sec at n_particles=1e6" if args.config == "cfg2" else f"particle-simulations/sec ({args.config})",
             "value": K * n / dt,
             "value_min": K * n / dts[-1], "value_max": K * n / dts[0], "repeats": len(samples),
-            "value_note": "median of `repeats` timed regions in this process (fresh handle, same warm-up, same K updates each)",
+            "value_note": "median of `repeats` timed regions in this process (population initialised again, same warm-up, same K updates each)",
             "unit": "particle-simulations/s",
             "n_gpus": world,
             "steps": K,
@@ -518,7 +514,7 @@ def main():
                     "n_accept_equal": same["n_accept"] == c["n_accept"], "updates": same["updates"],
                     "note": "same seed, same calls on the CPU restatement (oracle); the north star asks for moments within 1 %"}
         print(json.dumps(out), flush=True)
-    barrier()                         # handles that map each other's memory are torn down together
+    barrier()                         # handles that map each other's memory are torn down together, and once
     h.close()
     if world > 1:
         barrier()

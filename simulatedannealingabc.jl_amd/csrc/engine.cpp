@@ -485,6 +485,7 @@ int Engine::initialize_body() {
   n_simulation_ = sh_.n_global;                                             // :213
   cb_.n_accept = 0; n_resampling_ = 1; n_population_updates_ = 0;           // :223
   initialized_ = true;
+  population_replaced_ = true;                                              // (a handle may be initialised again: like a fresh one)
   return 0;
 }
 

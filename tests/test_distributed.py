@@ -128,6 +128,23 @@ def test_cpu_engine_histories_match_the_oracle(S, O, prop):
     h.close()
 
 
+def test_cpu_engine_a_handle_can_be_initialised_again(S):
+    """The host engine's state after a second sabc_initialize + update on the same handle equals the first (same seed)."""
+    from tests import cpu_engine
+    from tests.cases import SEED, hip_model_prior, hip_proposal
+    model, prior = hip_model_prior(S, "gauss2_2stats")
+    h = cpu_engine.handle_class()(n_particles=500, model=model, prior=prior, seed=SEED)
+    runs = []
+    for _ in range(2):
+        h.initialize(6 * 500)
+        h.update(n_simulation=5 * 500, proposal=hip_proposal(S, "rw", 2), resample=125)
+        runs.append((dict(h.counters), h.eps.copy(), [a.copy() for a in h.history], [a.copy() for a in h.get_population()]))
+    h.close()
+    assert runs[0][0] == runs[1][0] and runs[0][0]["n_resampling"] >= 3
+    for a, b in zip([runs[0][1]] + runs[0][2] + runs[0][3], [runs[1][1]] + runs[1][2] + runs[1][3]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_cpu_engine_failed_collective_restores_the_state(S):
     """Error contract of sabc_update on the product's host engine (engine.cpp over the oracle-backed Backend): a collective
     that fails in the middle of the loop leaves counters, eps and histories as they were at entry and the handle refuses

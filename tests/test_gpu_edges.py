@@ -178,3 +178,25 @@ def test_resample_with_all_but_weightless_particles(S, O, gpu, name):
     collapsed = len(np.unique(θ[0])) < 5
     np.testing.assert_allclose(θ, run.theta, rtol=1e-6 if collapsed else 1e-9, atol=1e-12)
     assert len(np.unique(θ[0])) < 0.2 * n              # the weights really were that uneven
+
+
+@pytest.mark.parametrize("name,prop", [("gauss1_cfg2", "rw"), ("gauss2_2stats", "de")])
+def test_a_handle_can_be_initialised_again(S, gpu, name, prop):
+    """sabc_initialize on a handle that has already run (bench.py repeats its timed region this way): the same seed gives the
+    very same trajectory as the first time -- counters, epsilon, histories and particles."""
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+    n, k = 20_000, 8
+    d = len(MODELS[name]["prior"])
+    model, prior = hip_model_prior(S, name)
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+    runs = []
+    for _ in range(3):
+        h.initialize((k + 1) * n)
+        h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=n // 2)
+        runs.append((dict(h.counters), h.eps.copy(), [a.copy() for a in h.history], [a.copy() for a in h.get_population()]))
+    h.close()
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[0]["n_resampling"] >= 3
+        np.testing.assert_array_equal(r[1], runs[0][1])
+        for a, b in zip(r[2] + r[3], runs[0][2] + runs[0][3]):
+            np.testing.assert_array_equal(a, b)
