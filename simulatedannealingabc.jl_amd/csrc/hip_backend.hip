@@ -5,6 +5,7 @@
 #include <unistd.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace sabc {
@@ -24,7 +25,13 @@ namespace sabc {
     if (e_) return check((hipError_t)e_, (what));  \
   } while (0)
 
-HipBackend::HipBackend(int device) : device_(device) {}
+HipBackend::HipBackend(int device) : device_(device) {
+  // (tests lower the limit to reach the two-launch form -- k_reduce_partials, then the control / exchange launch -- at small n)
+  if (const char *e = std::getenv("SABC_FUSE_REDUCE_MAX")) {
+    const long long v = std::atoll(e);
+    if (v >= 0) fuse_reduce_max_ = v;
+  }
+}
 
 // hipFree waits for EVERY stream of the process.  With several shards in one process (tests; a Julia host driving the GPUs
 // of a node from threads) a peer's kernel may be spinning for this shard's next post, which the host cannot enqueue while
@@ -592,7 +599,7 @@ double *HipBackend::sums_buffer() {
 int HipBackend::control(const ControlArgs &a) {
   const bool xchg = pending_xchg_ && pending_rows_ >= 0;
   const P2PView pv = xchg ? p2p_view() : P2PView();
-  if (pending_rows_ >= 0 && np_ <= 64 && pending_rows_ * np_ <= kFuseReduceMaxDoubles) {
+  if (pending_rows_ >= 0 && np_ <= 64 && pending_rows_ * np_ <= fuse_reduce_max_) {
     const int64_t rows = pending_rows_;
     pending_rows_ = -1;
     pending_xchg_ = false;

@@ -127,6 +127,7 @@ class HipBackend : public Backend {
   double *hist_dev_ = nullptr;
   int flush_reduce();                                     // launch a deferred k_reduce_partials
   int64_t pending_rows_ = -1;                             // >= 0: a reduction waits to be fused into k_control
+  int64_t fuse_reduce_max_ = kFuseReduceMaxDoubles;       // partial-row matrices up to this many doubles: reduced inside the control launch
   bool pending_guarded_ = false;
   double *sums_stage_ = nullptr;                          // reduction / allreduce target, taken over by k_control
   int64_t hist_cap_ = 0;

@@ -256,3 +256,41 @@ def test_p2p_four_processes_over_hip_ipc(S, gpu, tmp_path, prop):
     assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
     np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
     np.testing.assert_allclose(got["eps"], ref["eps"], rtol=tol)
+
+
+def test_p2p_with_the_two_launch_reduction(S, gpu, tmp_path, monkeypatch):
+    """A partial-row matrix too large for one workgroup is summed by k_reduce_partials first; the exchange + control launch then
+    takes the shard's sums from the staging buffer (`rows < 0`).  Reached at small n by lowering the limit (SABC_FUSE_REDUCE_MAX)."""
+    monkeypatch.setenv("SABC_FUSE_REDUCE_MAX", "64")
+    case, alg, prop, n, k = "gauss2d_cfg3", "multi_eps", "de", 30_000, 10
+    out = run_shards_in_one_process(S, case, alg, prop, n, k, resample=n // 4)
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k,
+                 resample=n // 4)
+    check_against_cpu_engine(out, ref, prop)
+    # one more launch per reduction than the fused form: k_update x 2 + barrier + k_reduce_partials + exchange-control
+    assert out[0]["launches"] >= k * 5
+
+
+def test_p2p_with_a_simulator_from_source(S, gpu):
+    """The run-time compiled update kernel (SABC_MODEL_USER) takes the same PartnerView -- peer pointers included -- as the
+    built-in ones: two shards over the peer-to-peer transport with the Gaussian simulator from HIP source reproduce the
+    compiled-in simulator bit for bit (DifferentialEvolution: partners read from the other shard's memory)."""
+    from tests.test_user_simulator import GAUSS_IID_SRC
+    import tests.cases as cases
+    n, k = 30_000, 8
+    ybar = cases.MODELS["gauss1_cfg2"]["model"][1]["obs_mean"]
+    orig = cases.hip_model_prior
+    runs = []
+    try:
+        for model in (None, S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, ybar, 0.0])):
+            if model is not None:
+                cases.hip_model_prior = lambda S_, name, m=model: (m, orig(S_, name)[1])
+            runs.append(run_shards_in_one_process(S, "gauss1_cfg2", "single_eps", "de", n, k, resample=n // 4))
+    finally:
+        cases.hip_model_prior = orig
+    a, b = runs
+    for oa, ob in zip(a, b):
+        assert oa["counters"] == ob["counters"] and oa["counters"]["n_resampling"] >= 2
+        np.testing.assert_array_equal(oa["theta"], ob["theta"])
+        np.testing.assert_array_equal(oa["rho"], ob["rho"])
+        np.testing.assert_array_equal(oa["eps"], ob["eps"])
