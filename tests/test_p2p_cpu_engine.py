@@ -135,7 +135,8 @@ def check(out, ref, tol=1e-10):
 
 
 @pytest.mark.parametrize("world,case,alg,prop,n", [(2, "gauss1_cfg2", "single_eps", "rw", 1001), (3, "gauss2_2stats", "multi_eps", "de", 1000),
-                                                   (2, "gauss2d_cfg3", "single_eps", "stretch", 777), (3, "gauss2_meansd", "single_eps", "rw", 1003)])
+                                                   (2, "gauss2d_cfg3", "single_eps", "stretch", 777), (3, "gauss2_meansd", "single_eps", "rw", 1003),
+                                                   (8, "gauss1_cfg2", "single_eps", "de", 1003)])     # a whole node's geometry, ragged last shard
 def test_engine_over_the_peer_to_peer_paths_equals_the_collectives(S, tmp_path, world, case, alg, prop, n):
     k = 10
     out = run_threads(S, case, alg, prop, n, k, resample=n // 4, world=world)
