@@ -5,7 +5,7 @@ for cfg in cfg2 cfg3 cfg4 cfg5; do
   for prop in randomwalk de stretch; do
     for alg in single_eps multi_eps; do
       steps=200; [ $cfg = cfg5 ] && steps=60; [ $cfg = cfg4 ] && steps=100
-      timeout -k 10 280 python bench.py --config $cfg --proposal $prop --algorithm $alg --steps $steps --warmup 2 --no-cpu-baseline \
+      timeout -k 10 280 python bench.py --config $cfg --proposal $prop --algorithm $alg --steps $steps --warmup 2 --no-cpu-baseline --repeats 1 \
         > $out/${cfg}_${prop}_${alg}.json 2> $out/${cfg}_${prop}_${alg}.err
       echo "$cfg $prop $alg rc=$? $(python3 -c "
 import json,sys
@@ -17,7 +17,7 @@ except Exception as e: print('PARSE FAIL', e)
     done
   done
 done
-timeout -k 10 280 python bench.py --steps 3000 --warmup 2 --no-cpu-baseline > $out/long_cfg2.json 2> $out/long_cfg2.err; echo "long cfg2 rc=$?"
+timeout -k 10 280 python bench.py --steps 3000 --warmup 2 --no-cpu-baseline --repeats 1 > $out/long_cfg2.json 2> $out/long_cfg2.err; echo "long cfg2 rc=$?"
 python3 -c "
 import json
 j=json.loads(open('$out/long_cfg2.json').read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step'], j['state'])"
