@@ -11,7 +11,7 @@ cp $lib /tmp/libsabc_cpu_engine.plain.so
 trap 'cp /tmp/libsabc_cpu_engine.plain.so '$lib'; touch '$lib EXIT
 flags="-O1 -g -fPIC -fno-fast-math -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer"
 gcc $flags -std=c11 -fopenmp -c oracle/sabc_oracle.c -o /tmp/sabc_oracle_asan.o
-g++ $flags -std=c++17 -shared -fopenmp -o $lib tests/cpu_engine/ref_backend.cpp simulatedannealingabc.jl_amd/csrc/engine.cpp /tmp/sabc_oracle_asan.o -lm
+g++ $flags -std=c++17 -shared -fopenmp -pthread -o $lib tests/cpu_engine/ref_backend.cpp simulatedannealingabc.jl_amd/csrc/engine.cpp /tmp/sabc_oracle_asan.o -lm
 touch $lib
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 \
-  UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_host_api.py tests/test_distributed.py -q -m "not gpu" -x
+  UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 python -m pytest tests/test_host_api.py tests/test_distributed.py tests/test_p2p_cpu_engine.py -q -m "not gpu" -x
