@@ -54,3 +54,42 @@ def test_plain_c_client_matches_oracle(demo, O, gpu, n, updates):
     assert [int(f[0]), int(f[1]), int(f[2])] == [c["n_accept"], c["n_resampling"], c["n_population_updates"]]
     th = run.theta[0]
     np.testing.assert_allclose([float(f[3]), float(f[4]), float(f[5])], [run.eps[0], th.mean(), th.var()], rtol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def demo_p2p(tmp_path_factory):
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not found")
+    out = str(tmp_path_factory.mktemp("c_abi_p2p") / "demo_p2p")
+    cmd = ["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "demo_p2p.c"), "-o", out, "-L", PKG, "-lsabc_hip", f"-Wl,-rpath,{PKG}"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return out
+
+
+def test_plain_c_p2p_client_builds_and_links(demo_p2p):
+    r = subprocess.run([demo_p2p], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop", [0, 1])
+def test_plain_c_p2p_client_matches_the_cpu_engine(demo_p2p, S, gpu, tmp_path, prop):
+    """Two processes from plain C (fork before any HIP call, descriptors over a socket pair, hipIpc mapping, no collective
+    library): the peer-to-peer transport through nothing but the C-ABI.  Same counters and moments as the CPU engine with
+    the same sharding."""
+    from tests.cases import SEED, y_obs_mean
+    from tests.test_distributed import launch
+    n, k = 20_000, 10
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([demo_p2p, str(n), str(k), str(SEED), repr(y_obs_mean()), str(prop)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = r.stdout.split()
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case="gauss1_cfg2", alg="single_eps",
+                 prop="de" if prop else "rw", n=n, updates=k, resample=n // 4)
+    assert [n * (k + 1), int(f[0]), int(f[1]), int(f[2])] == list(ref["counters"]) and int(f[1]) >= 2
+    th = ref["theta"][0]
+    tol = 1e-6 if prop else 1e-9
+    np.testing.assert_allclose([float(f[3]), float(f[4])], [ref["eps"][0], th.mean()], rtol=tol)
+    np.testing.assert_allclose(float(f[5]), ((th - th.mean()) ** 2).sum(), rtol=1e-6)
+    assert int(f[6]) == 0 and int(f[7]) > 0            # no collective call; kernels were launched
