@@ -12,7 +12,8 @@
 # argument list against the prototypes of include/sabc_hip.h, and the enum values used below.
 module SimulatedAnnealingABCHIP
 
-using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, MvNormal, UnivariateDistribution, logpdf
+using Distributions: Distribution, Normal, Uniform, Exponential, LogNormal, Gamma, Beta, Truncated, MvNormal, UnivariateDistribution,
+                     ContinuousMultivariateDistribution, logpdf
 using LinearAlgebra: cholesky, Symmetric
 using ProgressMeter: Progress, next!, finish!          # same progress UI as the reference (:290-292,374)
 import Dates

@@ -219,3 +219,26 @@ def test_progress_chunking_rule():
     body = re.search(r"function progress_chunk\(.*?\nend", jl_source(), re.S).group(0)
     for tok in ("k % cph == 0", "(n_pop ÷ 50) ÷ cph * cph", "chunk % bar != 0", "max(chunk, 1)"):
         assert tok in body
+
+
+def test_every_capitalised_name_resolves():
+    """Poor man's name resolution (no Julia here): every capitalised identifier in the wrapper's code -- types, modules,
+    constructors -- is defined in the file, imported by a `using X: ...` / `import X` line, a type parameter, or one of the Base
+    names listed here.  (Caught: a supertype used without being imported from Distributions.)"""
+    src = jl_source()
+    code = re.sub(r'"""(.*?)"""', '""', src, flags=re.S)
+    code = "\n".join(re.sub(r'"(\\.|[^"\\])*"', '""', ln).split("#")[0] for ln in code.splitlines())
+    imported = set()
+    for m in re.finditer(r"^using (\w+):((?:[^\n]|\n {2,})*)", src, re.M):
+        imported.add(m.group(1))
+        imported |= {x.strip().lstrip("@") for x in m.group(2).replace("\n", " ").split("#")[0].split(",") if x.strip()}
+    imported |= set(re.findall(r"^import (\w+)$", src, re.M)) | {"Base"}
+    defined = set(re.findall(r"^(?:mutable struct|struct|abstract type|const|module)\s+(\w+)", code, re.M))
+    defined |= {x.strip() for m in re.finditer(r"^const ([\w, ]+) =", code, re.M) for x in m.group(1).split(",")}
+    defined |= set(re.findall(r"^(?:function )?(\w+)\(", code, re.M))
+    base = {"Int", "Int32", "Int64", "UInt8", "UInt64", "Float64", "Bool", "Cint", "Cvoid", "Cstring", "Ptr", "Ref", "Vector", "Matrix",
+            "Array", "Tuple", "NTuple", "NamedTuple", "Union", "Nothing", "Symbol", "String", "Function", "Real", "Integer", "Any", "Dict",
+            "WeakKeyDict", "IO", "Inf", "ENV", "GC", "Threads", "C_NULL", "ArgumentError", "T", "S", "F"}
+    greek = {"Σ", "Θ", "R", "L"}                     # local variables of the wrapper
+    unknown = sorted({w for w in re.findall(r"(?<![\w.:@$])([A-ZΣΘ]\w*)", code)} - imported - defined - base - greek)
+    assert not unknown, unknown
