@@ -1004,7 +1004,7 @@ int HipBackend::p2p_selftest() {
   HB_CHECK(hipMemcpyAsync(d_in, in, sizeof(in), hipMemcpyHostToDevice, stream_), "memcpy");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   const P2PView pv = p2p_view();
-  HB_LAUNCH(launch_p2p_selftest(pv, ++xseq_, np, d_in, d_out, d_failed, stream_), "k_p2p_selftest");
+  HB_LAUNCH(launch_p2p_selftest(pv, ++xseq_, np, d_in, d_out, d_failed, take_silence(), stream_), "k_p2p_selftest");
   HB_LAUNCH(launch_p2p_barrier(pv, ++bseq_, cb_dev_, false, false, stream_), "k_p2p_barrier");
   int failed = 1;
   HB_CHECK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream_), "memcpy");

@@ -797,14 +797,14 @@ k_p2p_commit(const P2PView pv, const uint32_t call, const int status, const int 
 // rows of known values through the slots, for sabc_comm_p2p_selftest: out[q] = sum over shards of in[q]
 __global__ void __launch_bounds__(1024)
 k_p2p_selftest(const P2PView pv, const uint32_t seq, const int np, const double *__restrict__ in, double *__restrict__ out,
-               int *__restrict__ failed_out) {
+               int *__restrict__ failed_out, const int silent) {
   __shared__ int failed;
   __shared__ double sums[kMaxPartials];
   __shared__ uint32_t words[kMaxPeers * kP2PWords];
   if (threadIdx.x == 0) failed = 0;
   if ((int)threadIdx.x < np) sums[threadIdx.x] = in[threadIdx.x];
   __syncthreads();
-  const bool ok = p2p_allreduce_rows(pv, seq, np, sums, words, &failed, 0);
+  const bool ok = p2p_allreduce_rows(pv, seq, np, sums, words, &failed, silent);
   if (ok && (int)threadIdx.x < np) out[threadIdx.x] = sums[threadIdx.x];
   if (threadIdx.x == 0) *failed_out = ok ? 0 : failed;
 }
@@ -1639,8 +1639,9 @@ int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, C
   return SABC_LAUNCH_RC();
 }
 
-int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, hipStream_t stream) {
-  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(1024), 0, stream, pv, seq, np, in, out, failed);
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, bool silent,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(1024), 0, stream, pv, seq, np, in, out, failed, silent ? 1 : 0);
   return SABC_LAUNCH_RC();
 }
 

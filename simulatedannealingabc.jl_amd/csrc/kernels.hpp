@@ -118,7 +118,8 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
 // flag barrier between the shards' streams / end-of-call status exchange / a row of known values through the slots
 int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, bool silent, hipStream_t stream);
 int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, bool silent, hipStream_t stream);
-int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, hipStream_t stream);
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, bool silent,
+                        hipStream_t stream);
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
 int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
                             hipStream_t stream);

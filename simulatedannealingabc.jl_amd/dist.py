@@ -100,10 +100,13 @@ def try_p2p(handle, device, group=None, timeout_ms=None):
     every rank can: world <= 8, all ranks on this host, every peer's memory maps (hipIpc), and the library's self-test --
     a row of known values through the slots with a bounded wait -- passes everywhere.  The collectives already installed
     stay as the fallback.  Returns True when the handle now runs peer to peer (the same answer on every rank)."""
+    import os
     import socket
     import torch.distributed as dist
     world = dist.get_world_size(group)
     ok = 2 <= world <= 8
+    if not timeout_ms:
+        timeout_ms = float(os.environ.get("SABC_P2P_TIMEOUT_MS", "0") or 0)      # bound of every peer-to-peer wait (default 5000)
     desc = None
     if ok:
         try:

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--p2p", type=int, default=0, help="1: the peer-to-peer transport on top of the collectives (hip engine only)")
     ap.add_argument("--silence", type=int, default=0, help="p2p test hook: rank 1 lets this many posts go out, then skips one")
     ap.add_argument("--silence-init", type=int, default=0, help="the same inside sabc_initialize")
+    ap.add_argument("--silence-selftest", type=int, default=0, help="rank 1 posts nothing in the transport's self-test (first contact fails)")
     ap.add_argument("--p2p-timeout-ms", type=float, default=0.0)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -60,6 +61,10 @@ def main():
     alg = S._lib.ALG_MULTI_EPS if a.alg == "multi_eps" else S._lib.ALG_SINGLE_EPS
     h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
     transport = "none"
+    if a.silence_selftest and rank == 1:
+        h.p2p_inject_silence(a.silence_selftest)       # that many of rank 1's next posts (row, barrier flag) are skipped
+    if a.p2p_timeout_ms > 0 and a.silence_selftest:
+        os.environ["SABC_P2P_TIMEOUT_MS"] = str(a.p2p_timeout_ms)
     if world > 1:
         transport = install_collectives(h, device, alltoallv=bool(a.alltoallv), p2p=bool(a.p2p) if a.engine == "hip" else False)
         assert transport in ("p2p", "rccl", "hooks-nccl", "hooks-gloo"), transport

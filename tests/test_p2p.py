@@ -210,6 +210,23 @@ def test_p2p_failed_initialization_is_repeated_over_the_collectives_underneath(S
     np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("skipped", [1, 2])
+def test_p2p_failed_self_test_leaves_every_rank_on_the_collectives(S, gpu, tmp_path, skipped):
+    """First contact goes wrong: the peers map, but rank 1's row (and, skipped = 2, its barrier flag as well: rank 0's control
+    block then carries SABC_ERR_COMM) never arrives in the self-test.  Rank 0 runs into the bound, the ranks agree (over the
+    installed collectives) that nobody switches, and the run is the plain collectives run."""
+    case, n, k = "gauss1_cfg2", 8000, 6
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg="single_eps", prop="de", n=n, updates=k,
+                 resample=n // 4, p2p=1, **{"silence-selftest": skipped, "p2p-timeout-ms": 300})
+    assert str(got["transport"]) == "hooks-gloo" and int(got["p2p_fallbacks"]) == 0 and not bool(got["p2p_active_at_end"])
+    assert int(got["collective_calls"]) > k
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop="de", n=n, updates=k,
+                 resample=n // 4)
+    assert list(got["counters"]) == list(ref["counters"])
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=TOL["de"], atol=TOL["de"] * 1e-2)
+    np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=TOL["de"])
+
+
 @pytest.mark.parametrize("prop", ["rw", "de"])
 def test_p2p_failed_call_is_finished_over_the_collectives_underneath(S, gpu, tmp_path, prop):
     """Two processes, gloo hooks installed underneath the peer-to-peer transport.  Rank 1 skips a post in the middle of the
