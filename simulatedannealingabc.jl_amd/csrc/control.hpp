@@ -7,6 +7,10 @@
 #include "host_math.hpp"
 #include "sabc_types.hpp"
 
+#ifndef SABC_CTRL_MARK
+#define SABC_CTRL_MARK(i) do { } while (0)      // (timing instrumentation of an A/B build, kernels.hip)
+#endif
+
 namespace sabc {
 
 // returns false when the step was a no-op (guarded and halted): nothing must be posted then
@@ -21,6 +25,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
       const bool delta = a.rho_is_delta && q >= 1 + s && q < 1 + 2 * s;          // running sum(rho) += its change
       cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
     }
+  SABC_CTRL_MARK(9);
   const double n = a.n_global;
   const double *S = &cb.sums[1 + 2 * s], *Q = &cb.sums[1 + 2 * s + d];
 
@@ -40,24 +45,30 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
                            : hostmath::rw_proposal_from_sums<4>(S, Q, n, a.prop_p0, cb.sigma, cb.chol);
     if (!ok) cb.error = SABC_ERR_NOT_POSDEF;                                         // MvNormal(...), :42
   } else if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK) {     // update_proposal!
-    double cov[kMaxPara * kMaxPara];
-    hostmath::cov_from_sums(S, Q, d, n, cov);
+    // (no local d x d array: on the single control lane it would live in scratch memory, every element a trip to the L2)
     if (d == 1) {
+      const double c = (Q[0] - S[0] * S[0] / n) / (n - 1.0);                         // hostmath::cov_from_sums, d = 1
       // a variance is >= 0; the one-pass formula can round a population of identical particles (possible
       // after a resample of a tiny population) to -1e-17, where the reference's two-pass cov gives 0
-      cb.sigma[0] = a.prop_p0 * (cov[0] > 0.0 ? cov[0] : 0.0);                       // proposals.jl:59
+      cb.sigma[0] = a.prop_p0 * (c > 0.0 ? c : 0.0);                                 // proposals.jl:59
       cb.chol[0] = sqrt(cb.sigma[0]);                                                // proposals.jl:54
     } else {
+      hostmath::cov_from_sums(S, Q, d, n, cb.sigma);
       for (int k = 0; k < d; ++k)
         for (int l = 0; l < d; ++l)
-          cb.sigma[k * d + l] = a.prop_p0 * (cov[k * d + l] + (k == l ? 1e-8 : 0.0));   // proposals.jl:47
+          cb.sigma[k * d + l] = a.prop_p0 * (cb.sigma[k * d + l] + (k == l ? 1e-8 : 0.0));   // proposals.jl:47
       if (!hostmath::cholesky(cb.sigma, d, cb.chol)) cb.error = SABC_ERR_NOT_POSDEF;   // MvNormal(...), :42
     }
   }
 
+  SABC_CTRL_MARK(10);
   if (a.mode & CTRL_EPSILON) {                                                       // :350-354
     if (a.algorithm == SABC_ALG_MULTI_EPS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __shared__ double ubar[kMaxStats];             // (a local array indexed at run time would live in scratch memory)
+#else
       double ubar[kMaxStats];
+#endif
       for (int j = 0; j < s; ++j) ubar[j] = cb.sums[1 + j] / n;
       if (!hostmath::eps_multi(ubar, s, a.v, cb.eps)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
     } else {
@@ -67,6 +78,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
     }
   }
 
+  SABC_CTRL_MARK(11);
   if (a.mode & CTRL_HISTORY) {                                                       // :367-372
     if (cb.hist_rows < a.hist_capacity) {
       double *row = hist + cb.hist_rows * (cb.eps_len + 2 * s);
@@ -79,6 +91,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
     }
   }
 
+  SABC_CTRL_MARK(12);
   // keep the moment sums centred: the sums in hand are relative to the old pivot, so this goes last
   if (a.mode & CTRL_PIVOT)
     for (int k = 0; k < d; ++k) cb.pivot[k] += S[k] / n;

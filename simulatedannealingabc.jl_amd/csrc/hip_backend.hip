@@ -155,7 +155,7 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&sums_stage_, kMaxPartials * sizeof(double)), "hipMalloc(sums staging)");
   HB_CHECK(hipMemsetAsync(sums_stage_, 0, kMaxPartials * sizeof(double), stream_), "hipMemset(sums staging)");
   HB_CHECK(hipHostMalloc((void **)&mbox_host_, kMailboxRing * sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
-  for (int i = 0; i < kMailboxRing; ++i) { mbox_host_[i].seq = 0; mbox_host_[i].n_accept = 0; mbox_host_[i].error = 0; mbox_host_[i].halted = 0; }
+  for (int i = 0; i < kMailboxRing; ++i) { mbox_host_[i].w0 = kMailboxEmpty; mbox_host_[i].w1 = kMailboxEmpty; }
   HB_CHECK(hipHostGetDevicePointer((void **)&mbox_dev_, mbox_host_, 0), "hipHostGetDevicePointer(mailbox)");
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
   HB_CHECK(hipMalloc((void **)&block_sums_, (size_t)weight_scan_doubles((int64_t)N) * sizeof(double)), "hipMalloc(block_sums)");
@@ -629,23 +629,22 @@ int HipBackend::control(const ControlArgs &a) {
 // control kernel never ran (a fault upstream): report instead of spinning forever.
 int HipBackend::wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) {
   Mailbox *mb = mbox_host_ + (seq % kMailboxRing);
+  int32_t e = 0, hl = 0;
   for (uint64_t spins = 1;; ++spins) {
-    if (mb->seq == seq) break;
+    if (mailbox_unpack(mb->w0, mb->w1, seq, n_accept, &e, &hl)) break;
     __builtin_ia32_pause();
     if ((spins & 0x3FFF) == 0) {
       const hipError_t q = hipStreamQuery(stream_);
       if (q == hipSuccess) {
-        if (mb->seq == seq) break;
+        if (mailbox_unpack(mb->w0, mb->w1, seq, n_accept, &e, &hl)) break;
         err_ = "control step did not report back although the stream is idle";
         return -1;
       }
       if (q != hipErrorNotReady) return check(q, "hipStreamQuery");
     }
   }
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  *n_accept = mb->n_accept;
-  *error = (int)mb->error;
-  *halted = (int)mb->halted;
+  *error = (int)e;
+  *halted = (int)hl;
   return 0;
 }
 

@@ -12,7 +12,21 @@
 //    later in a fixed order (bitwise reproducible for a given grid).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstdlib>
 #include <cstring>
+#ifdef SABC_RC_TIMING
+// A/B instrumentation (tools/rc_timing.py; never in the shipped build): where the time of a reduce-and-control launch goes,
+// in ticks of the constant 100 MHz clock, summed over launches.  [0] launches, [1..] phases; marks are set by thread 0.
+__device__ unsigned long long g_rc_ticks[16];
+__device__ __forceinline__ void rc_mark(int i) {
+  static __shared__ unsigned long long last;
+  if (threadIdx.x != 0) return;
+  const unsigned long long t = wall_clock64();
+  if (i == 0) atomicAdd(&g_rc_ticks[0], 1ull); else atomicAdd(&g_rc_ticks[i], t - last);
+  last = t;
+}
+#define SABC_CTRL_MARK(i) rc_mark(i)
+#endif
 #include "control.hpp"
 #include "p2p.hpp"
 #include "update_kernel.hpp"
@@ -572,11 +586,11 @@ __device__ __forceinline__ void control_load(ControlBlock &lcb, const ControlBlo
 
 __device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a, const ControlBlock &lcb) {
   Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
-  mbox->n_accept = lcb.n_accept;
-  mbox->error = lcb.error;
-  mbox->halted = lcb.halt;
-  __threadfence_system();                   // payload before the sequence word, visible to the host
-  mbox->seq = a.notify_seq;
+  uint64_t w0, w1;
+  mailbox_pack(a.notify_seq, lcb.n_accept, lcb.error, lcb.halt, &w0, &w1);
+  // one 8-byte store each, straight to the host's pinned memory; nothing to order them against (sabc_types.hpp)
+  __hip_atomic_store(const_cast<uint64_t *>(&mbox->w0), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(const_cast<uint64_t *>(&mbox->w1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, ControlBlock *cb, const ControlArgs &a,
@@ -690,6 +704,20 @@ struct XchgArgs {
   int32_t do_control, silent, reserved;
 };
 
+// lane i of every row of 16 receives the value of lane i - k of its row (0.0 where there is none): v_mov_b32 dpp row_shr:k x 2
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+#ifdef SABC_RC_TIMING
+#define RC_MARK(i) rc_mark(i)
+#else
+#define RC_MARK(i) do { } while (0)
+#endif
+
 template <bool XCHG>
 __global__ void __launch_bounds__(1024)
 k_reduce_control(const double *__restrict__ partials, const int64_t rows, const int np, double *__restrict__ stage,
@@ -700,19 +728,35 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
   __shared__ double sm[1024];
   __shared__ double sums[kMaxPartials];
   __shared__ uint32_t words[XCHG ? kMaxPeers * kP2PWords : 1];
+  RC_MARK(0);
+  const int B = blockDim.x;                         // 1024, or 256 for a short matrix of partial rows (launch_reduce_control)
+  const int G = B / np;
+  const int g = threadIdx.x / np, c = threadIdx.x - g * np;
+  // the rows first (they come from the other XCDs' blocks, i.e. from memory: the longest latency of this launch), then the
+  // control block; all of a lane's rows in ONE round trip where they fit (20 at n = 1e6: 3906 rows over 204 row groups),
+  // masked so that there is no tail of dependent single loads (each a trip to the L2: 3-4 of them were ~3 us of this
+  // kernel); the additions stay in row order, a masked slot adds +0
+  constexpr int kInFlight = 24;
+  double xx[kInFlight];
+  if (rows >= 0 && g < G) {
+#pragma unroll
+    for (int e = 0; e < kInFlight; ++e) {
+      const int64_t r = g + (int64_t)e * G;
+      xx[e] = r < rows ? partials[r * np + c] : 0.0;
+    }
+  }
   control_load(lcb, cb);
+#ifdef SABC_RC_TIMING
+  __builtin_amdgcn_s_waitcnt(0);                    // thread 0's loads have arrived
+  RC_MARK(7);
+#endif
   if (threadIdx.x == 0) failed = 0;
   if (rows >= 0) {
-    const int G = 1024 / np;
-    const int g = threadIdx.x / np, c = threadIdx.x - g * np;
     double v = 0.0;
     if (g < G) {
-      // all of a lane's rows in ONE round trip where they fit (20 at n = 1e6: 3906 rows over 204 row groups), masked so that
-      // there is no tail of dependent single loads (each a trip to the L2: 3-4 of them were ~3 us of this kernel); the
-      // additions stay in row order, a masked slot adds +0
-      constexpr int kInFlight = 24;
-      for (int64_t r0 = g; r0 < rows; r0 += (int64_t)kInFlight * G) {
-        double xx[kInFlight];
+#pragma unroll
+      for (int e = 0; e < kInFlight; ++e) v += xx[e];
+      for (int64_t r0 = g + (int64_t)kInFlight * G; r0 < rows; r0 += (int64_t)kInFlight * G) {
 #pragma unroll
         for (int e = 0; e < kInFlight; ++e) {
           const int64_t r = r0 + (int64_t)e * G;
@@ -724,18 +768,38 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
     }
     sm[threadIdx.x] = v;
     __syncthreads();
-    // fixed-shape tree over the G row groups (a serial sum by np lanes would be G dependent LDS reads: 6 us at G = 204)
-    int top = 1;
-    while (top * 2 < G) top *= 2;
-    for (int stride = top; stride >= 1; stride >>= 1) {
-      if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
-      __syncthreads();
+    RC_MARK(1);                                     // control block + partial rows loaded
+    const int n_waves = B >> 6;
+    if (np <= 16) {
+      // one WAVE per column: lane l adds the groups l, l + 64, ... (<= 4 LDS reads), the 64 lane sums are added inside the
+      // wave -- DPP row shifts, then the four row totals in order -- without another barrier or LDS round (the 8-level LDS
+      // tree below was 1.2 us of this launch, tools/rc_timing.py)
+      const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+      for (int col = w; col < np; col += n_waves) {
+        double t = 0.0;
+        for (int gg = l; gg < G; gg += 64) t += sm[gg * np + col];
+        t += dpp_row_shr<0x111>(t);
+        t += dpp_row_shr<0x112>(t);
+        t += dpp_row_shr<0x114>(t);
+        t += dpp_row_shr<0x118>(t);                 // lane 16 r + 15 now holds the sum of row r
+        const double total = ((read_lane(t, 15) + read_lane(t, 31)) + read_lane(t, 47)) + read_lane(t, 63);
+        if (l == 0) sums[col] = total;
+      }
+    } else {
+      // fixed-shape tree over the G row groups (a serial sum by np lanes would be G dependent LDS reads: 6 us at G = 204)
+      int top = 1;
+      while (top * 2 < G) top *= 2;
+      for (int stride = top; stride >= 1; stride >>= 1) {
+        if (g < stride && g + stride < G) sm[threadIdx.x] += sm[threadIdx.x + stride * np];
+        __syncthreads();
+      }
+      if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
     }
-    if ((int)threadIdx.x < np) sums[threadIdx.x] = sm[threadIdx.x];
   } else if ((int)threadIdx.x < np) {
     sums[threadIdx.x] = stage[threadIdx.x];
   }
   __syncthreads();
+  RC_MARK(2);                                       // tree
   if (XCHG) {
     // every shard takes the same decision here (the halt flag follows from sums all shards share), so a step that is a
     // no-op posts nothing on ANY shard and nobody waits for it
@@ -753,8 +817,31 @@ k_reduce_control(const double *__restrict__ partials, const int64_t rows, const 
       return;
     }
   }
+  RC_MARK(3);                                       // exchange
+#ifdef SABC_RC_TIMING
+  if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums) ? 1 : 0;
+  __syncthreads();
+  RC_MARK(4);                                       // control step (one lane)
+  if (!ran) return;
+  for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
+    reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
+  if (stage && (int)threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
+  __syncthreads();
+  RC_MARK(5);                                       // write back issued
+  if (threadIdx.x == 0 && a.notify_seq != 0) mailbox_post(ring, a, lcb);
+  RC_MARK(6);                                       // mailbox
+#else
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, stage);
+#endif
 }
+
+#ifdef SABC_RC_TIMING
+extern "C" __attribute__((visibility("default"))) int sabc_debug_rc_ticks(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rc_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_rc_ticks), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 // Flag barrier between the shards' streams: everything every shard has enqueued before its barrier `seq` has completed
 // (kernel boundary) before anything enqueued behind it starts.  Lane r posts to / waits for shard r.
@@ -1620,11 +1707,15 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
   XchgArgs x;
   std::memset(&x, 0, sizeof(x));
   x.do_control = do_control ? 1 : 0;
+  // a short matrix of partial rows (a shard of an 8-GPU run: 489 rows at n = 1e6) takes 4 waves instead of 16: the waves of
+  // one workgroup start one after the other and the launch waits for the last one's loads (tools/rc_timing.py)
+  static const int forced = [] { const char *e = std::getenv("SABC_RC_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
+  const int block = forced ? forced : (rows < 0 || (np <= 64 && rows <= (int64_t)24 * (256 / np))) ? 256 : 1024;
   if (pv) {
     x.pv = *pv; x.seq = seq; x.silent = silent ? 1 : 0;
-    hipLaunchKernelGGL(k_reduce_control<true>, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
+    hipLaunchKernelGGL(k_reduce_control<true>, dim3(1), dim3(block), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
   } else {
-    hipLaunchKernelGGL(k_reduce_control<false>, dim3(1), dim3(1024), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
+    hipLaunchKernelGGL(k_reduce_control<false>, dim3(1), dim3(block), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
   }
   return SABC_LAUNCH_RC();
 }

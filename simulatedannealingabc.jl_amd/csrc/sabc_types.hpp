@@ -4,6 +4,12 @@
 #include <stdint.h>
 #include "../../include/sabc_hip.h"
 
+#if defined(__HIPCC__)
+#define SABC_TYPES_HD __host__ __device__
+#else
+#define SABC_TYPES_HD
+#endif
+
 namespace sabc {
 
 constexpr int kMaxPara = SABC_MAX_PARA;
@@ -76,13 +82,30 @@ struct ControlArgs {
 };
 
 // Pinned, host-visible words the control kernel posts to so that the host can learn n_accept
-// (the resample test of :340) by polling instead of draining the stream.
+// (the resample test of :340) by polling instead of draining the stream.  Two 8-byte words, each carrying the low 32 bits
+// of the step's sequence number in its upper half and written with ONE store: a reader that finds the number in both has
+// the payload -- no fence between payload and flag (a system-scope fence in the control kernel is a write-back of the L2:
+// 2.6 us of a 9.7 us launch, tools/rc_timing.py).
+//   w0 = seq32 << 32 | n_accept bits 0..31
+//   w1 = seq32 << 32 | halted << 31 | (-error) << 23 | n_accept bits 32..54
 struct Mailbox {
-  volatile int64_t seq;
-  volatile int64_t n_accept;
-  volatile int32_t error;
-  volatile int32_t halted;
+  volatile uint64_t w0, w1;
 };
+inline constexpr uint64_t kMailboxEmpty = ~0ull;        // what the host initialises the ring with
+SABC_TYPES_HD inline void mailbox_pack(int64_t seq, int64_t n_accept, int32_t error, int32_t halted, uint64_t *w0, uint64_t *w1) {
+  const uint64_t s32 = (uint64_t)(uint32_t)seq << 32, na = (uint64_t)n_accept;
+  *w0 = s32 | (na & 0xFFFFFFFFull);
+  *w1 = s32 | ((uint64_t)(halted ? 1 : 0) << 31) | ((uint64_t)((uint32_t)(-error) & 0xFFu) << 23) | ((na >> 32) & 0x7FFFFFull);
+}
+// false while the step's words have not both arrived
+SABC_TYPES_HD inline bool mailbox_unpack(uint64_t w0, uint64_t w1, int64_t seq, int64_t *n_accept, int32_t *error, int32_t *halted) {
+  const uint32_t s32 = (uint32_t)seq;
+  if ((uint32_t)(w0 >> 32) != s32 || (uint32_t)(w1 >> 32) != s32) return false;
+  *n_accept = (int64_t)((w0 & 0xFFFFFFFFull) | ((w1 & 0x7FFFFFull) << 32));
+  *error = -(int32_t)((w1 >> 23) & 0xFFu);
+  *halted = (int32_t)((w1 >> 31) & 1u);
+  return true;
+}
 constexpr int kMailboxRing = 8;          // slot = seq % kMailboxRing; the host lags by at most 2 steps
 
 // Layout of the fused per-update sums ("partials"): one row of `np` doubles.

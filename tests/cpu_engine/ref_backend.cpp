@@ -244,14 +244,17 @@ class RefBackend : public Backend {
     if (!control_step(cb_, a, hist_.data(), stage_)) { post_error_if_any(a); return 0; }
     if (a.notify_seq) {
       Mailbox &mb = ring_[a.notify_seq % kMailboxRing];
-      mb.n_accept = cb_.n_accept; mb.error = cb_.error; mb.halted = cb_.halt; mb.seq = a.notify_seq;
+      uint64_t w0, w1;
+      mailbox_pack(a.notify_seq, cb_.n_accept, cb_.error, cb_.halt, &w0, &w1);     // the product's packing, round trip
+      mb.w0 = w0; mb.w1 = w1;
     }
     return 0;
   }
   int wait_notify(int64_t seq, int64_t *n_accept, int *error, int *halted) override {
     const Mailbox &mb = ring_[seq % kMailboxRing];
-    if (mb.seq != seq) return -1;    // the synchronous backend must already have posted it
-    *n_accept = mb.n_accept; *error = mb.error; *halted = mb.halted;
+    int32_t e = 0, hl = 0;
+    if (!mailbox_unpack(mb.w0, mb.w1, seq, n_accept, &e, &hl)) return -1;    // the synchronous backend must already have posted it
+    *error = e; *halted = hl;
     return 0;
   }
   int read_control(ControlBlock *out) override { *out = cb_; return 0; }
@@ -428,7 +431,9 @@ class RefBackend : public Backend {
   void post_error_if_any(const ControlArgs &a) {
     if (a.notify_seq && cb_.error == SABC_ERR_COMM) {
       Mailbox &mb = ring_[a.notify_seq % kMailboxRing];
-      mb.n_accept = cb_.n_accept; mb.error = cb_.error; mb.halted = cb_.halt; mb.seq = a.notify_seq;
+      uint64_t w0, w1;
+      mailbox_pack(a.notify_seq, cb_.n_accept, cb_.error, cb_.halt, &w0, &w1);
+      mb.w0 = w0; mb.w1 = w1;
     }
   }
   int p2p_barrier(bool guarded) override {
@@ -522,7 +527,9 @@ class RefBackend : public Backend {
   std::vector<int64_t> idx_, slot_;
   int64_t cdf_len_[kMaxStats] = {0};
   ControlBlock cb_{};
-  Mailbox ring_[kMailboxRing] = {};
+  Mailbox ring_[kMailboxRing] = {{kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty},
+                                 {kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty}, {kMailboxEmpty, kMailboxEmpty}};
+  static_assert(kMailboxRing == 8, "initialiser above");
   double stage_[kMaxPartials] = {0};
   double ess_ = 0.0;
 };
