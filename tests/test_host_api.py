@@ -144,3 +144,37 @@ def test_p2p_descriptor_size_matches_the_header():
     assert int(re.search(r"#define SABC_P2P_MAX_WORLD (\d+)", hdr).group(1)) == sabc_amd._lib.P2P_MAX_WORLD
     assert int(re.search(r"#define SABC_MAX_PARA (\d+)", hdr).group(1)) == sabc_amd._lib.MAX_PARA
     assert int(re.search(r"#define SABC_MAX_JOINT_PARA (\d+)", hdr).group(1)) == sabc_amd._lib.MAX_JOINT_PARA
+
+
+def test_mailbox_words_round_trip(tmp_path):
+    """The two 8-byte words the control kernel posts to the host (csrc/sabc_types.hpp: mailbox_pack / mailbox_unpack): every
+    field survives, including n_accept beyond 2^32, every SABC_ERR_* a device step can raise, sequence numbers beyond 2^32;
+    a word pair whose halves belong to different steps (the host read between the two stores) does not unpack."""
+    import subprocess
+    src = tmp_path / "mbox.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "simulatedannealingabc.jl_amd/csrc/sabc_types.hpp"
+using namespace sabc;
+int main() {
+  const int64_t seqs[] = {1, 2, 7, 4294967295ll, 4294967296ll + 5, 123456789012ll};
+  const int64_t accs[] = {0, 1, 4294967295ll, 4294967296ll, 5000000000000ll, (1ll << 54) - 1};
+  const int32_t errs[] = {0, SABC_ERR_ZERO_MEAN_U, SABC_ERR_NOT_POSDEF, SABC_ERR_COMM, SABC_ERR_STATE, SABC_ERR_CALLBACK};
+  int bad = 0;
+  for (int64_t seq : seqs) for (int64_t na : accs) for (int32_t e : errs) for (int32_t h = 0; h < 2; ++h) {
+    uint64_t w0, w1, v0, v1;
+    mailbox_pack(seq, na, e, h, &w0, &w1);
+    int64_t na2 = -1; int32_t e2 = 1, h2 = -1;
+    if (!mailbox_unpack(w0, w1, seq, &na2, &e2, &h2) || na2 != na || e2 != e || h2 != h) ++bad;
+    if (mailbox_unpack(w0, w1, seq + 1, &na2, &e2, &h2)) ++bad;                 // another step's number
+    mailbox_pack(seq + 8, na, e, h, &v0, &v1);                                  // the slot's next occupant (ring of 8)
+    if (mailbox_unpack(v0, w1, seq + 8, &na2, &e2, &h2) || mailbox_unpack(w0, v1, seq, &na2, &e2, &h2)) ++bad;   // torn
+    if (mailbox_unpack(kMailboxEmpty, kMailboxEmpty, seq, &na2, &e2, &h2) && (uint32_t)seq != 0xFFFFFFFFu) ++bad;
+  }
+  std::printf("%d\n", bad);
+  return bad != 0;
+}
+''')
+    exe = tmp_path / "mbox"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", ROOT, "-o", str(exe), str(src)])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "0"
