@@ -96,7 +96,7 @@ typedef struct {
   double  prior_d[SABC_MAX_PARA]; /* truncated Normal: upper bound (others: unused) */
   int32_t prior_joint;            /* 0: product of the univariate families above | 1: MvNormal(mu, Sigma) over all n_para
                                      dimensions (d <= SABC_MAX_JOINT_PARA): mu = prior_a[0..d), Sigma = L L' with L = prior_chol | 2: host callbacks
-                                     (sabc_set_host_prior; SABC_MODEL_HOST only; prior_kind etc. unused) | 3: device code
+                                     (sabc_set_host_prior; next to any simulator; prior_kind etc. unused) | 3: device code
                                      in the simulator's HIP source (SABC_MODEL_USER only: sabc_user_prior_sample /
                                      sabc_user_prior_logpdf next to sabc_user_simulate; prior_kind etc. unused) */
   int32_t reserved2;
@@ -142,8 +142,10 @@ typedef int (*sabc_simulate_fn)(void *ctx, const double *theta, const int64_t *i
                                 double *rho_out);
 
 /* SimulatedAnnealingABC.jl:151 takes ANY Distributions.Distribution as prior.  One that is not among the families of
-   sabc_config can be supplied as two host callbacks -- sabc_config::prior_joint = 2, together with SABC_MODEL_HOST only (the
-   per-particle body is then already cut at the host):
+   sabc_config can be supplied as two host callbacks -- sabc_config::prior_joint = 2.  Next to SABC_MODEL_HOST the per-particle
+   body is already cut at the host; next to a device-coded simulator (built in or from source) it is cut there for the
+   log density alone: proposal kernel -> logpdf on the host -> the simulator as its own launch over the proposals inside the
+   support -> accept kernel (same Philox streams as the fused kernel: the same run as with the prior as data):
      sample:  rand(prior) for the m particles `ids` (:174), theta_out column-major m x d;
      logpdf:  logpdf(prior, theta) for m parameter vectors (:314, :318), theta column-major m x d; -inf outside the support.
    Both return 0 on success.  The library calls `logpdf` once per (half-)batch of an update with the proposals followed by

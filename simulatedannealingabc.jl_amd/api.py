@@ -137,8 +137,10 @@ def _dist_env(distributed):
 
 
 def as_prior(prior, seed=None):
-    """The reference takes ANY Distributions.Distribution (:151).  Here: the families that exist as data, or -- next to a
-    host-callable f_dist -- a HostPrior / a scipy.stats frozen distribution / a list of univariate ones (host callbacks)."""
+    """The reference takes ANY Distributions.Distribution (:151).  Here: the families that exist as data (evaluated inside the
+    fused kernel), or a HostPrior / a scipy.stats frozen distribution / a list of univariate ones: rand and logpdf are host
+    callbacks then, next to a host-callable f_dist or next to a device-coded simulator (which then runs as its own launch
+    between the proposal and the accept kernel)."""
     if isinstance(prior, Distribution):
         return prior
     from .distributions import from_scipy
@@ -210,9 +212,6 @@ def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.
     if alg not in _ALGORITHMS:                                                # :462-464
         raise SABCError(-5, f"Argument `algorithm` must be :multi_eps or :single_eps, not `{algorithm}`!")
     prior = as_prior(prior, seed)
-    if getattr(prior, "host_prior", False) and isinstance(f_dist, DeviceDistance) and not isinstance(f_dist, HostDistance):
-        raise TypeError("a host-callback prior (HostPrior / scipy.stats) needs a host-callable f_dist: a device-coded simulator "
-                        "evaluates the prior inside its fused kernel and needs it as data")
     if getattr(prior, "source_prior", False) and getattr(f_dist, "model_id", None) != _lib.MODEL_USER:
         raise TypeError("a SourcePrior is device code inside the simulator's HIP source: f_dist must be a DeviceSource")
     if not isinstance(f_dist, DeviceDistance):

@@ -72,7 +72,7 @@ int Engine::validate() {
       if (shard_n_local(sh_, r) < 2) return fail(SABC_ERR_BAD_CONFIG, "every shard needs at least two particles");
   const double *p = cfg_.model_params;
   bool ok = false;
-  host_mode_ = cfg_.model_id == SABC_MODEL_HOST;
+  host_mode_ = cfg_.model_id == SABC_MODEL_HOST || cfg_.prior_joint == 2;    // the per-particle body is cut at the host
   switch (cfg_.model_id) {
     case SABC_MODEL_HOST:
     case SABC_MODEL_USER:
@@ -98,8 +98,6 @@ int Engine::validate() {
   if (cfg_.prior_joint < 0 || cfg_.prior_joint > 3) return fail(SABC_ERR_BAD_CONFIG, "unknown joint prior");
   if (cfg_.prior_joint == 3 && cfg_.model_id != SABC_MODEL_USER)
     return fail(SABC_ERR_BAD_CONFIG, "a prior from device source travels in the simulator's source (SABC_MODEL_USER)");
-  if (cfg_.prior_joint == 2 && cfg_.model_id != SABC_MODEL_HOST)
-    return fail(SABC_ERR_BAD_CONFIG, "a host-callback prior needs a host-callback simulator (SABC_MODEL_HOST)");
   if (cfg_.prior_joint == 1) {
     if (d > kMaxJointPara) return fail(SABC_ERR_BAD_CONFIG, "an MvNormal prior as data takes at most 8 parameters");
     for (int k = 0; k < d; ++k)

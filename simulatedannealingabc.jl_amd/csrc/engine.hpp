@@ -196,7 +196,7 @@ class Engine {
   bool population_replaced_ = true;                 // the particles may lie anywhere relative to ControlBlock::pivot
 
   int np_ = 0, eps_len_ = 1;
-  bool host_mode_ = false;                          // f_dist is a host callback (SABC_MODEL_HOST)
+  bool host_mode_ = false;                          // f_dist (SABC_MODEL_HOST) and / or the prior (prior_joint = 2) are host callbacks
   ControlBlock cb_;                                 // host mirror, current after every public call
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};

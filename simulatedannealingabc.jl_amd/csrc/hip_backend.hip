@@ -68,6 +68,7 @@ HipBackend::~HipBackend() {
   if (host_gate_) (void)hipHostFree(host_gate_);
   if (dev_thp_) (void)hipFree(dev_thp_);
   if (dev_aux_) (void)hipFree(dev_aux_);
+  if (dev_rho_prop_) (void)hipFree(dev_rho_prop_);
   if (host_flag_) (void)hipHostFree(host_flag_);
   if (host_done_dev_) (void)hipFree(host_done_dev_);
   if (host_acc_dev_) (void)hipFree(host_acc_dev_);
@@ -267,7 +268,11 @@ int HipBackend::profile_get(int kernel, double *total_ms, int64_t *launches) {
   return 0;
 }
 
-// ---- host-simulator mode (SABC_MODEL_HOST) ---------------------------------------------------
+// ---- host mode: f_dist (SABC_MODEL_HOST) and / or the prior (prior_joint = 2) are host callbacks ----
+// A prior that lives in host callbacks next to a DEVICE-coded simulator (any Distribution of the reference next to a built-in
+// or source-compiled f_dist) takes the same cut -- k_host_propose -> logpdf(prior, .) on the host -> the simulator as its own
+// launch over the gated proposals (k_simulate_batch, the fused kernel's streams) -> k_host_accept -- with one chunk per half
+// batch: the callback is the log density alone, there is no host simulation to overlap.
 // f_dist is the caller's function (SimulatedAnnealingABC.jl:315), so every half batch is cut at the host:
 //   k_host_propose (device) -> f_dist on the proposals inside the prior's support (host) -> k_host_accept (device).
 // What the library adds around the callback is kept off the critical path:
@@ -297,6 +302,8 @@ int HipBackend::ensure_host_buffers() {
   // what only the device reads again: the proposals and (log prior, log factor) of the half batch in flight
   HB_CHECK(hipMalloc((void **)&dev_thp_, (size_t)m_.d * cap * sizeof(double)), "hipMalloc(proposals)");
   HB_CHECK(hipMalloc((void **)&dev_aux_, 2 * cap * sizeof(double)), "hipMalloc(log prior, log factor)");
+  if (m_.model_id != SABC_MODEL_HOST)                    // a device-coded simulator next to a host prior: its distances stay on the device
+    HB_CHECK(hipMalloc((void **)&dev_rho_prop_, (size_t)m_.s * cap * sizeof(double)), "hipMalloc(proposals' distances)");
   HB_CHECK(hipHostMalloc((void **)&host_flag_, kHostMaxChunks * sizeof(unsigned long long), hipHostMallocMapped), "hipHostMalloc(chunk flags)");
   for (int i = 0; i < kHostMaxChunks; ++i) host_flag_[i] = 0ull;
   HB_CHECK(hipHostGetDevicePointer((void **)&host_flag_dev_, host_flag_, 0), "hipHostGetDevicePointer(chunk flags)");
@@ -343,7 +350,8 @@ int HipBackend::wait_host_flag(int ch, unsigned long long seq) {
 }
 
 int HipBackend::host_prior_simulate() {
-  if (!host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
+  const bool device_sim = m_.model_id != SABC_MODEL_HOST;
+  if (!device_sim && !host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
   if (ensure_host_buffers()) return -1;
   const int d = m_.d, s = m_.s;
   const int64_t n = sh_.n_local;
@@ -359,6 +367,16 @@ int HipBackend::host_prior_simulate() {
     host_cb_seconds_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc) { err_ = "the host prior's sample callback failed"; return -1; }
     if (n > 0) HB_CHECK(hipMemcpy2DAsync(pop_[cur_], pitch, th, w, w, (size_t)d, hipMemcpyHostToDevice, stream_), "upload theta");
+    if (device_sim) {
+      // f_dist on the device (:175), the streams of the fused initialisation kernel (particle id, iteration 0); the pinned
+      // staging array is mapped into the device: the simulator reads theta [d][n] straight from it
+      if (n > 0) {
+        HB_LAUNCH(launch_simulate_batch(m_, host_thp_dev_, n, (uint64_t)sh_.gid0, 0, dev_rho_prop_, stream_, rtc()), "k_simulate_batch");
+        HB_CHECK(hipMemcpy2DAsync(rho_, pitch, dev_rho_prop_, w, w, (size_t)s, hipMemcpyDeviceToDevice, stream_), "rho");
+      }
+      HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+      return 0;
+    }
   } else {
     HB_LAUNCH(launch_host_prior(m_, pop_ptrs(cur_), stream_), "k_host_prior");
     if (n > 0) HB_CHECK(hipMemcpy2DAsync(th, w, pop_[cur_], pitch, w, (size_t)d, hipMemcpyDeviceToHost, stream_), "download theta");
@@ -376,14 +394,15 @@ int HipBackend::host_prior_simulate() {
 }
 
 int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt) {
-  if (!host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
+  const bool device_sim = m_.model_id != SABC_MODEL_HOST;
+  if (!device_sim && !host_fn_) { err_ = "no host simulator set (sabc_set_host_simulator)"; return -1; }
   if (lo < 0 || cnt < 0 || lo + cnt > sh_.n_local) { err_ = "host_update_range: range outside the shard"; return -1; }
   if (cnt == 0) return 0;
   if (ensure_host_buffers()) return -1;
   const int d = m_.d, s = m_.s;
   const bool host_prior = m_.prior_joint == 2;
   if (host_prior && !prior_logpdf_fn_) { err_ = "no host prior set (sabc_set_host_prior)"; return -1; }
-  const int64_t chunk = host_chunk_size(cnt);
+  const int64_t chunk = device_sim ? ((cnt + kBlock - 1) / kBlock) * kBlock : host_chunk_size(cnt);
   const int n_chunks = (int)((cnt + chunk - 1) / chunk);
   const unsigned long long seq = ++host_seq_;
   // ONE launch proposes the whole half batch (:311-314); it signals its chunks as they complete
@@ -412,6 +431,16 @@ int HipBackend::host_update_range(const StepArgs &c, const PartnerView &pv, int6
         host_lp2_[(size_t)(cnt + t0 + t)] = host_lp_[(size_t)(tn + t)];
         host_gate_[(size_t)(t0 + t)] = host_lp2_[(size_t)(t0 + t)] > -INFINITY ? 1 : 0;
       }
+    }
+    if (device_sim) {
+      // the simulator on the device, over the proposals the host's gate bytes let through (mapped memory: read in place)
+      prof_begin(SABC_KERNEL_UPDATE);
+      HB_LAUNCH(launch_simulate_batch(m_, dev_thp_, cnt, (uint64_t)(sh_.gid0 + lo), c.iter, dev_rho_prop_, stream_, rtc(), host_gate_dev_),
+                "k_simulate_batch");
+      HB_LAUNCH(launch_host_accept(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), lo, cnt, 0, cnt, dev_thp_, dev_aux_, dev_rho_prop_,
+                                   host_lp2_dev_, host_acc_dev_, stream_), "k_host_accept");
+      prof_end(SABC_KERNEL_UPDATE);
+      return 0;      // (nothing to wait for: the next half batch's proposal kernel is ordered behind these on the stream)
     }
     // only proposals inside the prior's support are simulated (:314-315): compact them for the callback
     host_ids_.resize((size_t)tn); host_where_.resize((size_t)tn);

@@ -157,6 +157,7 @@ class HipBackend : public Backend {
   double *host_thp_dev_ = nullptr, *host_rho_dev_ = nullptr, *host_cur_dev_ = nullptr, *host_lp2_dev_ = nullptr;
   unsigned char *host_gate_ = nullptr, *host_gate_dev_ = nullptr;      // one byte per proposal: inside the prior's support?
   double *dev_thp_ = nullptr, *dev_aux_ = nullptr;                     // device memory: proposals, (log prior, log factor)
+  double *dev_rho_prop_ = nullptr;                                     // ... and, for a device-coded simulator next to a host prior, their distances
   static constexpr int kHostMaxChunks = 64;
   unsigned long long *host_flag_ = nullptr, *host_flag_dev_ = nullptr;   // per chunk: the proposal kernel posts, the host polls
   unsigned int *host_done_dev_ = nullptr;

@@ -1919,20 +1919,21 @@ int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, do
 }
 
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
-                          double *rho_out, hipStream_t stream, const RtcKernels *rtc) {
+                          double *rho_out, hipStream_t stream, const RtcKernels *rtc, const unsigned char *gate) {
   if (n <= 0) return 0;
   if (m.model_id == SABC_MODEL_USER) {
     if (!rtc || !rtc->simulate_batch) return (int)hipErrorInvalidValue;
     return module_launch(rtc->simulate_batch, (unsigned)n_blocks(n), kBlock, stream, nullptr, nullptr, m, theta, n, pid0, iter,
-                         rho_out);
+                         rho_out, gate);
   }
-  if (m.model_id == SABC_MODEL_GK) {
+  if (m.model_id == SABC_MODEL_GK) {                  // (the gate is not looked at: the wave-cooperative simulator is a fixed
+                                                      // amount of arithmetic for any theta, and gated-out rows are never read)
     hipLaunchKernelGGL(k_simulate_gk, dim3(gk_blocks(n)), dim3(kBlock), 0, stream, m, theta, n, n, pid0, iter, 0,
                        (double *)nullptr, rho_out, n);
     return SABC_LAUNCH_RC();
   }
   const dim3 grid((unsigned)n_blocks(n)), block(kBlock);
-#define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out)
+#define CALL(M, D, S) hipLaunchKernelGGL((k_simulate_batch<M, D, S>), grid, block, 0, stream, m, theta, n, pid0, iter, rho_out, gate)
   SABC_DISPATCH_MODEL(m, CALL);
 #undef CALL
   return SABC_LAUNCH_RC();

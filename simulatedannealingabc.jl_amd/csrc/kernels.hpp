@@ -188,7 +188,7 @@ int launch_stats_rt(const ModelDesc &m, const ControlBlock *cb, PopPtrs pp, doub
 int launch_cdf_eval(const double *knots, int64_t len, const double *q, int64_t m, double *out, hipStream_t stream);
 int launch_cdf_apply_matrix(CdfPtrs cdf, int s, const double *rho, int64_t m, double *u_out, hipStream_t stream);
 int launch_simulate_batch(const ModelDesc &m, const double *theta, int64_t n, uint64_t pid0, uint64_t iter,
-                          double *rho_out, hipStream_t stream, const RtcKernels *rtc = nullptr);
+                          double *rho_out, hipStream_t stream, const RtcKernels *rtc = nullptr, const unsigned char *gate = nullptr);
 int launch_prior_op(const ModelDesc &m, uint64_t pid0, int64_t n, double *theta, double *lp, hipStream_t stream,
                     const RtcKernels *rtc = nullptr);
 int launch_normal_pairs(uint64_t seed, uint64_t pid0, uint32_t purpose, uint64_t iter, uint32_t k, int64_t m, double *out,

@@ -272,17 +272,23 @@ k_prior_op_t(const ModelDesc m, const uint64_t pid0, const int64_t n, double *__
   lp[i] = prior_logpdf<D>(m, th);
 }
 
+// gate (optional, one byte per row): 0 = this theta lies outside the prior's support (SimulatedAnnealingABC.jl:314-315): it is
+// not simulated, its distances are written as 0 and never looked at
 template <int MODEL, int D, int S>
 __global__ void __launch_bounds__(kBlock)
 k_simulate_batch(const ModelDesc m, const double *__restrict__ theta, const int64_t n, const uint64_t pid0,
-                 const uint64_t iter, double *__restrict__ rho_out) {
+                 const uint64_t iter, double *__restrict__ rho_out, const unsigned char *__restrict__ gate) {
   rng_tables_init();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   double th[D], rho[S];
 #pragma unroll
-  for (int k = 0; k < D; ++k) th[k] = theta[(int64_t)k * n + i];
-  Sim<MODEL, D, S>::run(m, th, pid0 + (uint64_t)i, iter, rho);
+  for (int j = 0; j < S; ++j) rho[j] = 0.0;
+  if (!gate || gate[i]) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) th[k] = theta[(int64_t)k * n + i];
+    Sim<MODEL, D, S>::run(m, th, pid0 + (uint64_t)i, iter, rho);
+  }
 #pragma unroll
   for (int j = 0; j < S; ++j) rho_out[(int64_t)j * n + i] = rho[j];
 }

@@ -207,8 +207,9 @@ function prior_descriptors(d::Distribution)
 end
 
 # ANY other Distribution (SimulatedAnnealingABC.jl:151): rand(prior) (:174) and logpdf(prior, θ) (:314, :318) stay Julia calls,
-# handed to the library as two host callbacks (sabc_set_host_prior, prior_joint = 2) -- possible next to a host `f_dist` only,
-# where the per-particle body is already cut at the host.
+# handed to the library as two host callbacks (sabc_set_host_prior, prior_joint = 2) -- next to a Julia `f_dist`, where the
+# per-particle body is already cut at the host, or next to a device-coded one, which then runs as its own launch between the
+# proposal and the accept kernel.
 is_data_prior(d::Distribution) =
     d isa MvNormal || d isa Union{Normal,Uniform,Exponential,LogNormal,Gamma,Beta,Truncated{<:Normal}} ||
     ((hasproperty(d, :v) || hasproperty(d, :dists)) &&
@@ -296,8 +297,6 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     source_prior = prior isa SourcePrior
     source_prior && !(f_dist isa DeviceSource) && error("a SourcePrior is device code inside the HIP source of a DeviceSource")
     host_prior = !source_prior && !is_data_prior(prior)
-    host_prior && !(f_dist isa HostDistance) &&
-        error("a prior that is not Normal / Uniform / Exponential / LogNormal / Gamma / Beta / truncated(Normal) / a product of those / MvNormal needs a Julia function as f_dist")
     pd = (host_prior || source_prior) ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
     joint, chol = host_prior ? (Int32(2), Float64[]) : source_prior ? (Int32(3), Float64[]) : prior_chol(prior)
     p = params(f_dist)
@@ -344,6 +343,11 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
             check(h[], ccall((:sabc_set_host_prior, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                              h[], pcb[1], pcb[2], C_NULL))
         end
+    elseif host_prior                                  # any Distribution next to a device-coded simulator
+        pcb = host_prior_callbacks(prior)
+        HOST_CALLBACKS[h[]] = (nothing, f_dist, pcb, prior)
+        check(h[], ccall((:sabc_set_host_prior, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                         h[], pcb[1], pcb[2], C_NULL))
     end
     h
 end
@@ -481,7 +485,7 @@ function update_population!(res::SABCresult, f_dist::Function, prior::Distributi
     f_dist isa DeviceDistance && return invoke(update_population!, Tuple{SABCresult,DeviceDistance,Distribution}, res, f_dist, prior; kwargs...)
     haskey(HOST_CALLBACKS, handle_of(res)[]) || error("this SABCresult was not created with a host `f_dist`")
     hd = HOST_CALLBACKS[handle_of(res)[]][2]
-    hd.f === f_dist || error("`f_dist` differs from the one this SABCresult was initialised with")
+    (hd isa HostDistance && hd.f === f_dist) || error("`f_dist` differs from the one this SABCresult was initialised with")
     own = (:n_simulation, :v, :δ, :proposal, :resample, :checkpoint_history, :show_progressbar, :show_checkpoint)
     mine = (; (k => v for (k, v) in kwargs if k in own)...)
     invoke(update_population!, Tuple{SABCresult,DeviceDistance,Distribution}, res, hd, prior; mine...)

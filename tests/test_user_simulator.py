@@ -345,3 +345,31 @@ def test_prior_from_source_equals_the_same_prior_as_host_callbacks(S, O, gpu, pr
     mix_cdf = lambda x: W_MIX * stats.gamma(2, scale=0.5).cdf(x) + (1 - W_MIX) * stats.gamma(3, scale=1.0).cdf(x)
     assert stats.kstest(th[0], mix_cdf).pvalue > 1e-3 and stats.kstest(th[1], stats.uniform(0.5, 1.5).cdf).pvalue > 1e-3
     np.testing.assert_allclose(lp, logpdf(th.T), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_host_prior_next_to_a_simulator_from_source(S, gpu, prop):
+    """A prior in HOST callbacks next to a simulator compiled from source (the third way to give a DeviceSource a prior, after
+    data and SourcePrior): the run-time compiled k_simulate_batch runs between the proposal and the accept kernel, over the
+    proposals the host's gate bytes let through.  Same run as with the prior as data."""
+    from scipy import stats
+    n, k = 1500, 6
+    params = [0.1] + DECAY_OBS
+    prior = S.product_distribution([S.Uniform(0.5, 6.0), S.Uniform(0.05, 2.0)])
+    kw = dict(n_particles=n, n_simulation=(k + 1) * n, proposal=hip_proposal(S, prop, 2), resample=n // 3, algorithm="multi_eps", seed=SEED)
+    ref = S.sabc(S.DeviceSource(DECAY_SRC, 2, 2, params), prior, **kw)
+    helper = S.SabcHandle(n_particles=256, model=S.GaussianIID(n_obs=10, sd=1.0, obs_mean=0.0), prior=prior, seed=SEED)
+    outside = []
+
+    def logpdf(th):
+        lp = stats.uniform(0.5, 5.5).logpdf(th[:, 0]) + stats.uniform(0.05, 1.95).logpdf(th[:, 1])
+        outside.append(int(np.isneginf(lp).sum()))
+        return lp
+    hp = S.HostPrior(lambda ids: helper.prior(int(ids[0]), len(ids))[0].T, logpdf, 2, univariate=False)
+    res = S.sabc(S.DeviceSource(DECAY_SRC, 2, 2, params), hp, **kw)
+    helper.close()
+    assert (res.state.n_accept, res.state.n_resampling) == (ref.state.n_accept, ref.state.n_resampling) and ref.state.n_resampling >= 1
+    np.testing.assert_allclose(res.population, ref.population, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(res.ρ, ref.ρ, rtol=1e-9, atol=1e-12)
+    assert sum(outside) > 0                              # the gate was exercised: some proposals left the support
