@@ -20,6 +20,8 @@ MODELS = {
     # BASELINE configs 1-2
     "gauss1_cfg2": dict(model=("GaussianIID", dict(n_obs=100, sd=1.0, obs_mean=y_obs_mean())),
                         prior=[("N", 0.0, 2.0)], s=1),
+    # a short simulation (20 draws): what a host callable transcribing the device's simulator can afford (tests of the host-f_dist path)
+    "gauss1_small": dict(model=("GaussianIID", dict(n_obs=20, sd=1.0, obs_mean=1.4)), prior=[("N", 0.0, 2.0)], s=1),
     # test/runtests.jl:86-88
     "gauss2_meansd": dict(model=("GaussianIID", dict(n_obs=100, sd=1.0, obs_mean=0.0)),
                           prior=[("N", 0.0, 1.0), ("U", 0.0, 1.0)], s=1),

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--silence-init", type=int, default=0, help="the same inside sabc_initialize")
     ap.add_argument("--silence-selftest", type=int, default=0, help="rank 1 posts nothing in the transport's self-test (first contact fails)")
     ap.add_argument("--p2p-timeout-ms", type=float, default=0.0)
+    ap.add_argument("--host-fdist", type=int, default=0, help="hip engine, case gauss1_small: f_dist as a HOST callable that draws the device simulator's Philox blocks")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
 
@@ -57,6 +58,13 @@ def main():
     else:
         Handle = S.SabcHandle
     model, prior = hip_model_prior(S, a.case)
+    if a.host_fdist:
+        assert a.engine == "hip" and a.case == "gauss1_small"
+        from oracle import oracle as O
+        O.build()
+        from tests.test_gpu_host_fdist import gauss_iid_keyed
+        kw = MODELS[a.case]["model"][1]
+        model = S.HostDistance(gauss_iid_keyed(O, kw["n_obs"], kw["obs_mean"]), n_stats=1, n_para=1, univariate=True, with_ids=True)
     d = len(MODELS[a.case]["prior"])
     alg = S._lib.ALG_MULTI_EPS if a.alg == "multi_eps" else S._lib.ALG_SINGLE_EPS
     h = Handle(n_particles=a.n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)

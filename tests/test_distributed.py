@@ -296,6 +296,25 @@ def test_rccl_two_gpus(S, gpu, tmp_path, case, alg, prop, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_hip_host_simulator_on_two_shards(S, gpu, tmp_path, prop):
+    """f_dist as a HOST callable on a sharded population (two processes, gloo hooks): every rank's callback gets its own
+    shard's proposals with their GLOBAL particle ids; partners of DifferentialEvolution come from all shards.  The callable
+    draws the Philox blocks of the device-coded Gaussian simulator, so the run must equal the CPU engine with that simulator
+    and the same sharding."""
+    n, k = 1200, 8
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case="gauss1_small", alg="single_eps", prop=prop, n=n,
+                 updates=k, resample=n // 4, **{"host-fdist": 1})
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case="gauss1_small", alg="single_eps", prop=prop, n=n,
+                 updates=k, resample=n // 4)
+    tol = {"rw": 1e-9, "de": 1e-6}[prop]
+    assert list(got["counters"]) == list(ref["counters"]) and got["counters"][2] >= 2
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["rho"], ref["rho"], rtol=tol, atol=tol * 1e-2)
+    np.testing.assert_allclose(got["eps_hist"], ref["eps_hist"], rtol=tol)
+
+
+@pytest.mark.gpu
 def test_nccl_hooks_single_rank(S, gpu):
     """The torch.distributed "nccl" (= RCCL) hooks take raw device pointers on the library's stream:
     exercised here on a 1-rank group (this box has one GPU; the multi-rank transport is the driver's run)."""
