@@ -200,3 +200,32 @@ def test_a_handle_can_be_initialised_again(S, gpu, name, prop):
         np.testing.assert_array_equal(r[1], runs[0][1])
         for a, b in zip(r[2] + r[3], runs[0][2] + runs[0][3]):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_accept_counter_beyond_two_to_the_32(S, gpu, prop):
+    """A long-running chain: n_accept and the resample threshold (n_resampling + 1) * resample far beyond 2^32 (resumed from
+    stored counters).  The device-side resample test, the two mailbox words the host polls (n_accept split at bit 32) and the
+    history must behave exactly as for the same run counted from zero."""
+    from tests.cases import SEED, hip_model_prior, hip_proposal
+    n, k, resample = 4000, 12, 2000
+    offset = resample * 5_000_000                                   # 1e10 > 2^33, a multiple of `resample`: the same firing pattern
+    runs = []
+    for start in (0, offset):
+        model, prior = hip_model_prior(S, "gauss1_cfg2")
+        h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+        h.initialize((k + 1) * n)
+        c = h.counters
+        h.set_counters(c["n_simulation"], c["n_accept"] + start, c["n_resampling"] + start // resample, c["n_population_updates"])
+        h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, 1), resample=resample)
+        runs.append((h.counters, h.get_population(), h.eps, h.history))
+        h.close()
+    (c0, p0, e0, h0), (c1, p1, e1, h1) = runs
+    assert c1["n_accept"] == c0["n_accept"] + offset and c1["n_accept"] > 2 ** 33
+    assert c1["n_resampling"] == c0["n_resampling"] + offset // resample and c0["n_resampling"] >= 3
+    for a, b in zip(p0, p1):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(e0, e1)
+    for a, b in zip(h0, h1):
+        np.testing.assert_array_equal(a, b)
