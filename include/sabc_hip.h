@@ -26,10 +26,13 @@
 extern "C" {
 #endif
 
-#define SABC_ABI_VERSION 4      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
-                                   4: peer-to-peer transport (sabc_comm_p2p_*), launch counters, SABC_MAX_PARA / _STATS 8 -> 16, prior_joint = 3 */
-#define SABC_MAX_PARA 16        /* host-callback and source-compiled simulators: any d, s up to these (the reference takes any */
-#define SABC_MAX_STATS 16       /* length(prior) and any number of distances, SimulatedAnnealingABC.jl:163-167,181)          */
+#define SABC_ABI_VERSION 5      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
+                                   4: peer-to-peer transport (sabc_comm_p2p_*), launch counters, SABC_MAX_PARA / _STATS 8 -> 16, prior_joint = 3;
+                                   5: SABC_MAX_STATS 16 -> 64 (the buffers of sabc_get_epsilon / sabc_set_epsilon / sabc_cdf_apply callers) */
+#define SABC_MAX_PARA 16        /* host-callback and source-compiled simulators: any d up to this (the reference takes any length(prior),      */
+#define SABC_MAX_STATS 64       /* SimulatedAnnealingABC.jl:163) and -- host-callback simulators -- any number of distances up to this (:164-167,181: */
+                                /* summaries of a time series easily number dozens)                                                            */
+#define SABC_MAX_SOURCE_STATS 16 /* a simulator compiled from source: its ECDF index lives in the fused kernel's LDS, s <= 16 */
 #define SABC_MAX_JOINT_PARA 8   /* an MvNormal prior as data: d <= 8 (its Cholesky factor travels in kernel arguments)       */
 #define SABC_MAX_MODEL_PARAMS 32
 

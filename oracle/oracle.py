@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsabc_oracle.so")
 
-MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
+MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 64, 32
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV = 0, 1, 2, 3, 4
 SIMULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int64, C.c_uint64,
                           C.POINTER(C.c_double))
@@ -78,12 +78,18 @@ class UpdateArgs(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (oracle/Makefile)."""
+    """Compile the oracle with gcc (oracle/Makefile).  Safe when several processes ask at once: one builds, the others wait."""
+    import fcntl
     src = os.path.join(_HERE, "sabc_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "sabc_oracle.h"))
-    ):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libsabc_oracle.so"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "sabc_oracle.h")))
+    if force or stale():
+        with open(_LIB_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-B", "libsabc_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 

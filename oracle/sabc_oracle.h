@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define ORC_MAX_PARA 16
-#define ORC_MAX_STATS 16
+#define ORC_MAX_STATS 64
 #define ORC_MAX_MODEL_PARAMS 32
 
 /* model ids (device-coded simulators; see DESIGN.md "Simulators") */

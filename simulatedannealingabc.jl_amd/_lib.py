@@ -15,9 +15,10 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 P2P_DESC_BYTES, P2P_MAX_WORLD = 384, 8
-MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
+MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 64, 32
+MAX_SOURCE_STATS = 16     # simulators compiled from source (SABC_MODEL_USER)
 MAX_JOINT_PARA = 8
 MODEL_HOST, MODEL_GAUSS_IID, MODEL_GAUSS2D, MODEL_GK, MODEL_LV, MODEL_USER = 0, 1, 2, 3, 4, 5
 PRIOR_NORMAL, PRIOR_UNIFORM, PRIOR_EXPONENTIAL, PRIOR_LOGNORMAL, PRIOR_GAMMA, PRIOR_BETA, PRIOR_TRUNCNORMAL = 0, 1, 2, 3, 4, 5, 6
@@ -81,14 +82,19 @@ def sources_newer_than_lib() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 build of every HIP translation unit (csrc/Makefile)."""
+    """hipcc --offload-arch=gfx950 build of every HIP translation unit (csrc/Makefile).  Safe when several processes ask at
+    once (the ranks of a multi-process run start together): one builds, the others wait on the lock."""
     if force or sources_newer_than_lib():
-        cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if verbose or r.returncode:
-            print(r.stdout)
-        if r.returncode:
-            raise RuntimeError("building libsabc_hip.so failed")
+        import fcntl
+        with open(LIB_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or sources_newer_than_lib():
+                cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                if verbose or r.returncode:
+                    print(r.stdout)
+                if r.returncode:
+                    raise RuntimeError("building libsabc_hip.so failed")
     return LIB_PATH
 
 

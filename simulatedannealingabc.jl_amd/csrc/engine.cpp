@@ -66,6 +66,8 @@ int Engine::validate() {
   if (cfg_.n_particles < 1) return fail(SABC_ERR_BAD_CONFIG, "n_particles must be positive");
   const int d = cfg_.n_para, s = cfg_.n_stats;
   if (d < 1 || d > kMaxPara || s < 1 || s > kMaxStats) return fail(SABC_ERR_BAD_CONFIG, "n_para / n_stats out of range");
+  if (cfg_.model_id == SABC_MODEL_USER && s > SABC_MAX_SOURCE_STATS)
+    return fail(SABC_ERR_BAD_CONFIG, "a simulator compiled from source takes at most 16 statistics (its ECDF index lives in the kernel's LDS)");
   if (cfg_.world < 1 || cfg_.rank < 0 || cfg_.rank >= cfg_.world) return fail(SABC_ERR_BAD_CONFIG, "bad rank / world");
   if (cfg_.world > 1)
     for (int r = 0; r < cfg_.world; ++r)

@@ -574,7 +574,7 @@ k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const
 
 // The state hand-over between two population updates (control.hpp), one lane -- on an LDS copy of the control
 // block: the step is a chain of dependent reads and writes of the block, each of which would be a round trip to
-// L2 (~1 us); the workgroup loads the 5.9 KB block once, lane 0 works on the copy, the workgroup writes it back.
+// L2 (~1 us); the workgroup loads the 7 KB block once, lane 0 works on the copy, the workgroup writes it back.
 static_assert(sizeof(ControlBlock) % 8 == 0, "copied as 8-byte words");
 constexpr int kControlWords = (int)(sizeof(ControlBlock) / 8);
 

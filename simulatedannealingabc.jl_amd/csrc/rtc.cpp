@@ -97,7 +97,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   constexpr int kKernels = 7;
   HiprtcApi *api = hiprtc_api();
   if (!api) { *log = "libhiprtc.so could not be loaded: simulators from source need the hipRTC of ROCm"; return -1; }
-  if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_STATS) { *log = "n_para / n_stats out of range"; return -1; }
+  if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_SOURCE_STATS) { *log = "n_para / n_stats out of range (a simulator from source: d <= 16, s <= 16)"; return -1; }
   char tail[2048];
   std::snprintf(tail, sizeof(tail),
                 "\nnamespace sabc {\n"

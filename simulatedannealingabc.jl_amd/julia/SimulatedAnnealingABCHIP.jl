@@ -24,7 +24,7 @@ export sabc, update_population!, RandomWalk, DifferentialEvolution, StretchMove,
 
 const libsabc = get(ENV, "SABC_HIP_LIB", joinpath(@__DIR__, "..", "libsabc_hip.so"))
 
-const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 16, 32
+const MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 64, 32
 const MAX_PARA2 = MAX_PARA * MAX_PARA      # the row-major Cholesky factor of an MvNormal prior
 
 # ---- C structs (must match include/sabc_hip.h field for field) ----
@@ -300,7 +300,7 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     pd = (host_prior || source_prior) ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
     joint, chol = host_prior ? (Int32(2), Float64[]) : source_prior ? (Int32(3), Float64[]) : prior_chol(prior)
     p = params(f_dist)
-    cfg = Ref(CConfig(4, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
+    cfg = Ref(CConfig(5, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
                       padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(getindex.(pd, 3), MAX_PARA, Float64),

@@ -20,12 +20,28 @@ _DEPS = _SRCS + [os.path.join(ROOT, "simulatedannealingabc.jl_amd", "csrc", f)
 
 
 def build():
-    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(p) for p in _DEPS):
+    """Compile the harness if it is older than its sources.  Several processes may ask at once (the ranks of a multi-process
+    test start together): one builds -- into a temporary file, renamed into place -- the others wait on the lock."""
+    import fcntl
+
+    def fresh():
+        return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(p) for p in _DEPS)
+    if fresh():
         return LIB
-    obj = os.path.join(_HERE, "sabc_oracle.o")
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-c", _SRCS[2], "-o", obj])
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off", "-pthread",
-                           "-o", LIB, _SRCS[0], _SRCS[1], obj, "-lm"])
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if fresh():
+            return LIB
+        obj, tmp = os.path.join(_HERE, f"sabc_oracle.{os.getpid()}.o"), LIB + f".{os.getpid()}.tmp"
+        try:
+            subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-c", _SRCS[2], "-o", obj])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math", "-ffp-contract=off", "-pthread",
+                                   "-o", tmp, _SRCS[0], _SRCS[1], obj, "-lm"])
+            os.replace(tmp, LIB)
+        finally:
+            for f in (obj, tmp):
+                if os.path.exists(f):
+                    os.remove(f)
     return LIB
 
 

@@ -63,7 +63,7 @@ def test_zero_distances_are_dropped_from_the_ecdf(S, gpu):
 
 
 def test_maximum_shapes_in_host_mode(S, O, gpu):
-    """d = 8 parameters, s = 8 statistics (SABC_MAX_PARA / SABC_MAX_STATS), both eps schedules, every proposal,
+    """d = 8 parameters, s = 8 statistics (the maxima of rounds 1-2), both eps schedules, every proposal,
     against the oracle driven by the same (deterministic, id-keyed) host simulator.  With 8 statistics the
     multi-eps schedule of :100-117 can leave the (0, 1/2) branch of its beta equation (mean u > 1/2 gives a
     negative beta): the device-side control step must follow the oracle there too."""
@@ -92,7 +92,7 @@ def test_maximum_shapes_in_host_mode(S, O, gpu):
             np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
             np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
     with pytest.raises(S.SABCError):
-        S.sabc(lambda θ: np.zeros(17) + 1, prior, n_particles=100, n_simulation=1000)     # s = 17 > SABC_MAX_STATS
+        S.sabc(lambda θ: np.zeros(65) + 1, prior, n_particles=100, n_simulation=1000)     # s = 65 > SABC_MAX_STATS
 
 
 def test_beyond_eight_dimensions_in_host_mode(S, O, gpu):
@@ -123,6 +123,39 @@ def test_beyond_eight_dimensions_in_host_mode(S, O, gpu):
         np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
         np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
         np.testing.assert_allclose(res.ρ.T, run.rho, rtol=tol, atol=tol)
+
+
+def test_dozens_of_statistics_in_host_mode(S, O, gpu):
+    """A time series as summary statistics: d = 3 parameters, s = 48 distances (one per time point; SABC_MAX_STATS = 64 for
+    host-callback simulators -- the reference takes any number, SimulatedAnnealingABC.jl:164-167,181): 48 ECDF tables, a
+    48-vector of epsilons under :multi_eps (its q^(s/2) terms and c_n at s = 48), rows of 51 doubles in the resample, 103
+    sum columns.  Against the oracle driven by the same id-keyed host simulator."""
+    d, s = 3, 48
+    t = np.linspace(0.0, 4.0, s)
+    obs = 2.0 * np.exp(-0.6 * t) + 0.3
+
+    def f_dist(θ, pid, it):
+        z = np.array([O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b) for b in range(s // 2)]).ravel()
+        return np.abs(θ[0] * np.exp(-θ[1] * t) + θ[2] + 0.05 * z - obs)
+    prior = S.product_distribution([S.Uniform(0.5, 4.0), S.Uniform(0.05, 2.0), S.Normal(0.0, 1.0)])
+    opri = [(O.PRIOR_UNIFORM, 0.5, 4.0), (O.PRIOR_UNIFORM, 0.05, 2.0), (O.PRIOR_NORMAL, 0.0, 1.0)]
+    n, k = 300, 8
+    for alg, prop in (("multi_eps", "rw"), ("single_eps", "de"), ("multi_eps", "stretch")):
+        hd = S.HostDistance(f_dist, n_stats=s, n_para=d, univariate=False, with_ids=True)
+        res = S.sabc(hd, prior, n_particles=n, n_simulation=n * (k + 1), algorithm=alg, proposal=hip_proposal(S, prop, d),
+                     resample=60, seed=SEED)
+        cfg = O.make_config(n_particles=n, n_para=d, n_stats=s, model_id=O.MODEL_HOST, model_params=[], prior=opri, seed=SEED,
+                            algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS, host_fn=O.host_simulator(f_dist, d, s))
+        run = O.OracleRun(cfg)
+        run.initialize(n * (k + 1))
+        run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=60))
+        assert res.population.shape == (n, d) and res.u.shape == (n, s) and len(res.state.ϵ) == (s if alg == "multi_eps" else 1)
+        assert res.state.n_accept == run.counters["n_accept"] and res.state.n_resampling == run.counters["n_resampling"] >= 2
+        tol = {"rw": 1e-8, "stretch": 1e-6, "de": 1e-5}[prop]
+        np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+        np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
+        np.testing.assert_allclose(res.ρ.T, run.rho, rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.array(res.state.ϵ_history), run.history[0], rtol=tol)
 
 
 def test_resample_disabled_and_every_update(S, O, gpu):
