@@ -61,7 +61,8 @@ def cpu_baseline(n, updates, threads, warmup=0, steps=0):
     dt = time.perf_counter() - t0
     out = {"value": updates * n / dt, "unit": "particle-simulations/s", "cores": threads, "kind": "port",
            "sample": f"oracle/sabc_oracle.c (OpenMP), cfg2 n_particles={n}, {updates} population updates, "
-                     f"{dt:.1f} s; CPU restatement, not the Julia reference"}
+                     f"{dt:.1f} s; CPU restatement, not the Julia reference; {threads} threads = the CPU share of a one-GPU box "
+                     f"of this pool ({os.cpu_count()} logical CPUs visible; SABC_CPU_THREADS overrides)"}
     return out, same
 
 
