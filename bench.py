@@ -257,8 +257,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions per process; `value` is their median")
     ap.add_argument("--preheat-seconds", type=float, default=1.0,
-                    help="untimed population updates of the same workload before the first timed region, until this much wall time has passed "
-                         "(the GPU's clocks ramp over the first ~100 ms of load: five cold regions of 4 ms each measured 4.65 -> 5.46e9 in run order)")
+                    help="untimed launches of the bare generator loop (k_rng_peak) before the first timed region, until this much wall time has "
+                         "passed (the GPU's clocks ramp over the first ~100 ms of load: five cold regions of 4 ms each measured 4.65 -> 5.46e9 in run order)")
     ap.add_argument("--p2p", default="auto", choices=["auto", "on", "off"],
                     help="N > 1: the peer-to-peer transport on top of the collectives (auto: on for --dist-backend nccl)")
     ap.add_argument("--all-kernel-events", action="store_true", help="bracket every kernel, not only k_update (adds ~15 us/step)")
@@ -344,7 +344,7 @@ def main():
 
     h = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device, rank=rank, world=world)
     transport, fallback = "none", None
-    preheat = {"seconds": 0.0, "updates": 0}
+    preheat = {"seconds": 0.0, "kernel": "k_rng_peak (1e6 lanes x 50 Philox + Box-Muller pairs)", "launches": 0}
     for rep in range(max(args.repeats, 1)):
         say(f"repeat {rep}")
         if world > 1 and rep == 0:
@@ -365,22 +365,14 @@ def main():
                       "(torch.distributed on device pointers, a Python callback per collective): the line says so in "
                       "config.collectives and transport_degraded", file=sys.stderr, flush=True)
         if rep == 0 and args.preheat_seconds > 0:
-            # bring the device to its sustained clocks with the workload itself (same handle, same kernels); every rank runs the
-            # same number of updates (rank 0 decides when the time is up)
+            # bring the device to its sustained clocks before anything is timed: the bare Philox + Box-Muller loop (k_rng_peak,
+            # the instruction mix of the simulators) for about a second.  Not the workload's own kernels: the chain's state is not
+            # advanced, and a rocprofv3 pass of this command averages k_update over warm-up and timed regions only.
             say("pre-heat")
-            h.initialize(n)
             t_pre = time.perf_counter()
-            while True:
-                h.update(n_simulation=20 * n, proposal=proposal)
-                preheat["updates"] += 20
-                go_on = time.perf_counter() - t_pre < args.preheat_seconds
-                if world > 1:
-                    box = [go_on]
-                    dist.broadcast_object_list(box, src=0)
-                    go_on = box[0]
-                if not go_on:
-                    break
-            torch.cuda.synchronize()
+            while time.perf_counter() - t_pre < args.preheat_seconds:
+                S.op_rng_peak(n_lanes=1_000_000, pairs_per_lane=50, repeats=20, device=device)
+                preheat["launches"] += 20
             preheat["seconds"] = time.perf_counter() - t_pre
         say(f"repeat {rep}: transport {transport}, initialize")
         t_init0 = time.perf_counter()
@@ -460,7 +452,7 @@ def main():
             "metric": "particle-simulations/sec at n_particles=1e6" if args.config == "cfg2" else f"particle-simulations/sec ({args.config})",
             "value": K * n / dt,
             "value_min": K * n / dts[-1], "value_max": K * n / dts[0], "repeats": len(samples),
-            "preheat": dict(preheat, note="untimed updates of the same workload before the first timed region (clock ramp); --preheat-seconds 0 turns it off"),
+            "preheat": dict(preheat, note="untimed launches of the bare generator loop before the first timed region (the device's clocks ramp over the first ~100 ms of load); --preheat-seconds 0 turns it off"),
             "values_in_run_order": [K * n / x["dt"] for x in samples],
             "kernel_us_in_run_order": [(x["kern_ms"] / x["launches"] * 1e3) if x["launches"] else None for x in samples],
             "value_note": "median of `repeats` timed regions in this process (population initialised again, same warm-up, same K updates each)",

@@ -5,7 +5,7 @@ cp simulatedannealingabc.jl_amd/libsabc_hip.so /tmp/lib_orig.so
 for f in tools/exp_libs/lib_*.so; do
   cp $f simulatedannealingabc.jl_amd/libsabc_hip.so
   tag=$(basename $f .so)
-  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmcx_$tag -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $root/gpurun_out/pmcx_$tag.json 2>/dev/null)
+  (cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $root/gpurun_out/pmcx_$tag -- python3 $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --preheat-seconds 0 > $root/gpurun_out/pmcx_$tag.json 2>/dev/null)
 done
 cp /tmp/lib_orig.so simulatedannealingabc.jl_amd/libsabc_hip.so
 python - <<'PY'

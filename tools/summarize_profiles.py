@@ -29,6 +29,9 @@ for cfg in ("cfg2", "cfg3", "cfg4", "cfg5"):
     shutil.copyfile(src, dst)
     rows = list(csv.DictReader(open(src)))
     upd = max((r for r in rows if "k_update" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
+    # share of the run WITHOUT bench.py's pre-heat (k_rng_peak launches before the first timed region, not part of the workload)
+    total = sum(float(r["TotalDurationNs"]) for r in rows if "k_rng_peak" not in r["Name"])
+    upd = dict(upd, Percentage=100.0 * float(upd["TotalDurationNs"]) / total)
     bench = json.loads(open(os.path.join(out, f"prof_{tag}_{cfg}.json")).read().strip().splitlines()[-1])
     lines.append(dict(cfg=cfg, kernel=upd["Name"].split("(")[0], calls=int(upd["Calls"]), rocprof_avg_us=float(upd["AverageNs"]) / 1e3,
                       pct=float(upd["Percentage"]), bench_events_us=bench["roofline"]["avg_launch_us"], value=bench["value"],
