@@ -70,7 +70,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
       double ubar[kMaxStats];
 #endif
       for (int j = 0; j < s; ++j) ubar[j] = cb.sums[1 + j] / n;
-      if (!hostmath::eps_multi(ubar, s, a.v, cb.eps)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
+      if (!hostmath::eps_multi(ubar, s, a.v, cb.eps, cb.beta)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
     } else {
       double tot = 0.0;
       for (int j = 0; j < s; ++j) tot += cb.sums[1 + j];

@@ -63,11 +63,16 @@ SABC_HD inline double tilted_mean_deriv(double b) {
 
 // beta_i of :113: tilted_mean(beta) = ubar_i.  Decreasing in beta, 1/2 at 0, < 1/beta for beta > 0:
 // the root lies in (0, 1/ubar_i].  Newton kept inside the bracket, bisection when it leaves it.
-SABC_HD inline double multi_eps_beta(double ub) {
+// `hint` (optional): the root of the previous population update -- mean u moves by a fraction of a percent per update, so
+// the iteration starts two or three steps from its end instead of at the bracket's end (on the single control lane every
+// step is an expm1, ~1 us; a cold start takes 5-14 of them).  The derivative is written so that it stays finite when
+// expm1(b) overflows (b > 709, i.e. mean u < 0.0014, the late stage of every chain): the literal (e + 1) / e^2 is inf / inf
+// there and sent the iteration into ~50 bisection steps per statistic.
+SABC_HD inline double multi_eps_beta(double ub, double hint = 0.0) {
   if (ub == 0.5) return 0.0;
   const bool mirror = ub > 0.5;                      // tilted_mean(-b) = 1 - tilted_mean(b)
-  if (mirror) ub = 1.0 - ub;
-  double lo = 0.0, hi = 1.0 / ub, b = hi;
+  if (mirror) { ub = 1.0 - ub; hint = -hint; }
+  double lo = 0.0, hi = 1.0 / ub, b = (hint > 0.0 && hint < hi) ? hint : hi;
   for (int it = 0; it < 200; ++it) {
     // tilted_mean(b) and tilted_mean_deriv(b) from ONE expm1 (the same expressions as the two functions above: on the
     // single control lane an expm1 is a few hundred dependent instructions)
@@ -76,9 +81,9 @@ SABC_HD inline double multi_eps_beta(double ub) {
       tm = tilted_mean(b);
       td = tilted_mean_deriv(b);
     } else {
-      const double em = expm1(b);
-      tm = 1.0 / b - 1.0 / em;
-      td = -1.0 / (b * b) + (em + 1.0) / (em * em);
+      const double r = 1.0 / expm1(b);               // 0 when expm1 overflows
+      tm = 1.0 / b - r;
+      td = -1.0 / (b * b) + r * (1.0 + r);           // = (e + 1) / e^2 with e = expm1(b)
     }
     const double f = tm - ub;
     if (f > 0.0) lo = b; else hi = b;
@@ -100,7 +105,8 @@ SABC_HD inline double pow_half_int(double x, int s) {
 }
 
 // update_epsilon_multi_eps (:100-117); returns false when some ubar_i <= eps() (:107-109)
-SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out) {
+// beta_io (optional, s doubles): in = the betas of the previous update (0 = none), out = this update's
+SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out, double *beta_io = nullptr) {
   double cn = 1.0;                                   // (2s+2)! / ((s+1)! (s+2)!)  (:103)
   for (int k = 1; k <= s + 1; ++k) cn = cn * (double)(s + 1 + k) / (double)k;
   cn /= (double)(s + 2);
@@ -114,7 +120,9 @@ SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_o
       prodq *= q;
     }
     const double den = cn * (s + 1) * (ui * pow_half_int(ui, s)) * prodq;   // :112  ui^(1 + s/2)
-    eps_out[i] = 1.0 / (multi_eps_beta(ui) + v * num / den);                 // :113-114
+    const double beta = multi_eps_beta(ui, beta_io ? beta_io[i] : 0.0);
+    if (beta_io) beta_io[i] = beta;
+    eps_out[i] = 1.0 / (beta + v * num / den);                               // :113-114
   }
   return true;
 }

@@ -178,3 +178,41 @@ int main() {
     exe = tmp_path / "mbox"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", ROOT, "-o", str(exe), str(src)])
     assert subprocess.check_output([str(exe)], text=True).strip() == "0"
+
+
+def test_multi_eps_beta_solve_warm_cold_and_overflow(tmp_path):
+    """The root beta_i of the multi-eps schedule (SimulatedAnnealingABC.jl:113; csrc/host_math.hpp: multi_eps_beta): started
+    from the previous update's root (the control step's warm start), from a useless hint or cold, the iteration ends at the
+    same root; where expm1(beta) overflows (mean u < 0.0014: the late stage of every chain) the derivative stays finite and
+    the root is 1 / mean u; the equation holds at the root."""
+    import subprocess
+    src = tmp_path / "beta.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include "simulatedannealingabc.jl_amd/csrc/host_math.hpp"
+using namespace sabc::hostmath;
+int main() {
+  double worst = 0.0, worst_tail = 0.0, worst_res = 0.0;
+  srand(1);
+  for (int t = 0; t < 100000; ++t) {
+    double ub = pow(10.0, -7.0 * rand() / RAND_MAX) * 0.45;                 // 4.5e-8 .. 0.45
+    if (t % 7 == 0) ub = 0.55 + 0.44 * rand() / RAND_MAX;                   // the mirrored branch (negative beta)
+    const double cold = multi_eps_beta(ub);
+    const double warm = multi_eps_beta(ub, cold * (1.0 + 0.02 * (rand() / (double)RAND_MAX - 0.5)));
+    const double far = multi_eps_beta(ub, cold * 3.0);
+    const double d = fmax(fabs(warm - cold), fabs(far - cold)) / fabs(cold);
+    if (d > worst) worst = d;
+    if (ub < 1e-3) { const double e = fabs(cold * ub - 1.0); if (e > worst_tail) worst_tail = e; }
+    const double tm = 1.0 / cold - 1.0 / expm1(cold);                       // the equation of :113, literally
+    const double r = fabs(tm - ub) / ub;
+    if (r > worst_res) worst_res = r;
+  }
+  std::printf("%.3g %.3g %.3g\n", worst, worst_tail, worst_res);
+  return 0;
+}
+''')
+    exe = tmp_path / "beta"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, "-o", str(exe), str(src)])
+    worst, tail, res = (float(x) for x in subprocess.check_output([str(exe)], text=True).split())
+    assert worst < 1e-12 and tail < 1e-12 and res < 1e-12, (worst, tail, res)
