@@ -13,10 +13,18 @@
 
 namespace sabc {
 
+// the multi-eps schedule's epsilons, computed ahead of the step by one lane per statistic (kernels.hip: control_on_copy) from
+// the sums the step is about to take over; the step applies them in order, exactly as it would have computed them
+struct EpsCandidates {
+  double eps[kMaxStats], beta[kMaxStats];
+  int32_t ok[kMaxStats];                  // 0: mean u of this statistic <= eps() (:107-109)
+};
+
 // returns false when the step was a no-op (guarded and halted): nothing must be posted then
 // `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
 // control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
-SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in) {
+SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in,
+                                 const EpsCandidates *pre = nullptr) {
   if ((a.mode & CTRL_GUARDED) && cb.halt) return false;
   if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
   const int d = a.d, s = a.s;
@@ -63,7 +71,13 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
 
   SABC_CTRL_MARK(10);
   if (a.mode & CTRL_EPSILON) {                                                       // :350-354
-    if (a.algorithm == SABC_ALG_MULTI_EPS) {
+    if (a.algorithm == SABC_ALG_MULTI_EPS && pre) {
+      for (int j = 0; j < s; ++j) {                  // (a failing statistic stops the schedule where eps_multi would have)
+        if (!pre->ok[j]) { cb.error = SABC_ERR_ZERO_MEAN_U; break; }                 // :107-109
+        cb.eps[j] = pre->eps[j];
+        cb.beta[j] = pre->beta[j];
+      }
+    } else if (a.algorithm == SABC_ALG_MULTI_EPS) {
 #if defined(__HIP_DEVICE_COMPILE__)
       __shared__ double ubar[kMaxStats];             // (a local array indexed at run time would live in scratch memory)
 #else

@@ -104,25 +104,39 @@ SABC_HD inline double pow_half_int(double x, int s) {
   return p;
 }
 
+// update_epsilon_multi_eps (:100-117), one statistic at a time: the s epsilons do not depend on each other, so the control
+// kernels give each its own lane (kernels.hip: control_on_copy) -- on ONE lane the schedule is s^2 divisions and square
+// roots plus s root solves per population update: 12 us at s = 3, over a millisecond at s = 48.
+SABC_HD inline double eps_multi_cn(int s) {          // (2s+2)! / ((s+1)! (s+2)!)  (:103)
+  double cn = 1.0;
+  for (int k = 1; k <= s + 1; ++k) cn = cn * (double)(s + 1 + k) / (double)k;
+  return cn / (double)(s + 2);
+}
+// false when ubar_i <= eps() (:107-109); hint / beta_i: the root beta_i of the previous / of this update (multi_eps_beta)
+SABC_HD inline bool eps_multi_one(const double *ubar, int s, double v, double cn, int i, double hint, double *eps_i, double *beta_i) {
+  const double ui = ubar[i];
+  if (ui <= DBL_EPSILON) return false;
+  double num = 1.0, prodq = 1.0;
+  for (int j = 0; j < s; ++j) {
+    const double q = ubar[j] / ui;                   // :110
+    num += pow_half_int(q, s);                       // :111  q^(s/2)
+    prodq *= q;
+  }
+  const double den = cn * (s + 1) * (ui * pow_half_int(ui, s)) * prodq;   // :112  ui^(1 + s/2)
+  const double beta = multi_eps_beta(ui, hint);
+  *beta_i = beta;
+  *eps_i = 1.0 / (beta + v * num / den);                                   // :113-114
+  return true;
+}
+
 // update_epsilon_multi_eps (:100-117); returns false when some ubar_i <= eps() (:107-109)
 // beta_io (optional, s doubles): in = the betas of the previous update (0 = none), out = this update's
 SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out, double *beta_io = nullptr) {
-  double cn = 1.0;                                   // (2s+2)! / ((s+1)! (s+2)!)  (:103)
-  for (int k = 1; k <= s + 1; ++k) cn = cn * (double)(s + 1 + k) / (double)k;
-  cn /= (double)(s + 2);
+  const double cn = eps_multi_cn(s);
   for (int i = 0; i < s; ++i) {
-    const double ui = ubar[i];
-    if (ui <= DBL_EPSILON) return false;
-    double num = 1.0, prodq = 1.0;
-    for (int j = 0; j < s; ++j) {
-      const double q = ubar[j] / ui;                 // :110
-      num += pow_half_int(q, s);                // :111  q^(s/2)
-      prodq *= q;
-    }
-    const double den = cn * (s + 1) * (ui * pow_half_int(ui, s)) * prodq;   // :112  ui^(1 + s/2)
-    const double beta = multi_eps_beta(ui, beta_io ? beta_io[i] : 0.0);
+    double beta;
+    if (!eps_multi_one(ubar, s, v, cn, i, beta_io ? beta_io[i] : 0.0, &eps_out[i], &beta)) return false;
     if (beta_io) beta_io[i] = beta;
-    eps_out[i] = 1.0 / (beta + v * num / den);                               // :113-114
   }
   return true;
 }

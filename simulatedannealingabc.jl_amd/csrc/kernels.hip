@@ -595,7 +595,23 @@ __device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a
 
 __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, ControlBlock *cb, const ControlArgs &a,
                                                 double *hist, Mailbox *ring, const double *sums, double *stage) {
-  if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums) ? 1 : 0;
+  // the multi-eps schedule (:100-117): one lane per statistic computes its epsilon from the sums the step is about to take
+  // over -- s^2 divisions and square roots plus s root solves on ONE lane are 12 us per update at s = 3 and over a
+  // millisecond at s = 48; lane 0 then applies the candidates inside control_step(), in order
+  __shared__ EpsCandidates cand;
+  __shared__ double ubar_s[kMaxStats];
+  const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS && !((a.mode & CTRL_GUARDED) && lcb.halt);   // uniform
+  if (multi) {
+    const double *src = (a.mode & CTRL_KEEP_SUMS) ? lcb.sums : sums;
+    if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = src[1 + threadIdx.x] / a.n_global;
+    __syncthreads();
+    if ((int)threadIdx.x < a.s) {
+      const int i = threadIdx.x;
+      cand.ok[i] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), i, lcb.beta[i], &cand.eps[i], &cand.beta[i]) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums, multi ? &cand : nullptr) ? 1 : 0;
   __syncthreads();
   if (!ran) {                               // guarded and halted: nothing changed
     // ... and nothing is posted, unless the halt is a peer-to-peer wait that gave up (p2p.hpp): the host is waiting for
