@@ -20,6 +20,13 @@ struct EpsCandidates {
   int32_t ok[kMaxStats];                  // 0: mean u of this statistic <= eps() (:107-109)
 };
 
+// component q of the sums, taken over from the staging buffer (the control kernels do this with one lane per component and
+// then run the step with CTRL_KEEP_SUMS: 1 + 2s + d + d(d+1)/2 dependent LDS round trips on one lane are 10 us at s = 48)
+SABC_HD inline void control_take_sum(ControlBlock &cb, const ControlArgs &a, const double *sums_in, int q) {
+  const bool delta = a.rho_is_delta && q >= 1 + a.s && q < 1 + 2 * a.s;            // running sum(rho) += its change
+  cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
+}
+
 // returns false when the step was a no-op (guarded and halted): nothing must be posted then
 // `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
 // control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
@@ -29,10 +36,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
   if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
   const int d = a.d, s = a.s;
   if (!(a.mode & CTRL_KEEP_SUMS))
-    for (int q = 0; q < n_partials(d, s); ++q) {
-      const bool delta = a.rho_is_delta && q >= 1 + s && q < 1 + 2 * s;          // running sum(rho) += its change
-      cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
-    }
+    for (int q = 0; q < n_partials(d, s); ++q) control_take_sum(cb, a, sums_in, q);
   SABC_CTRL_MARK(9);
   const double n = a.n_global;
   const double *S = &cb.sums[1 + 2 * s], *Q = &cb.sums[1 + 2 * s + d];

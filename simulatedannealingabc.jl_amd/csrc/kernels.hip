@@ -576,6 +576,7 @@ k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const
 // block: the step is a chain of dependent reads and writes of the block, each of which would be a round trip to
 // L2 (~1 us); the workgroup loads the 7 KB block once, lane 0 works on the copy, the workgroup writes it back.
 static_assert(sizeof(ControlBlock) % 8 == 0, "copied as 8-byte words");
+static_assert(kMaxPartials <= 1024, "the reduce-and-control kernels give every component of a row of sums a lane");
 constexpr int kControlWords = (int)(sizeof(ControlBlock) / 8);
 
 // the workgroup's loads of the block; the caller puts a barrier between this and control_on_copy()
@@ -600,10 +601,17 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
   // millisecond at s = 48; lane 0 then applies the candidates inside control_step(), in order
   __shared__ EpsCandidates cand;
   __shared__ double ubar_s[kMaxStats];
-  const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS && !((a.mode & CTRL_GUARDED) && lcb.halt);   // uniform
+  const bool noop = (a.mode & CTRL_GUARDED) && lcb.halt;                  // uniform; nobody has written lcb.halt yet
+  ControlArgs a_step = a;
+  if (!noop && !(a.mode & CTRL_KEEP_SUMS)) {
+    // the sums are taken over by one lane per component; the step then works on them as they stand
+    for (int q = threadIdx.x; q < n_partials(a.d, a.s); q += blockDim.x) control_take_sum(lcb, a, sums, q);
+    a_step.mode |= CTRL_KEEP_SUMS;
+    __syncthreads();
+  }
+  const bool multi = !noop && (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
   if (multi) {
-    const double *src = (a.mode & CTRL_KEEP_SUMS) ? lcb.sums : sums;
-    if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = src[1 + threadIdx.x] / a.n_global;
+    if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = lcb.sums[1 + threadIdx.x] / a.n_global;
     __syncthreads();
     if ((int)threadIdx.x < a.s) {
       const int i = threadIdx.x;
@@ -611,7 +619,7 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) ran = control_step(lcb, a, hist, sums, multi ? &cand : nullptr) ? 1 : 0;
+  if (threadIdx.x == 0) ran = control_step(lcb, a_step, hist, sums, multi ? &cand : nullptr) ? 1 : 0;
   __syncthreads();
   if (!ran) {                               // guarded and halted: nothing changed
     // ... and nothing is posted, unless the halt is a peer-to-peer wait that gave up (p2p.hpp): the host is waiting for
@@ -621,7 +629,8 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
   }
   for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
     reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
-  if (stage && (int)threadIdx.x < n_partials(a.d, a.s)) stage[threadIdx.x] = sums[threadIdx.x];
+  if (stage)
+    for (int q = threadIdx.x; q < n_partials(a.d, a.s); q += blockDim.x) stage[q] = sums[q];
   if (threadIdx.x == 0 && a.notify_seq != 0) mailbox_post(ring, a, lcb);
 }
 
@@ -1726,7 +1735,8 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
   // a short matrix of partial rows (a shard of an 8-GPU run: 489 rows at n = 1e6) takes 4 waves instead of 16: the waves of
   // one workgroup start one after the other and the launch waits for the last one's loads (tools/rc_timing.py)
   static const int forced = [] { const char *e = std::getenv("SABC_RC_BLOCK"); const int v = e ? std::atoi(e) : 0; return (v == 256 || v == 1024) ? v : 0; }();
-  const int block = forced ? forced : (rows < 0 || (np <= 64 && rows <= (int64_t)24 * (256 / np))) ? 256 : 1024;
+  // (np <= 256 threads' worth: the kernel gives every component of the row a lane)
+  const int block = forced && np <= 256 ? forced : ((rows < 0 && np <= 256) || (np <= 64 && rows >= 0 && rows <= (int64_t)24 * (256 / np))) ? 256 : 1024;
   if (pv) {
     x.pv = *pv; x.seq = seq; x.silent = silent ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_control<true>, dim3(1), dim3(block), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);

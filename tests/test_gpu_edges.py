@@ -158,6 +158,36 @@ def test_dozens_of_statistics_in_host_mode(S, O, gpu):
         np.testing.assert_allclose(np.array(res.state.ϵ_history), run.history[0], rtol=tol)
 
 
+def test_the_largest_shapes_in_host_mode(S, O, gpu):
+    """d = 16 parameters and s = 64 statistics at once (SABC_MAX_PARA, SABC_MAX_STATS): rows of 281 fused sums (more than a
+    256-thread workgroup has lanes), a 16 x 16 covariance and Cholesky factor on the control lane, 64 epsilons under
+    :multi_eps.  Against the oracle driven by the same id-keyed host simulator."""
+    d, s = 16, 64
+    truth = np.linspace(-1, 1, d)
+
+    def f_dist(θ, pid, it):
+        z = np.array([O.normal_pair(SEED, pid, O.PURPOSE_SIM, it, b) for b in range(s // 2)]).ravel()
+        return np.abs(np.tile(θ - truth, 4) + 0.2 * z) + 0.01
+    prior = S.product_distribution([S.Normal(0.0, 2.0)] * 8 + [S.Uniform(-3.0, 3.0)] * 8)
+    opri = [(O.PRIOR_NORMAL, 0.0, 2.0)] * 8 + [(O.PRIOR_UNIFORM, -3.0, 3.0)] * 8
+    n, k = 200, 8
+    for alg, prop in (("multi_eps", "rw"), ("single_eps", "de")):
+        hd = S.HostDistance(f_dist, n_stats=s, n_para=d, univariate=False, with_ids=True)
+        res = S.sabc(hd, prior, n_particles=n, n_simulation=n * (k + 1), algorithm=alg, proposal=hip_proposal(S, prop, d),
+                     resample=30, seed=SEED)
+        cfg = O.make_config(n_particles=n, n_para=d, n_stats=s, model_id=O.MODEL_HOST, model_params=[], prior=opri, seed=SEED,
+                            algorithm=O.ALG_MULTI_EPS if alg == "multi_eps" else O.ALG_SINGLE_EPS, host_fn=O.host_simulator(f_dist, d, s))
+        run = O.OracleRun(cfg)
+        run.initialize(n * (k + 1))
+        run.update(O.make_update_args(n_simulation=n * k, proposal=oracle_proposal(O, prop, d), n_para=d, n_particles=n, resample=30))
+        assert res.population.shape == (n, d) and res.u.shape == (n, s) and len(res.state.ϵ) == (s if alg == "multi_eps" else 1)
+        assert res.state.n_accept == run.counters["n_accept"] and res.state.n_resampling == run.counters["n_resampling"] >= 1
+        tol = {"rw": 1e-8, "de": 1e-5}[prop]
+        np.testing.assert_allclose(res.state.ϵ, run.eps, rtol=tol)
+        np.testing.assert_allclose(res.population.T, run.theta, rtol=tol, atol=tol)
+        np.testing.assert_allclose(res.ρ.T, run.rho, rtol=tol, atol=tol)
+
+
 def test_resample_disabled_and_every_update(S, O, gpu):
     """`resample` is any positive real (:255): inf never resamples, a tiny value resamples after every update."""
     n, name = 600, "gauss1_2stats"
