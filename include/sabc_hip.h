@@ -26,9 +26,11 @@
 extern "C" {
 #endif
 
-#define SABC_ABI_VERSION 5      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
+#define SABC_ABI_VERSION 6      /* 2: prior_c / prior_d (Gamma, Beta, truncated Normal priors); 3: prior_joint / prior_chol (MvNormal);
                                    4: peer-to-peer transport (sabc_comm_p2p_*), launch counters, SABC_MAX_PARA / _STATS 8 -> 16, prior_joint = 3;
-                                   5: SABC_MAX_STATS 16 -> 64 (the buffers of sabc_get_epsilon / sabc_set_epsilon / sabc_cdf_apply callers) */
+                                   5: SABC_MAX_STATS 16 -> 64 (the buffers of sabc_get_epsilon / sabc_set_epsilon / sabc_cdf_apply callers);
+                                   6: peer-to-peer life cycle (sabc_comm_p2p_setup, leaving handshake, descriptor 384 -> 512 bytes),
+                                      sabc_update_args::history_phase / final_push */
 #define SABC_MAX_PARA 16        /* host-callback and source-compiled simulators: any d up to this (the reference takes any length(prior),      */
 #define SABC_MAX_STATS 64       /* SimulatedAnnealingABC.jl:163) and -- host-callback simulators -- any number of distances up to this (:164-167,181: */
                                 /* summaries of a time series easily number dozens)                                                            */
@@ -119,11 +121,17 @@ typedef struct {
   double  v;
   double  delta;
   double  resample;               /* kw resample (default 2 n_particles) */
-  int64_t checkpoint_history;
+  int64_t checkpoint_history;     /* >= 1 (`ix % checkpoint_history`, :367, is a DivideError for 0 in the reference) */
   int32_t proposal_kind;          /* SABC_PROP_* */
-  int32_t reserved;
+  int32_t more_chunks_follow;     /* 0: this call ends an update_population! call: the final history push of :378-382 applies.
+                                     1: the wrapper has cut one update_population! call into several sabc_update calls (to print
+                                     its progress lines, :359-364) and this is not the last of them: no final push */
   double  proposal_p0;            /* RandomWalk beta | DifferentialEvolution gamma0 | StretchMove a */
   double  proposal_p1;            /* DifferentialEvolution sigma_gamma */
+  int64_t history_phase;          /* population updates of the SAME update_population! call done by earlier sabc_update calls:
+                                     update ix of this call is update history_phase + ix of the loop at :294, and that number is
+                                     what `% checkpoint_history` (:367) and the final push (:378) see -- a call cut into chunks
+                                     of any length leaves the histories of the uncut call */
 } sabc_update_args;
 
 /* Collective hooks for world > 1 (one process per GPU).  `buf` is a device pointer when
@@ -221,23 +229,56 @@ SABC_API int         sabc_comm_selftest(sabc_handle *h);
    Every wait is bounded (sabc_comm_p2p_set_timeout, default 5000 ms).  A shard that gives up fails the call on EVERY shard
    (the end-of-call status exchange) and switches the handle back to the collectives underneath; with such collectives
    installed sabc_update then puts the particles back and repeats the call over them (sabc_comm_p2p_fallbacks counts),
-   without them it returns SABC_ERR_COMM per its error contract. */
-#define SABC_P2P_DESC_BYTES 384
+   without them it returns SABC_ERR_COMM per its error contract.
+
+   LEAVING.  No shard ever frees memory a peer may still read, and no caller has to arrange that with barriers:
+   sabc_comm_p2p_disable, a failed call, a new set-up and sabc_destroy all LEAVE the group -- the shard marks itself as
+   leaving (a host page every peer has mapped + a word in every peer's slots: their waits for this shard give up at once
+   instead of running into the bound), drains its stream, unmaps every peer and records that it has.  A peer notices at the
+   entry of its next sabc_update / sabc_initialize (before it launches anything) or inside the call it is in, leaves as
+   well, and carries on over the collectives underneath or returns SABC_ERR_COMM.  sabc_destroy then waits (up to
+   sabc_comm_p2p_set_destroy_wait, default: the bound of the waits) until every peer has recorded that it unmapped this
+   shard's memory; memory a peer has not released by then is PARKED -- kept until the process exits -- never freed under
+   a reader (sabc_comm_p2p_parked_bytes).  The reference never corrupts state on the way out either
+   (SimulatedAnnealingABC.jl:264-267,387-397). */
+#define SABC_P2P_DESC_BYTES 512
 #define SABC_P2P_MAX_WORLD 8
+/* ONE call that sets the transport up on every shard, or leaves every shard on the collectives -- the same answer
+   everywhere, nobody waiting out a bound because the others decided differently: descriptors exchanged over the
+   collectives already installed -> peers mapped -> agreement (an allreduce of an ok flag) -> self-test -> agreement.
+   Returns 1 when the handle now runs peer to peer, 0 when every shard stays on the collectives (sabc_last_error says why),
+   < 0 when the collectives themselves failed.  Collective: every shard calls it. */
+SABC_API int         sabc_comm_p2p_setup(sabc_handle *h);
+/* the pieces of the above, for callers that move the descriptors themselves (shards in one process; tests) */
 SABC_API int         sabc_comm_p2p_descriptor(sabc_handle *h, void *out_desc);
 SABC_API int         sabc_comm_p2p_init(sabc_handle *h, const void *all_descs);
-/* one exchange of known rows + one barrier over the mapped slots, checked on the host; SABC_ERR_COMM within the bound */
+/* first contact, checked on the device and the host, SABC_ERR_COMM within the bound: a row of known values through the
+   slots + a barrier; then what the transport READS -- every shard writes a rank- and round-tagged pattern into lines spread
+   over both of its population buffers and rho (plain device memory), a barrier, every shard reads every peer's lines
+   through its mappings and compares; a second round with another pattern (a line kept from the first would show); the
+   lines are put back.  Every shard has to call it the same number of times. */
 SABC_API int         sabc_comm_p2p_selftest(sabc_handle *h);
 SABC_API int         sabc_comm_p2p_set_timeout(sabc_handle *h, double milliseconds);
+/* leave the group (see LEAVING above); the handle keeps its particles and continues over the collectives underneath */
 SABC_API int         sabc_comm_p2p_disable(sabc_handle *h);
+/* how long sabc_destroy waits for the peers' acknowledgement; 0 = not at all (for finalizers: what a peer has not
+   released is parked at once) */
+SABC_API int         sabc_comm_p2p_set_destroy_wait(sabc_handle *h, double milliseconds);
+/* bytes of device memory this process has parked so far (0 in a run whose shards all left in order) */
+SABC_API int64_t     sabc_comm_p2p_parked_bytes(void);
 /* 1 while the handle runs over the peer-to-peer transport */
 SABC_API int         sabc_comm_p2p_active(const sabc_handle *h);
 /* sabc_update calls in which a peer-to-peer wait gave up and that were put back (device-side copy of the particles taken
    at entry) and finished over the collectives installed underneath -- the caller sees a successful call */
 SABC_API int64_t     sabc_comm_p2p_fallbacks(const sabc_handle *h);
-/* test hook: n > 0: this shard skips its next n posts (rows of sums / barrier flags / call status), so that its peers run
-   into the bound; n < 0: -n more posts go out first, then one is skipped */
+/* test hooks.  inject_silence: n > 0: this shard skips its next n posts (rows of sums / barrier flags / call status), so
+   that its peers run into the bound; n < 0: -n more posts go out first, then one is skipped.  inject_loss: n more posts
+   go out, then one reaches only this shard's own slots -- a post lost on the wire: the shard itself carries on with its
+   peers' rows (and may flip its population buffers in a resample they never reach).  inject_stale: the next self-test's
+   pattern check on this shard reports a mismatch (what a stale line would look like) */
 SABC_API int         sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n);
+SABC_API int         sabc_comm_p2p_inject_loss(sabc_handle *h, int32_t n);
+SABC_API int         sabc_comm_p2p_inject_stale(sabc_handle *h, int32_t n);
 
 /* ---- the hot path ---- */
 /* initialization(), SimulatedAnnealingABC.jl:151-227.  n_simulation is sabc()'s budget (:155). */

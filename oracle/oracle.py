@@ -78,18 +78,26 @@ class UpdateArgs(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (oracle/Makefile).  Safe when several processes ask at once: one builds, the others wait."""
+    """Compile the oracle with gcc (oracle/Makefile).  Safe when several processes ask at once: the staleness check happens
+    under the lock, the compiler writes a temporary name and the finished library is renamed into place (a library some
+    process has already mapped is never rewritten)."""
     import fcntl
     src = os.path.join(_HERE, "sabc_oracle.c")
 
     def stale():
         return not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
             os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "sabc_oracle.h")))
-    if force or stale():
-        with open(_LIB_PATH + ".lock", "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            if force or stale():
-                subprocess.check_call(["make", "-C", _HERE, "-B", "libsabc_oracle.so"], stdout=subprocess.DEVNULL)
+    with open(_LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or stale():
+            tmp = os.path.join(_HERE, f"libsabc_oracle.{os.getpid()}.tmp.so")
+            try:
+                subprocess.check_call(["make", "-C", _HERE, "-B", "libsabc_oracle.so", f"OUT={os.path.basename(tmp)}"],
+                                      stdout=subprocess.DEVNULL)
+                os.replace(tmp, _LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return _LIB_PATH
 
 

@@ -906,6 +906,10 @@ int orc_update(orc_state *st, const orc_update_args *a) {
   const int64_t n_pop = a->n_simulation / n;                         /* :275 */
   const int64_t n_updates = n_pop * n;                               /* :276 */
   int64_t last_checkpoint = 0;                                       /* :277 */
+  /* `ix % checkpoint_history` (:367) is a DivideError for 0; Julia's rem by a negative interval is that by its magnitude */
+  if (n_pop > 0 && a->checkpoint_history == 0)
+    return fail(st, ORC_ERR_BAD_CONFIG, "DivideError: integer division error (`checkpoint_history` must not be zero)");
+  const int64_t cph = a->checkpoint_history < 0 ? -a->checkpoint_history : (a->checkpoint_history > 0 ? a->checkpoint_history : 1);
   int rc = update_proposal(st, a);                                   /* :284 */
   if (rc) return rc;
   const int64_t half = n / 2;
@@ -937,7 +941,7 @@ int orc_update(orc_state *st, const orc_update_args *a) {
     if (rc) return rc;
     rc = update_epsilon(st, a->v);                                   /* :350-354 */
     if (rc) return rc;
-    if (a->checkpoint_history > 0 && ix % a->checkpoint_history == 0) {   /* :367-372 */
+    if (ix % cph == 0) {                                             /* :367-372 */
       push_history(st, 0);
       last_checkpoint = ix;
     }

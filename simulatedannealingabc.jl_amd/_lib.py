@@ -15,8 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libsabc_hip.so")
 HEADER = os.path.normpath(os.path.join(_HERE, "..", "include", "sabc_hip.h"))
 
-ABI_VERSION = 5
-P2P_DESC_BYTES, P2P_MAX_WORLD = 384, 8
+ABI_VERSION = 6
+P2P_DESC_BYTES, P2P_MAX_WORLD = 512, 8
 MAX_PARA, MAX_STATS, MAX_MODEL_PARAMS = 16, 64, 32
 MAX_SOURCE_STATS = 16     # simulators compiled from source (SABC_MODEL_USER)
 MAX_JOINT_PARA = 8
@@ -57,8 +57,8 @@ class Config(C.Structure):
 class UpdateArgs(C.Structure):
     _fields_ = [
         ("n_simulation", C.c_int64), ("v", C.c_double), ("delta", C.c_double), ("resample", C.c_double),
-        ("checkpoint_history", C.c_int64), ("proposal_kind", C.c_int32), ("reserved", C.c_int32),
-        ("proposal_p0", C.c_double), ("proposal_p1", C.c_double),
+        ("checkpoint_history", C.c_int64), ("proposal_kind", C.c_int32), ("more_chunks_follow", C.c_int32),
+        ("proposal_p0", C.c_double), ("proposal_p1", C.c_double), ("history_phase", C.c_int64),
     ]
 
 
@@ -83,18 +83,24 @@ def sources_newer_than_lib() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of every HIP translation unit (csrc/Makefile).  Safe when several processes ask at
-    once (the ranks of a multi-process run start together): one builds, the others wait on the lock."""
-    if force or sources_newer_than_lib():
-        import fcntl
-        with open(LIB_PATH + ".lock", "w") as lock:
-            fcntl.flock(lock, fcntl.LOCK_EX)
-            if force or sources_newer_than_lib():
-                cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else [])
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-                if verbose or r.returncode:
-                    print(r.stdout)
-                if r.returncode:
-                    raise RuntimeError("building libsabc_hip.so failed")
+    once (the ranks of a multi-process run start together): the staleness check happens UNDER the lock -- a rank that arrives
+    while another is linking waits instead of loading a half-written file --, the linker writes a temporary name and the
+    finished library is renamed into place, so a library some process has already mapped is never rewritten."""
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or sources_newer_than_lib():
+            tmp = f"libsabc_hip.{os.getpid()}.tmp.so"
+            cmd = ["make", "-C", CSRC, "-j4", f"OUT=../{tmp}"] + (["-B"] if force else [])
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if verbose or r.returncode:
+                print(r.stdout)
+            tmp_path = os.path.join(_HERE, tmp)
+            if r.returncode:
+                if os.path.exists(tmp_path):
+                    os.remove(tmp_path)
+                raise RuntimeError("building libsabc_hip.so failed")
+            os.replace(tmp_path, LIB_PATH)
     return LIB_PATH
 
 
@@ -185,6 +191,7 @@ def bind(L, strict=True):
         "sabc_host_syncs": ([vp], C.c_int64),
         "sabc_kernel_launches": ([vp], C.c_int64),
         "sabc_collective_calls": ([vp], C.c_int64),
+        "sabc_comm_p2p_setup": ([vp], C.c_int),
         "sabc_comm_p2p_descriptor": ([vp, vp], C.c_int),
         "sabc_comm_p2p_init": ([vp, vp], C.c_int),
         "sabc_comm_p2p_selftest": ([vp], C.c_int),
@@ -193,6 +200,10 @@ def bind(L, strict=True):
         "sabc_comm_p2p_active": ([vp], C.c_int),
         "sabc_comm_p2p_fallbacks": ([vp], C.c_int64),
         "sabc_comm_p2p_inject_silence": ([vp, C.c_int32], C.c_int),
+        "sabc_comm_p2p_inject_stale": ([vp, C.c_int32], C.c_int),
+        "sabc_comm_p2p_inject_loss": ([vp, C.c_int32], C.c_int),
+        "sabc_comm_p2p_set_destroy_wait": ([vp, C.c_double], C.c_int),
+        "sabc_comm_p2p_parked_bytes": ([], C.c_int64),
     }
     for name, (args, res) in sig.items():
         if not strict and not hasattr(L, name):

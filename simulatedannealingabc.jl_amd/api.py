@@ -181,26 +181,20 @@ def as_host_distance(f_dist, prior, args=(), kwargs=None):
     return hd
 
 
-def progress_chunk(n_pop, cph, show_checkpoint, show_progressbar):
-    """Progress output needs the device loop to come up for air: `update_population!` is split into chunks of population
-    updates.  Chunks are multiples of `checkpoint_history`, which leaves counters, histories and particles exactly as in
-    one call (the final history push of :378-382 then never fires in between); a checkpoint interval is a multiple of the
-    chunk.  The Julia wrapper has the same function."""
-    chunk = n_pop
+def progress_stops(n_pop, show_checkpoint, show_progressbar):
+    """Progress output needs the device loop to come up for air: `update_population!` is cut into several sabc_update calls.
+    Returns the update counts after which a call ends: every multiple of `show_checkpoint` (:359), every step of the
+    progress bar (a fiftieth of the run), and n_pop.  The cuts may fall anywhere: each call is told how many updates of the
+    loop came before it (sabc_update_args::history_phase) and whether another follows (more_chunks_follow), so `ix %
+    checkpoint_history` (:367) and the final push (:378-382) see the loop's own numbering and the histories are those of
+    the uncut call -- `show_checkpoint` and `checkpoint_history` are independent moduli, as in the reference.  The Julia
+    wrapper has the same function."""
+    stops = {n_pop}
     if math.isfinite(show_checkpoint) and show_checkpoint >= 1:
-        k = int(show_checkpoint)
-        if k % cph == 0:
-            chunk = min(chunk, k)
+        stops.update(range(int(show_checkpoint), n_pop, int(show_checkpoint)))
     if show_progressbar and n_pop > 0:
-        bar = max(cph, (n_pop // 50) // cph * cph)
-        if chunk < n_pop:                                  # both: a bar step that divides the checkpoint interval
-            while chunk % bar != 0 and bar > cph:
-                bar -= cph
-            if chunk % bar == 0:
-                chunk = bar
-        else:
-            chunk = min(chunk, bar)
-    return max(chunk, 1)
+        stops.update(range(max(n_pop // 50, 1), n_pop, max(n_pop // 50, 1)))
+    return sorted(stops)
 
 
 def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.1, algorithm="single_eps",
@@ -290,7 +284,6 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
     n_global = h.cfg.n_particles
     if resample is None:
         resample = 2 * n_global                                                        # :255
-    explicit_checkpoint = show_checkpoint is not None
     if show_progressbar is None:
         show_progressbar = not is_logging(sys.stderr)                                  # :257
     if show_checkpoint is None:
@@ -300,11 +293,8 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
     h.set_population(th, np.ascontiguousarray(res.u.T), np.ascontiguousarray(res.ρ.T))
 
     n_pop = n_simulation // n_global                                                   # :275
-    cph = max(int(checkpoint_history), 1)
-    if math.isfinite(show_checkpoint) and show_checkpoint >= 1 and int(show_checkpoint) % cph != 0:
-        if explicit_checkpoint:
-            warnings.warn("show_checkpoint is not a multiple of checkpoint_history; progress lines are disabled")
-        show_checkpoint = math.inf
+    if n_pop > 0 and int(checkpoint_history) == 0:
+        raise ZeroDivisionError("integer division or modulo by zero: `ix % checkpoint_history`")   # :367 (a DivideError there)
     pbar = None
     if show_progressbar and n_pop > 0:
         try:
@@ -312,20 +302,17 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
             pbar = tqdm(total=n_pop, desc=f"{n_pop} population updates:", file=sys.stderr)   # :290-291
         except ImportError:
             pbar = None
-    chunk = progress_chunk(n_pop, cph, show_checkpoint, pbar is not None)
     done, t0 = 0, time.time()
-    while True:
-        todo = min(chunk, n_pop - done) if n_pop > 0 else 0
+    for stop in progress_stops(n_pop, show_checkpoint, pbar is not None):
+        todo = stop - done
         budget = todo * n_global if n_pop > 0 else n_simulation
         h.update(n_simulation=budget, proposal=proposal, v=v, delta=δ, resample=resample,
-                 checkpoint_history=checkpoint_history)
-        done += todo
+                 checkpoint_history=checkpoint_history, history_phase=done, more_chunks_follow=stop < n_pop)
+        done = stop
         if pbar is not None:
             pbar.update(todo)
             pbar.set_postfix_str(f"ϵ={np.array2string(h.eps, precision=4)}")                  # :292,374
-        if done >= n_pop:
-            break
-        if math.isfinite(show_checkpoint) and done % int(show_checkpoint) == 0:
+        if done > 0 and math.isfinite(show_checkpoint) and show_checkpoint >= 1 and done % int(show_checkpoint) == 0:
             eta = (time.time() - t0) / done * (n_pop - done)                              # :359-364
             log.info("Update %d of %d. ϵ: %s, ETA: %.0f s", done, n_pop, np.array2string(h.eps, precision=4), eta)
     if pbar is not None:

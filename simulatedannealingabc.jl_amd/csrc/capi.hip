@@ -17,6 +17,7 @@
 #include "host_math.hpp"
 #include "kernels.hpp"
 #include "p2p.hpp"
+#include "p2p_setup.hpp"
 #include "rtc.hpp"
 
 using namespace sabc;
@@ -400,17 +401,22 @@ int sabc_comm_p2p_init(sabc_handle *h, const void *all_descs) {
   if (all_descs) {
     std::memcpy(all.data(), all_descs, all.size() * sizeof(P2PDesc));
   } else {
-    // the descriptors travel over the collectives already installed (an allgather of raw bytes, carried as doubles)
     P2PDesc mine;
     if (h->be->p2p_descriptor(&mine)) return hfail(h, SABC_ERR_COMM);
-    constexpr int64_t kD = (int64_t)(sizeof(P2PDesc) / sizeof(double));
-    double *g = h->be->gather_buffer((int64_t)(sh.world + 1) * kD);
-    if (!g) return hset(h, SABC_ERR_HIP, "out of memory for the descriptor exchange");
-    if (h->be->to_backend(g, reinterpret_cast<const double *>(&mine), kD)) return hfail(h, SABC_ERR_HIP);
-    if (h->coll->allgather(g, g + kD, kD)) return hset(h, SABC_ERR_COMM, "allgather of the peer-to-peer descriptors failed (no transport installed?)");
-    if (h->be->to_host(reinterpret_cast<double *>(all.data()), g + kD, (int64_t)sh.world * kD)) return hfail(h, SABC_ERR_HIP);
+    std::string why;
+    if (int rc = p2p_gather_descriptors(h->be, h->coll, sh.world, mine, all, &why)) return hset(h, rc, why.c_str());
   }
   return h->be->p2p_init(all.data()) ? hfail(h, SABC_ERR_COMM) : 0;
+}
+
+// The whole set-up, with the shards agreeing after every step (csrc/p2p_setup.hpp).
+int sabc_comm_p2p_setup(sabc_handle *h) {
+  if (!h) return SABC_ERR_STATE;
+  if (hipSetDevice(h->be->device()) != hipSuccess) return hset(h, SABC_ERR_HIP, "hipSetDevice failed");
+  std::string note;
+  const int rc = p2p_setup_sequence(h->be, h->coll, h->eng->shard(), h->eng->host_mode(), &note);
+  h->err = note;
+  return rc == 1 ? (h->eng->p2p() ? 1 : 0) : rc;
 }
 
 int sabc_comm_p2p_selftest(sabc_handle *h) {
@@ -438,6 +444,26 @@ int sabc_comm_p2p_inject_silence(sabc_handle *h, int32_t n) {
   h->be->p2p_inject_silence(n);
   return 0;
 }
+
+int sabc_comm_p2p_inject_loss(sabc_handle *h, int32_t n) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->p2p_inject_loss(n);
+  return 0;
+}
+
+int sabc_comm_p2p_inject_stale(sabc_handle *h, int32_t n) {
+  if (!h) return SABC_ERR_STATE;
+  h->be->p2p_inject_stale(n);
+  return 0;
+}
+
+int sabc_comm_p2p_set_destroy_wait(sabc_handle *h, double milliseconds) {
+  if (!h || !(milliseconds >= 0)) return hset(h, SABC_ERR_BAD_CONFIG, "the wait of sabc_destroy must not be negative");
+  h->be->p2p_set_destroy_wait(milliseconds);
+  return 0;
+}
+
+int64_t sabc_comm_p2p_parked_bytes(void) { return HipBackend::parked_bytes(); }
 
 int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
   if (!h) return SABC_ERR_STATE;

@@ -206,6 +206,16 @@ void Engine::p2p_abort(int rc) {
   if (rc == SABC_ERR_COMM || rc == SABC_ERR_HIP) be_->p2p_disable();
 }
 
+// Entry of sabc_initialize / sabc_update on the peer-to-peer transport, before anything is launched: has a peer left the
+// group (its host page says so: p2p.hpp)?  Then this shard leaves as well -- nothing of the peer's is read again -- and the
+// call runs over the collectives underneath; without any it fails here, the handle untouched.
+int Engine::p2p_check_peers() {
+  if (!p2p() || be_->p2p_peers_present()) return 0;
+  be_->p2p_disable();
+  if (coll_->usable()) return 0;
+  return fail(SABC_ERR_COMM, "a shard has left the peer-to-peer group and no collectives are installed underneath");
+}
+
 int Engine::stats_reduce() {
   int64_t rows = 0;
   if (be_->stats(&rows)) return fail(SABC_ERR_HIP, "stats kernel failed");
@@ -256,9 +266,11 @@ int Engine::sync_control() {
     case SABC_ERR_NOT_POSDEF: return fail(SABC_ERR_NOT_POSDEF, "RandomWalk covariance is not positive definite");
     case SABC_ERR_COMM: {
       static const char *kind[4] = {"?", "sums exchange", "barrier", "end-of-call status"};
+      const int k = (cb_.comm_where >> 24) & 7;
       char buf[200];
-      std::snprintf(buf, sizeof(buf), "peer-to-peer %s %d: shard %d did not post within the bound (or reported a failed call)",
-                    kind[(cb_.comm_where >> 24) & 3], cb_.comm_where & 0xFFFFF, (cb_.comm_where >> 20) & 15);
+      std::snprintf(buf, sizeof(buf), k & 4 ? "peer-to-peer %s %d: shard %d has left the group"
+                                            : "peer-to-peer %s %d: shard %d did not post within the bound (or reported a failed call)",
+                    kind[k & 3], cb_.comm_where & 0xFFFFF, (cb_.comm_where >> 20) & 15);
       return fail(SABC_ERR_COMM, buf);
     }
     default: return fail(cb_.error, "error raised by the device-side control step");
@@ -427,6 +439,7 @@ int Engine::initialize(int64_t n_simulation) {
                   (long long)sh_.n_global);
     return fail(SABC_ERR_NSIM_TOO_SMALL, buf);
   }
+  if (int rc0 = p2p_check_peers()) return rc0;
   const bool can_retry = p2p() && coll_->usable();
   int rc = initialize_body();
   if (rc) { const std::string why = err_; p2p_abort(rc); err_ = why; }
@@ -561,6 +574,7 @@ int Engine::update(const sabc_update_args &a) {
   // Peer-to-peer transport with Collectives installed underneath: keep a device-side copy of the particles, so that a
   // call in which a peer-to-peer wait gave up can be put back and finished over the Collectives (every shard's call fails
   // with SABC_ERR_COMM then -- the end-of-call status exchange sees to that -- and every shard repeats it).
+  if (int rc0 = p2p_check_peers()) return rc0;
   const bool can_retry = p2p() && coll_->usable() && be_->snapshot() == 0;
   const bool replaced_at_entry = population_replaced_;
   int rc = update_once(a);
@@ -610,12 +624,18 @@ int Engine::update_loop(const sabc_update_args &a) {
   const int64_t N = sh_.n_global;
   const int64_t n_pop = a.n_simulation / N;                                 // :275
   const int64_t n_updates = n_pop * N;                                      // :276
-  const int64_t cph = a.checkpoint_history;
-  int64_t last_checkpoint = 0;                                              // :277
+  // `ix % checkpoint_history` (:367): a DivideError for 0 in the reference; a negative interval divides like its magnitude
+  if (n_pop > 0 && a.checkpoint_history == 0)
+    return fail(SABC_ERR_BAD_CONFIG, "DivideError: integer division error (`checkpoint_history` must not be zero)");
+  const int64_t cph = a.checkpoint_history < 0 ? -a.checkpoint_history : (a.checkpoint_history > 0 ? a.checkpoint_history : 1);
+  // a wrapper may cut one update_population! call into several of these calls (progress lines, :359-364): update ix here is
+  // update phase + ix of the loop at :294, and the histories follow THAT number
+  if (a.history_phase < 0) return fail(SABC_ERR_BAD_CONFIG, "history_phase must not be negative");
+  const int64_t phase = a.history_phase;
   int rc;
   // the host mirror is the truth between calls (state setters write into it)
   cb_.hist_rows = 0; cb_.error = 0; cb_.eps_len = eps_len_;
-  hist_capacity_ = (cph > 0 ? n_pop / cph : 0) + 2;
+  hist_capacity_ = n_pop / cph + 3;
   if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
   if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
 
@@ -653,7 +673,7 @@ int Engine::update_loop(const sabc_update_args &a) {
   int64_t seqs[kMaxDepth + 1] = {0};
   int64_t next_enqueue = 1, next_confirm = 1;
   int64_t known_accept = cb_.n_accept, last_delta = 0;   // as of the last confirmed update
-  auto hist_flag = [&](int64_t ix) { return (cph > 0 && ix % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };
+  auto hist_flag = [&](int64_t ix) { return ((phase + ix) % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };   // :367
   // Queueing ahead of an update that then triggers the resample costs three no-op launches; the accept
   // count moves slowly from one update to the next, so the host only queues ahead when the update in
   // flight is not expected to reach the threshold (a wrong guess costs one ~10 us gap, never correctness).
@@ -687,10 +707,11 @@ int Engine::update_loop(const sabc_update_args &a) {
       if ((rc = control(CTRL_CLEAR_HALT | after_update | hist_flag(ix), &a, a.v))) return rc;
       next_enqueue = ix + 1;
     }
-    if (cph > 0 && ix % cph == 0) last_checkpoint = ix;                     // :371
     ++next_confirm;
   }
-  if (last_checkpoint != n_pop) {                                           // :378-382
+  // :378-382 -- `last_checkpoint_epsilon != n_population_updates` is `the loop's last update was not a checkpoint`; only the
+  // call that ends the loop stores the last value
+  if (!a.more_chunks_follow && (phase + n_pop) % cph != 0) {
     if ((rc = control(CTRL_HISTORY | CTRL_KEEP_SUMS, &a, a.v))) return rc;
   }
   if ((rc = p2p_commit_ok())) return rc;

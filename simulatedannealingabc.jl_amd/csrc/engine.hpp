@@ -108,7 +108,10 @@ class Backend {
   virtual int p2p_barrier(bool) { return -1; }
   // end of a call: post this shard's status (0 = fine), and on the success path wait for everyone's
   virtual int p2p_commit(int, bool) { return -1; }
+  // leave the group (p2p.hpp): the peers learn of it, this shard's stream is drained, the peers are unmapped
   virtual void p2p_disable() {}
+  // host-side look at the peers' pages: false when one of them has left the group (nothing is launched then)
+  virtual bool p2p_peers_present() { return true; }
   // device-side copy of the particles (theta, u, rho) as they stand / put it back: what lets a call that failed over the
   // peer-to-peer transport be repeated over the Collectives without the caller noticing
   virtual int snapshot() { return -1; }
@@ -163,6 +166,7 @@ class Engine {
   // the peer-to-peer transport carries this handle (the backend has it mapped and the simulator is device code: a host
   // callback's duration differs from shard to shard by more than any sensible wait bound)
   bool p2p() const { return be_->p2p_active() && !host_mode_ && sh_.world > 1; }
+  bool host_mode() const { return host_mode_; }
 
  private:
   int fail(int code, const std::string &msg) { err_ = msg; return code; }
@@ -202,6 +206,7 @@ class Engine {
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
   int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0;
+  int p2p_check_peers();                            // p2p: a peer has left the group? (entry of a call, nothing launched yet)
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
   void p2p_abort(int rc);                           // ... and after a failure (rc: what the call returns)
   int initialize_body();

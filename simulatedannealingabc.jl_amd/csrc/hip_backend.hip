@@ -3,12 +3,18 @@
 
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
+#include <string>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 namespace sabc {
+
+namespace {
+std::atomic<int64_t> g_parked_bytes{0};       // device memory kept because a peer had not released it when its owner went away
+}
 
 #define HB_CHECK(expr, what)                       \
   do {                                             \
@@ -49,6 +55,15 @@ HipBackend::~HipBackend() {
   if (!stream_ && !pop_[0]) return;                // never allocated (e.g. create failed on a bad device ordinal)
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  // the peer-to-peer group first (p2p.hpp "LEAVES"): what peers may have mapped -- both population buffers, rho, the slot
+  // area -- is freed only when every one of them has recorded that it unmapped it; otherwise it is parked until the process
+  // exits: a late reader meets stale particles, never an unmapped page
+  const size_t pop_bytes = (size_t)(m_.d + m_.s + 1) * (size_t)sh_.cap * sizeof(double), rho_bytes = (size_t)m_.s * (size_t)sh_.cap * sizeof(double);
+  if (!p2p_finish()) {
+    g_parked_bytes += (int64_t)((pop_[0] ? pop_bytes : 0) + (pop_[1] ? pop_bytes : 0) + (rho_ ? rho_bytes : 0) + (slots_ ? (size_t)kP2PSlotWords * 8 : 0));
+    pop_[0] = pop_[1] = rho_ = nullptr;
+    slots_ = nullptr;
+  }
   end_of_call();
   for (auto &v : ev_)
     for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -79,7 +94,10 @@ HipBackend::~HipBackend() {
   if (mbox_host_) (void)hipHostFree(mbox_host_);
   if (totals_host_) (void)hipHostFree(totals_host_);
   rtc_release(&rtc_);
-  p2p_close();
+  if (slots_) (void)hipFree(slots_);
+  if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
+  if (snap_pop_) (void)hipFree(snap_pop_);
+  if (snap_rho_) (void)hipFree(snap_rho_);
   if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -614,7 +632,7 @@ int HipBackend::flush_reduce() {
     none.mode = pending_guarded_ ? CTRL_GUARDED : 0;
     const P2PView pv = p2p_view();
     HB_LAUNCH(launch_reduce_control(partials_, -1, np_, sums_stage_, pending_guarded_, cb_dev_, none, hist_dev_, mbox_dev_, stream_, &pv,
-                                    ++xseq_, /*do_control=*/false, take_silence()), "k_reduce_control (exchange)");
+                                    tag(++xseq_), /*do_control=*/false, take_silence()), "k_reduce_control (exchange)");
   }
   prof_end(SABC_KERNEL_REDUCE);
   return 0;
@@ -635,7 +653,7 @@ int HipBackend::control(const ControlArgs &a) {
     prof_begin(SABC_KERNEL_REDUCE);
     // several shards over the peer-to-peer slots: reduce -> exchange -> control step, ONE launch
     HB_LAUNCH(launch_reduce_control(partials_, rows, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_,
-                                    xchg ? &pv : nullptr, xchg ? ++xseq_ : 0, true, xchg && take_silence()),
+                                    xchg ? &pv : nullptr, xchg ? tag(++xseq_) : 0, true, xchg ? take_silence() : 0),
               "k_reduce_control");
     prof_end(SABC_KERNEL_REDUCE);
     return 0;
@@ -645,7 +663,7 @@ int HipBackend::control(const ControlArgs &a) {
     if (flush_reduce()) return -1;
     prof_begin(SABC_KERNEL_REDUCE);
     HB_LAUNCH(launch_reduce_control(partials_, -1, np_, sums_stage_, pending_guarded_, cb_dev_, a, hist_dev_, mbox_dev_, stream_, &pv,
-                                    ++xseq_, true, take_silence()), "k_reduce_control (exchange)");
+                                    tag(++xseq_), true, take_silence()), "k_reduce_control (exchange)");
     prof_end(SABC_KERNEL_REDUCE);
     return 0;
   }
@@ -728,7 +746,7 @@ int HipBackend::resample_draw(const double *gathered_pop, uint64_t iter) {
   HB_LAUNCH(launch_resample_gather(m_, blocks, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_),
             "k_resample_gather");
   prof_end(SABC_KERNEL_RESAMPLE);
-  cur_ = nxt;
+  flip_cur();
   return 0;
 }
 
@@ -745,7 +763,7 @@ int HipBackend::resample_local(double delta, uint64_t iter, int64_t *stats_rows)
                                   pack_dev_, partials_, stats_rows, stream_), "resample kernels");
   launches_ += 3;
   prof_end(SABC_KERNEL_RESAMPLE);
-  cur_ = nxt;
+  flip_cur();
   return 0;
 }
 
@@ -795,7 +813,7 @@ int HipBackend::resample_serve(const double *req_in, int64_t m, double *rows_out
 int HipBackend::resample_scatter(const double *rows_in) {
   const int nxt = 1 - cur_;
   HB_LAUNCH(launch_resample_scatter(rows_in, slot_dev_, sh_.n_local, m_.d + m_.s, pop_ptrs(nxt), stream_), "k_resample_scatter");
-  cur_ = nxt;
+  flip_cur();
   return 0;
 }
 
@@ -897,6 +915,8 @@ int HipBackend::simulate_host(const double *theta, int64_t n, uint64_t pid0, uin
 }
 
 // ---- peer-to-peer transport (p2p.hpp) ----------------------------------------------------------
+int64_t HipBackend::parked_bytes() { return g_parked_bytes.load(); }
+
 P2PView HipBackend::p2p_view() const {
   P2PView v;
   std::memset(&v, 0, sizeof(v));
@@ -911,26 +931,25 @@ int HipBackend::p2p_descriptor(P2PDesc *out) {
   std::memset(out, 0, sizeof(*out));
   if (sh_.world < 2 || sh_.world > kMaxPeers) { err_ = "the peer-to-peer transport takes 2..8 shards (one node)"; return -1; }
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
+  // a new set-up (after a failed call switched the transport off, or on top of a live one): this shard LEAVES the old group
+  // first -- its peers are unmapped and told so -- before anything of the new one is exported
+  if (p2p_leave()) return -1;
+  if (!page_) {
+    page_ = p2p_page_create(page_name_);
+    if (!page_) { err_ = "the peer-to-peer transport needs POSIX shared memory for its host page (shm_open failed)"; return -1; }
+  }
   if (!slots_) {
     // fine-grained, uncached device memory: a peer's store is visible to this device's loads without a cache to go through
     hipError_t e = hipExtMallocWithFlags((void **)&slots_, (size_t)kP2PSlotWords * 8, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags((void **)&slots_, (size_t)kP2PSlotWords * 8, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { slots_ = nullptr; return check(e, "hipExtMallocWithFlags(slot area)"); }
-    HB_CHECK(hipMemsetAsync(slots_, 0, (size_t)kP2PSlotWords * 8, stream_), "hipMemset(slot area)");
-    HB_CHECK(hipMalloc((void **)&p2p_test_dev_, (2 * kMaxPartials + 2) * sizeof(double)), "hipMalloc(self-test)");
-    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    HB_CHECK(hipMalloc((void **)&p2p_test_dev_, (size_t)(2 * kMaxPartials + 2 + p2p_pattern_save_words() + 2) * sizeof(double)), "hipMalloc(self-test)");
   }
-  if (p2p_on_ || xseq_ || bseq_ || call_) {
-    // a new set-up (after a failed call switched the transport off): the slots are wiped and the sequence numbers start
-    // over HERE, before this shard's descriptor leaves -- no peer can post into the slots before it has the descriptor
-    p2p_on_ = false;
-    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    HB_CHECK(hipMemsetAsync(slots_, 0, (size_t)kP2PSlotWords * 8, stream_), "hipMemset(slot area)");
-    HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-    xseq_ = bseq_ = call_ = 0;
-    for (void *p : ipc_opened_) (void)hipIpcCloseMemHandle(p);
-    ipc_opened_.clear();
-  }
+  // the slots are wiped and the running numbers start over.  (Correctness does not rest on the wipe: every word carries the
+  // set-up generation, and a word of an earlier generation -- a status post still in flight from an old peer -- matches nothing.)
+  HB_CHECK(hipMemsetAsync(slots_, 0, (size_t)kP2PSlotWords * 8, stream_), "hipMemset(slot area)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  xseq_ = bseq_ = call_ = 0;
   out->magic = kP2PMagic;
   out->pid = (int32_t)getpid();
   out->device = device_;
@@ -940,6 +959,10 @@ int HipBackend::p2p_descriptor(P2PDesc *out) {
   out->ptr_slots = (uint64_t)(uintptr_t)slots_;
   out->ptr_pop[0] = (uint64_t)(uintptr_t)pop_[0]; out->ptr_pop[1] = (uint64_t)(uintptr_t)pop_[1];
   out->ptr_rho = (uint64_t)(uintptr_t)rho_;
+  out->cur = cur_;
+  out->gen_proposal = gen_ >= kP2PMaxGen ? 1u : gen_ + 1u;
+  out->ptr_page = (uint64_t)(uintptr_t)page_;
+  std::memcpy(out->page_name, page_name_, sizeof(out->page_name));
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "P2PDesc holds 64-byte IPC handles");
   // the handles are only needed by shards in OTHER processes; a failure here surfaces there (all-zero handle)
   hipIpcMemHandle_t hd;
@@ -949,78 +972,163 @@ int HipBackend::p2p_descriptor(P2PDesc *out) {
     if (hipIpcGetMemHandle(&hd, what[i]) == hipSuccess) std::memcpy(where[i], &hd, 64);
     else (void)hipGetLastError();
   }
+  exported_ = true;                                     // from here on a peer may hold a mapping of this shard's memory
   return 0;
 }
 
 int HipBackend::p2p_init(const P2PDesc *all) {
-  if (!slots_) { err_ = "sabc_comm_p2p_descriptor has to be called first"; return -1; }
+  if (!slots_ || !page_) { err_ = "sabc_comm_p2p_descriptor has to be called first"; return -1; }
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
   const int W = sh_.world;
+  if (mapped_ && p2p_leave()) return -1;                // (init twice without a new descriptor)
   p2p_on_ = false;
   int khz = 0;                                          // rate of the constant wall clock the waits are bounded by
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) == hipSuccess && khz > 0) wall_clock_khz_ = khz;
   else (void)hipGetLastError();
+  uint32_t proposals[kMaxPeers] = {0};
   for (int r = 0; r < W; ++r) {
     const P2PDesc &d = all[r];
     if (d.magic != kP2PMagic || d.rank != r || d.world != W || d.cap != sh_.cap || d.n_global != sh_.n_global || d.d != m_.d || d.s != m_.s) {
       err_ = "peer-to-peer descriptor of a shard does not match this handle's configuration";
       return -1;
     }
+    proposals[r] = d.gen_proposal;
+  }
+  // the group's generation: above every member's last one; from here on this shard counts as mapped -- whatever goes wrong
+  // below is undone by p2p_leave(), which also tells the peers (through the host page) that nothing of theirs stays mapped
+  gen_ = p2p_agree_gen(proposals, W);
+  flips_ = 0;
+  page_->gen.store(gen_, std::memory_order_relaxed);
+  page_->cur_parity.store((uint32_t)cur_, std::memory_order_relaxed);
+  page_->state.store(kP2PNone, std::memory_order_release);
+  mapped_ = true;
+  auto fail = [&](const std::string &why) { (void)p2p_leave(); err_ = why; return -1; };
+  for (int r = 0; r < W; ++r) {
+    const P2PDesc &d = all[r];
+    peer_cur0_[r] = d.cur & 1;
     if (r == sh_.rank) {
       peer_slots_[r] = slots_; peer_pop_[0][r] = pop_[0]; peer_pop_[1][r] = pop_[1]; peer_rho_[r] = rho_;
+      peer_page_[r] = page_; peer_page_shm_[r] = false;
       continue;
     }
     if (d.pid == (int32_t)getpid()) {                   // same process: the pointers themselves
       if (d.device != device_) {
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, device_, d.device) != hipSuccess || !can) { err_ = "no peer access between the devices of two shards"; return -1; }
+        if (hipDeviceCanAccessPeer(&can, device_, d.device) != hipSuccess || !can) return fail("no peer access between the devices of two shards");
         const hipError_t e = hipDeviceEnablePeerAccess(d.device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return check(e, "hipDeviceEnablePeerAccess");
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)check(e, "hipDeviceEnablePeerAccess"); return fail(err_); }
         (void)hipGetLastError();
       }
       peer_slots_[r] = (uint64_t *)(uintptr_t)d.ptr_slots;
       peer_pop_[0][r] = (double *)(uintptr_t)d.ptr_pop[0]; peer_pop_[1][r] = (double *)(uintptr_t)d.ptr_pop[1];
       peer_rho_[r] = (double *)(uintptr_t)d.ptr_rho;
+      peer_page_[r] = (const P2PHostPage *)(uintptr_t)d.ptr_page; peer_page_shm_[r] = false;
       continue;
     }
     if (d.device != device_) {                          // another GPU of the node: kernels here must be able to reach it
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, device_, d.device) != hipSuccess || !can) {
         (void)hipGetLastError();
-        err_ = "no peer access between the devices of two shards (is the peer on this node?)";
-        return -1;
+        return fail("no peer access between the devices of two shards (is the peer on this node?)");
       }
     }
+    char name[sizeof(d.page_name) + 1];
+    std::memcpy(name, d.page_name, sizeof(d.page_name)); name[sizeof(d.page_name)] = 0;
+    peer_page_[r] = p2p_page_open(name);
+    peer_page_shm_[r] = peer_page_[r] != nullptr;
+    if (!peer_page_[r]) return fail("a peer shard's host page could not be opened (POSIX shared memory; is the peer on this node?)");
     const unsigned char *from[4] = {d.ipc_slots, d.ipc_pop[0], d.ipc_pop[1], d.ipc_rho};
     void *got[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i) {
       hipIpcMemHandle_t hd;
       std::memcpy(&hd, from[i], 64);
       const hipError_t e = hipIpcOpenMemHandle(&got[i], hd, hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) return check(e, "hipIpcOpenMemHandle (a peer shard's memory)");
+      if (e != hipSuccess) { (void)check(e, "hipIpcOpenMemHandle (a peer shard's memory)"); return fail(err_); }
       ipc_opened_.push_back(got[i]);
     }
     peer_slots_[r] = (uint64_t *)got[0];
     peer_pop_[0][r] = (double *)got[1]; peer_pop_[1][r] = (double *)got[2];
     peer_rho_[r] = (double *)got[3];
   }
+  page_->state.store(kP2PActive, std::memory_order_release);
   p2p_on_ = true;
   return 0;
 }
 
-void HipBackend::p2p_close() {
+// p2p.hpp "LEAVES".  Safe to call in any state and more than once; never frees anything a peer may have mapped.
+int HipBackend::p2p_leave() {
+  pending_xchg_ = false;
   p2p_on_ = false;
+  if (!mapped_) return 0;
+  (void)hipSetDevice(device_);
+  page_->state.store(kP2PLeaving, std::memory_order_release);
+  if (stream_) {
+    // the peers' waits for this shard give up at once; then everything this shard has in flight -- it may be reading the
+    // peers' populations -- is drained before their memory is unmapped
+    const P2PView pv = p2p_view();
+    (void)hipGetLastError();
+    (void)launch_p2p_leave(pv, gen_, stream_);
+    launches_ += 1;
+    (void)hipStreamSynchronize(stream_);
+    (void)hipGetLastError();
+  }
   for (void *p : ipc_opened_) (void)hipIpcCloseMemHandle(p);
   ipc_opened_.clear();
-  if (slots_) (void)hipFree(slots_);
-  if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
-  if (snap_pop_) (void)hipFree(snap_pop_);
-  if (snap_rho_) (void)hipFree(snap_rho_);
-  slots_ = nullptr; p2p_test_dev_ = nullptr; snap_pop_ = snap_rho_ = nullptr;
+  (void)hipGetLastError();
+  for (int r = 0; r < kMaxPeers; ++r) {
+    peer_slots_[r] = nullptr; peer_pop_[0][r] = peer_pop_[1][r] = nullptr; peer_rho_[r] = nullptr;
+    page_->released[r].store(gen_, std::memory_order_release);          // "nothing of shard r's generation-gen_ memory is mapped here"
+  }
+  mapped_ = false;
+  return 0;
 }
 
-// a row of known values through the slots + one barrier; the host checks the sums.  Sequence numbers advance exactly as
-// in a real exchange, so every shard has to call it the same number of times.
+bool HipBackend::p2p_peers_present() {
+  if (!mapped_ || !p2p_on_) return true;
+  for (int r = 0; r < sh_.world; ++r) {
+    const P2PHostPage *pg = peer_page_[r];
+    if (r == sh_.rank || !pg) continue;
+    if (pg->gen.load(std::memory_order_acquire) != gen_ || pg->state.load(std::memory_order_acquire) != kP2PActive) return false;
+  }
+  return true;
+}
+
+// Destructor: leave, then wait (bounded) until every peer has recorded that it unmapped this shard's memory.  true: the
+// memory peers could map may be freed; false: it has to be parked.
+bool HipBackend::p2p_finish() {
+  const P2PHostPage *pages[kMaxPeers];
+  for (int r = 0; r < kMaxPeers; ++r) pages[r] = peer_page_[r];
+  (void)p2p_leave();
+  bool ok = true;
+  if (exported_) {
+    const double wait_ms = destroy_wait_ms_ < 0 ? p2p_timeout_ms_ : destroy_wait_ms_;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < sh_.world && r < kMaxPeers; ++r) {
+      if (r == sh_.rank) continue;
+      // a peer this shard never got to know (set-up stopped before or inside sabc_comm_p2p_init) cannot acknowledge
+      if (!pages[r] || gen_ == 0) { ok = false; continue; }
+      // acknowledged: the peer has unmapped this generation -- or has moved on to a later set-up, which begins by leaving
+      while (pages[r]->released[sh_.rank].load(std::memory_order_acquire) != gen_ && pages[r]->gen.load(std::memory_order_acquire) <= gen_) {
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > wait_ms) { ok = false; break; }
+        usleep(50);
+      }
+    }
+  }
+  for (int r = 0; r < kMaxPeers; ++r) {
+    if (peer_page_shm_[r]) p2p_page_unmap(peer_page_[r]);
+    peer_page_[r] = nullptr; peer_page_shm_[r] = false;
+  }
+  if (page_) {
+    page_->state.store(kP2PGone, std::memory_order_release);
+    p2p_page_destroy(page_, page_name_);
+    page_ = nullptr;
+  }
+  return ok;
+}
+
+// First contact.  (1) a row of known values through the slots + one barrier, the host checks the sums; (2) what the
+// transport READS: selftest_patterns().  Sequence numbers advance exactly as in a real exchange, so every shard has to call
+// it the same number of times.
 int HipBackend::p2p_selftest() {
   if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
@@ -1032,20 +1140,65 @@ int HipBackend::p2p_selftest() {
   HB_CHECK(hipMemcpyAsync(d_in, in, sizeof(in), hipMemcpyHostToDevice, stream_), "memcpy");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   const P2PView pv = p2p_view();
-  HB_LAUNCH(launch_p2p_selftest(pv, ++xseq_, np, d_in, d_out, d_failed, take_silence(), stream_), "k_p2p_selftest");
-  HB_LAUNCH(launch_p2p_barrier(pv, ++bseq_, cb_dev_, false, false, stream_), "k_p2p_barrier");
+  HB_LAUNCH(launch_p2p_selftest(pv, tag(++xseq_), np, d_in, d_out, d_failed, take_silence(), stream_), "k_p2p_selftest");
+  HB_LAUNCH(launch_p2p_barrier(pv, tag(++bseq_), cb_dev_, false, take_silence(), stream_), "k_p2p_barrier");
   int failed = 1;
   HB_CHECK(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, stream_), "memcpy");
   HB_CHECK(hipMemcpyAsync(&failed, d_failed, sizeof(int), hipMemcpyDeviceToHost, stream_), "memcpy");
   HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   ControlBlock cb;
   if (read_control(&cb)) return -1;
-  if (failed || cb.error == SABC_ERR_COMM) { err_ = "peer-to-peer self-test: a shard did not post within the bound"; p2p_on_ = false; return -1; }
-  for (int q = 0; q < np; ++q) {
+  bool slots_ok = !(failed || cb.error == SABC_ERR_COMM);
+  std::string why = slots_ok ? "" : "peer-to-peer self-test: a shard did not post within the bound";
+  for (int q = 0; slots_ok && q < np; ++q) {
     double want = 0.0;
     for (int r = 0; r < W; ++r) { const double x = (double)(r + 1) * (q + 1) + (q == 3 ? 0.1 : 0.0); want = r == 0 ? x : want + x; }
-    if (out[q] != want) { err_ = "peer-to-peer self-test: wrong sums came back through the slots"; p2p_on_ = false; return -1; }
+    if (out[q] != want) { slots_ok = false; why = "peer-to-peer self-test: wrong sums came back through the slots"; }
   }
+  // the second half runs whatever the first said: the shards stay in step (its barriers return at once behind an error)
+  const int prc = selftest_patterns(pv);
+  if (!slots_ok) { err_ = why; p2p_on_ = false; return -1; }
+  if (prc) { p2p_on_ = false; return -1; }
+  return 0;
+}
+
+// What the transport reads (kernels.hip: k_p2p_pattern_*): two rounds of write -> barrier -> read every shard's samples ->
+// barrier, then the parked values go back.  Works on live populations (a set-up after sabc_initialize).
+int HipBackend::selftest_patterns(const P2PView &pv) {
+  const int64_t len[3] = {(int64_t)(m_.d + m_.s + 1) * sh_.cap, (int64_t)(m_.d + m_.s + 1) * sh_.cap, (int64_t)m_.s * sh_.cap};
+  double *own[3] = {pop_[0], pop_[1], rho_};
+  const double *peers[3][kMaxPeers];
+  for (int r = 0; r < kMaxPeers; ++r) { peers[0][r] = peer_pop_[0][r]; peers[1][r] = peer_pop_[1][r]; peers[2][r] = peer_rho_[r]; }
+  double *save = p2p_test_dev_ + 2 * kMaxPartials + 2;
+  unsigned int *d_out = (unsigned int *)(save + p2p_pattern_save_words());
+  unsigned int res[2][2] = {{0, 0}, {0, 0}};
+  for (int round = 1; round <= 2; ++round) {
+    HB_LAUNCH(launch_p2p_pattern_write(own, len, save, gen_, round, sh_.rank, round == 1 ? 0 : 1, stream_), "k_p2p_pattern_write");
+    HB_LAUNCH(launch_p2p_barrier(pv, tag(++bseq_), cb_dev_, false, take_silence(), stream_), "k_p2p_barrier");   // every shard's pattern is written
+    HB_CHECK(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned int), stream_), "memset");
+    // (test hook: a shard told to see stale data compares the second round against a pattern nobody wrote)
+    const int expect = (round == 2 && p2p_stale_ > 0) ? 3 : round;
+    HB_LAUNCH(launch_p2p_pattern_check(peers, len, gen_, expect, sh_.world, d_out, stream_), "k_p2p_pattern_check");
+    HB_CHECK(hipMemcpyAsync(res[round - 1], d_out, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, stream_), "memcpy");
+    HB_LAUNCH(launch_p2p_barrier(pv, tag(++bseq_), cb_dev_, false, take_silence(), stream_), "k_p2p_barrier");   // every shard has read
+  }
+  if (p2p_stale_ > 0) --p2p_stale_;
+  HB_LAUNCH(launch_p2p_pattern_write(own, len, save, gen_, 0, sh_.rank, 2, stream_), "k_p2p_pattern_write (restore)");
+  HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+  ControlBlock cb;
+  if (read_control(&cb)) return -1;
+  if (cb.error == SABC_ERR_COMM) { err_ = "peer-to-peer self-test: a shard did not reach a barrier within the bound"; return -1; }
+  for (int round = 1; round <= 2; ++round)
+    if (res[round - 1][0]) {
+      static const char *what[3] = {"population buffer 0", "population buffer 1", "rho"};
+      const unsigned w = res[round - 1][1];
+      char buf[256];
+      std::snprintf(buf, sizeof(buf), "peer-to-peer self-test: %u of the words read from the shards' memory were not what their owners wrote "
+                    "(round %d; first: shard %u, %s, sample %u) -- a kernel boundary does not make a peer's plain device memory visible here",
+                    res[round - 1][0], round, w >> 28, what[((w >> 24) & 15) % 3], w & 0xFFFFFFu);
+      err_ = buf;
+      return -1;
+    }
   return 0;
 }
 
@@ -1073,14 +1226,14 @@ int HipBackend::restore_snapshot() {
 
 int HipBackend::p2p_barrier(bool guarded) {
   if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
-  HB_LAUNCH(launch_p2p_barrier(p2p_view(), ++bseq_, cb_dev_, guarded, take_silence(), stream_), "k_p2p_barrier");
+  HB_LAUNCH(launch_p2p_barrier(p2p_view(), tag(++bseq_), cb_dev_, guarded, take_silence(), stream_), "k_p2p_barrier");
   return 0;
 }
 
 int HipBackend::p2p_commit(int status, bool wait) {
   if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
   if (pending_rows_ >= 0 && flush_reduce()) return -1;
-  HB_LAUNCH(launch_p2p_commit(p2p_view(), ++call_, status, wait, cb_dev_, take_silence(), stream_), "k_p2p_commit");
+  HB_LAUNCH(launch_p2p_commit(p2p_view(), tag(++call_), status, wait, cb_dev_, take_silence(), stream_), "k_p2p_commit");
   return 0;
 }
 
@@ -1098,7 +1251,7 @@ int HipBackend::partner_view_p2p(PartnerView *pv) {
   pv->base = nullptr;
   pv->rank_stride = 0;
   pv->cap = sh_.cap;
-  for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peer_pop_[cur_][r] : nullptr;   // every shard flips `cur_` in step
+  for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peer_pop_cur(r) : nullptr;   // the OWNER's current buffer
   return 0;
 }
 
@@ -1111,13 +1264,13 @@ int HipBackend::resample_p2p(double delta, uint64_t iter) {
   if (p2p_barrier(false)) return -1;                     // every shard's weight row is written
   ShardBlocks b = flat_blocks(nullptr, rows, sh_.cap, sh_.world);
   b.direct = 1;
-  for (int r = 0; r < sh_.world; ++r) b.peer[r] = peer_pop_[cur_][r];
+  for (int r = 0; r < sh_.world; ++r) b.peer[r] = peer_pop_cur(r);
   HB_LAUNCH(launch_weight_scan(b, sh_.n_global, block_sums_, cum_, totals_dev_, totals_host_dev_, stream_), "weight scan");
   launches_ += 2;
   const int nxt = 1 - cur_;
   HB_LAUNCH(launch_resample_gather(m_, b, sh_.n_global, cum_, block_sums_, totals_dev_, iter, pop_ptrs(nxt), stream_), "k_resample_gather");   // :129-132
   prof_end(SABC_KERNEL_RESAMPLE);
-  cur_ = nxt;
+  flip_cur();
   return 0;
 }
 

@@ -6,6 +6,7 @@
 #include <vector>
 #include "engine.hpp"
 #include "kernels.hpp"
+#include "p2p_page.hpp"
 
 namespace sabc {
 
@@ -68,7 +69,8 @@ class HipBackend : public Backend {
   int p2p_exchange_pending() override { pending_xchg_ = true; return 0; }
   int p2p_barrier(bool guarded) override;
   int p2p_commit(int status, bool wait) override;
-  void p2p_disable() override { p2p_on_ = false; pending_xchg_ = false; }
+  void p2p_disable() override { (void)p2p_leave(); }
+  bool p2p_peers_present() override;                // every peer's host page still says `active` for this generation
   int build_cdf_p2p(int64_t *len_out, int *any_negative) override;
   int partner_view_p2p(PartnerView *pv) override;
   int resample_p2p(double delta, uint64_t iter) override;
@@ -77,9 +79,16 @@ class HipBackend : public Backend {
   int p2p_descriptor(P2PDesc *out);                 // allocates the slot area on first use
   int p2p_init(const P2PDesc *all);                 // maps every peer's slots, populations and rho; switches the transport on
   int p2p_selftest();
+  int p2p_leave();                                  // p2p.hpp "LEAVES": leaving -> leave words -> drain -> unmap -> released
+  void p2p_set_destroy_wait(double ms) { destroy_wait_ms_ = ms; }
+  void p2p_inject_stale(int n) { p2p_stale_ = n > 0 ? n : 0; }
+  static int64_t parked_bytes();
   void p2p_set_timeout(double ms) { if (ms > 0) p2p_timeout_ms_ = ms; }
   // test hook: n > 0: the next n posts are skipped; n < 0: -n more posts go out, then one is skipped
-  void p2p_inject_silence(int n) { if (n >= 0) { p2p_skip_ = 0; p2p_silent_ = n; } else { p2p_skip_ = -n; p2p_silent_ = 1; } }
+  void p2p_inject_silence(int n) { p2p_loss_ = false; if (n >= 0) { p2p_skip_ = 0; p2p_silent_ = n; } else { p2p_skip_ = -n; p2p_silent_ = 1; } }
+  // test hook: n more posts go out, then one reaches only this shard's OWN slots (a post lost on the wire: the shard itself
+  // carries on with its peers' rows, they run into the bound)
+  void p2p_inject_loss(int n) { p2p_loss_ = true; p2p_skip_ = n > 0 ? n : 0; p2p_silent_ = 1; }
   int64_t kernel_launches() const { return launches_; }
   // host-simulator mode: seconds spent inside the caller's callbacks so far / calls of f_dist; particles per chunk
   double host_callback_seconds() const { return host_cb_seconds_; }
@@ -178,22 +187,39 @@ class HipBackend : public Backend {
   // peer-to-peer transport
   int build_cdf_blocks(const ShardBlocks &rho_blocks, int64_t *len_out, int *any_negative);
   P2PView p2p_view() const;
-  bool take_silence() {
-    if (p2p_skip_ > 0) { --p2p_skip_; return false; }
-    if (p2p_silent_ > 0) { --p2p_silent_; return true; }
-    return false;
+  int take_silence() {                                    // 0 | 1 skipped | 2 own slots only
+    if (p2p_skip_ > 0) { --p2p_skip_; return 0; }
+    if (p2p_silent_ > 0) { --p2p_silent_; return p2p_loss_ ? 2 : 1; }
+    return 0;
   }
-  void p2p_close();
+  bool p2p_finish();                                      // destructor: leave, wait for the peers' `released`; false = park
+  void flip_cur() { cur_ = 1 - cur_; ++flips_; if (page_) page_->cur_parity.store((uint32_t)cur_, std::memory_order_relaxed); }
+  // a peer's CURRENT population: indexed by the owner's parity at set-up + the flips since (p2p.hpp: P2PDesc::cur)
+  double *peer_pop_cur(int r) const { return peer_pop_[(peer_cur0_[r] ^ (int)(flips_ & 1u)) & 1][r]; }
+  uint32_t tag(uint32_t seq) const { return p2p_tag(gen_, seq); }
+  int selftest_patterns(const P2PView &pv);
   uint64_t *slots_ = nullptr;                             // this shard's slot area (fine-grained device memory)
   uint64_t *peer_slots_[kMaxPeers] = {nullptr};
   double *peer_pop_[2][kMaxPeers] = {{nullptr}};
   double *peer_rho_[kMaxPeers] = {nullptr};
-  std::vector<void *> ipc_opened_;                        // what hipIpcOpenMemHandle returned (closed on destroy)
+  int peer_cur0_[kMaxPeers] = {0};                        // the owner's parity when the descriptors were written
+  uint32_t flips_ = 0;                                    // buffer flips of THIS shard since then (in step on all shards)
+  std::vector<void *> ipc_opened_;                        // what hipIpcOpenMemHandle returned (closed when this shard leaves)
+  P2PHostPage *page_ = nullptr;                           // this shard's host page (POSIX shared memory)
+  char page_name_[48] = {0};
+  const P2PHostPage *peer_page_[kMaxPeers] = {nullptr};
+  bool peer_page_shm_[kMaxPeers] = {false};               // opened by name (to be unmapped), not a pointer of this process
+  uint32_t gen_ = 0;                                      // generation of the current (or last) set-up
+  bool mapped_ = false;                                   // the peers' memory is mapped
+  bool exported_ = false;                                 // a descriptor has left: peers may have mapped this shard's memory
+  double destroy_wait_ms_ = -1.0;                         // < 0: the bound of the waits
+  int p2p_stale_ = 0;
   bool p2p_on_ = false, pending_xchg_ = false;
   uint32_t xseq_ = 0, bseq_ = 0, call_ = 0;               // exchange / barrier / call sequence numbers (the same on every shard)
   double p2p_timeout_ms_ = 5000.0;
   int wall_clock_khz_ = 100000;                           // s_memrealtime: 100 MHz unless the device says otherwise
   int p2p_silent_ = 0, p2p_skip_ = 0;
+  bool p2p_loss_ = false;
   double *p2p_test_dev_ = nullptr;
   double *snap_pop_ = nullptr, *snap_rho_ = nullptr;     // device-side copy of the particles at the entry of a call
   int64_t launches_ = 0;

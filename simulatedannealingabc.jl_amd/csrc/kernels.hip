@@ -657,12 +657,23 @@ __device__ __forceinline__ uint64_t p2p_load(const uint64_t *p) {
 }
 __device__ __forceinline__ uint64_t p2p_clock() { return (uint64_t)wall_clock64(); }
 
-// spin until the word's upper half is `seq`; gives up after `ticks` (or as soon as another lane of the workgroup has)
+// spin until the word's upper half is the tag `seq`; gives up after `ticks`, as soon as another lane of the workgroup has,
+// or as soon as the awaited shard has LEFT the group (its leave word in this shard's slots carries the tag's generation:
+// p2p.hpp) -- *failed = 1 + peer, + 16 when the peer left
 __device__ __forceinline__ uint64_t p2p_wait_word(const uint64_t *src, uint32_t seq, uint64_t t0, uint64_t ticks, volatile int *failed,
-                                                  int peer) {
+                                                  int peer, const uint64_t *my_slots) {
   uint64_t w = p2p_load(src);
   for (uint32_t polls = 1; (uint32_t)(w >> 32) != seq; ++polls) {
-    if ((polls & 15u) == 0 && (*failed || p2p_clock() - t0 > ticks)) { if (!*failed) *failed = 1 + peer; break; }
+    if ((polls & 15u) == 0) {
+      if (*failed) break;
+      if (p2p_clock() - t0 > ticks) { *failed = 1 + peer; break; }
+      const uint64_t lw = p2p_load(my_slots + kP2PLeaveOff + peer);
+      if ((uint32_t)(lw >> 32) == p2p_tag_gen(seq) && (uint32_t)lw == 1u) {
+        w = p2p_load(src);                                   // (what it posted before it left still counts)
+        if ((uint32_t)(w >> 32) != seq) *failed = 17 + peer;
+        break;
+      }
+    }
     __builtin_amdgcn_s_sleep(2);
     w = p2p_load(src);
   }
@@ -675,7 +686,8 @@ __device__ __forceinline__ void p2p_fail(ControlBlock *cb, ControlBlock *lcb, co
                                          uint32_t seq) {
   cb->error = SABC_ERR_COMM;
   cb->halt = 1;
-  cb->comm_where = (kind << 24) | (((failed - 1) & 15) << 20) | (int)(seq & 0xFFFFFu);
+  // kind: 1 sums exchange | 2 barrier | 3 end-of-call status; + 4 when the shard waited for has left the group
+  cb->comm_where = ((kind + (failed > 16 ? 4 : 0)) << 24) | (((failed - 1) & 15) << 20) | (int)(seq & kP2PSeqMask);
   if (lcb) { lcb->error = SABC_ERR_COMM; lcb->halt = 1; lcb->comm_where = cb->comm_where; }
   __threadfence();
   if (lcb && a && ring && a->notify_seq != 0) mailbox_post(ring, *a, *lcb);
@@ -688,16 +700,17 @@ __device__ __forceinline__ bool p2p_allreduce_rows(const P2PView &pv, const uint
                                                    uint32_t *words, volatile int *failed, const int silent) {
   const int W = pv.world, nw = 2 * np, ring = (int)(seq % kP2PRing);
   const uint32_t *half = reinterpret_cast<const uint32_t *>(mine);
-  if (!silent)
+  if (silent != 1)                                   // test hook: 1 = nothing is posted, 2 = the post reaches this shard's own slots only
     for (int i = threadIdx.x; i < W * nw; i += blockDim.x) {
       const int p = i / nw, t = i - p * nw;
+      if (silent == 2 && p != pv.rank) continue;
       p2p_store(pv.slots[p] + kP2PSumsOff + ((int64_t)ring * kMaxPeers + pv.rank) * kP2PWords + t, ((uint64_t)seq << 32) | half[t]);
     }
   const uint64_t t0 = p2p_clock();
   for (int i = threadIdx.x; i < W * nw; i += blockDim.x) {
     const int r = i / nw, t = i - r * nw;
     const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PSumsOff + ((int64_t)ring * kMaxPeers + r) * kP2PWords + t, seq, t0,
-                                     pv.timeout_ticks, failed, r);
+                                     pv.timeout_ticks, failed, r, pv.slots[pv.rank]);
     words[i] = (uint32_t)w;
   }
   __syncthreads();
@@ -878,9 +891,10 @@ k_p2p_barrier(const P2PView pv, const uint32_t seq, ControlBlock *cb, const int 
   if ((guarded && cb->halt) || cb->error == SABC_ERR_COMM) return;        // the same on every shard (see k_reduce_control)
   const int r = threadIdx.x, ring = (int)(seq % kP2PRing);
   __threadfence_system();
-  if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PBarOff + (int64_t)ring * kMaxPeers + pv.rank, ((uint64_t)seq << 32) | 1u);
+  if (r < pv.world && silent != 1 && (silent != 2 || r == pv.rank)) p2p_store(pv.slots[r] + kP2PBarOff + (int64_t)ring * kMaxPeers + pv.rank, ((uint64_t)seq << 32) | 1u);
   if (r < pv.world)
-    (void)p2p_wait_word(pv.slots[pv.rank] + kP2PBarOff + (int64_t)ring * kMaxPeers + r, seq, p2p_clock(), pv.timeout_ticks, &failed, r);
+    (void)p2p_wait_word(pv.slots[pv.rank] + kP2PBarOff + (int64_t)ring * kMaxPeers + r, seq, p2p_clock(), pv.timeout_ticks, &failed, r,
+                        pv.slots[pv.rank]);
   __syncthreads();
   if (threadIdx.x == 0 && failed) p2p_fail(cb, nullptr, nullptr, nullptr, 2, failed, seq);
   __threadfence_system();
@@ -896,10 +910,11 @@ k_p2p_commit(const P2PView pv, const uint32_t call, const int status, const int 
   __syncthreads();
   const int r = threadIdx.x;
   const int mine = (status != 0 || cb->error != 0) ? 1 : 0;
-  if (r < pv.world && !silent) p2p_store(pv.slots[r] + kP2PCommitOff + pv.rank, ((uint64_t)call << 32) | (uint32_t)mine);
+  if (r < pv.world && silent != 1 && (silent != 2 || r == pv.rank)) p2p_store(pv.slots[r] + kP2PCommitOff + pv.rank, ((uint64_t)call << 32) | (uint32_t)mine);
   if (!wait) return;
   if (r < pv.world) {
-    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PCommitOff + r, call, p2p_clock(), pv.timeout_ticks, &failed, r);
+    const uint64_t w = p2p_wait_word(pv.slots[pv.rank] + kP2PCommitOff + r, call, p2p_clock(), pv.timeout_ticks, &failed, r,
+                                     pv.slots[pv.rank]);
     if ((uint32_t)w != 0u && !failed) failed = 1 + r;                     // the peer's call failed
   }
   __syncthreads();
@@ -919,6 +934,58 @@ k_p2p_selftest(const P2PView pv, const uint32_t seq, const int np, const double 
   const bool ok = p2p_allreduce_rows(pv, seq, np, sums, words, &failed, silent);
   if (ok && (int)threadIdx.x < np) out[threadIdx.x] = sums[threadIdx.x];
   if (threadIdx.x == 0) *failed_out = ok ? 0 : failed;
+}
+
+// This shard leaves the group of generation `gen`: one word into every peer's slots (p2p.hpp); lane r tells shard r.
+__global__ void __launch_bounds__(64) k_p2p_leave(const P2PView pv, const uint32_t gen) {
+  const int r = threadIdx.x;
+  if (r < pv.world && pv.slots[r]) p2p_store(pv.slots[r] + kP2PLeaveOff + pv.rank, ((uint64_t)gen << 32) | 1u);
+}
+
+// First contact, second half (sabc_comm_p2p_selftest): what the transport READS.  Partners, resampled rows and the ECDF
+// build read a peer's populations and rho -- plain device memory, written by the owner's kernels, made visible by nothing but
+// a kernel boundary on each side of a flag (p2p.hpp).  Every shard writes a pattern tagged with (generation, round, rank,
+// buffer, sample) into `count` doubles spread evenly over each of its three buffers (mode 0: after parking what was there
+// in `save`; mode 1: the second round), a barrier, every shard reads every shard's samples through its mappings and counts
+// what is not the pattern; mode 2 puts the parked values back.
+struct PatternBufs {
+  uint64_t *buf[3];              // population buffer 0, population buffer 1, rho (as 64-bit words)
+  int64_t len[3];                // doubles in each
+  int32_t count[3];              // samples in each (<= kPatternSamples)
+};
+constexpr int kPatternSamples = 1024;
+__device__ __forceinline__ uint64_t pattern_word(uint32_t gen, int round, int rank, int b, int k) {
+  return 0x5AB0000000000000ull | ((uint64_t)(gen & 0xFFFu) << 40) | ((uint64_t)(round & 0xFF) << 32) | ((uint64_t)(rank & 0xFF) << 24) |
+         ((uint64_t)(b & 0xF) << 20) | (uint64_t)(k & 0xFFFFF);
+}
+__device__ __forceinline__ int64_t pattern_index(int64_t len, int count, int k) { return (int64_t)k * (len / count); }
+
+__global__ void __launch_bounds__(256)
+k_p2p_pattern_write(const PatternBufs own, uint64_t *__restrict__ save, const uint32_t gen, const int round, const int rank, const int mode) {
+  const int b = blockIdx.y;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < own.count[b]; k += gridDim.x * blockDim.x) {
+    uint64_t *p = own.buf[b] + pattern_index(own.len[b], own.count[b], k);
+    if (mode == 2) { *p = save[b * kPatternSamples + k]; continue; }
+    if (mode == 0) save[b * kPatternSamples + k] = *p;
+    *p = pattern_word(gen, round, rank, b, k);
+  }
+}
+
+struct PatternPeers {
+  const uint64_t *buf[3][kMaxPeers];
+};
+// out[0] = mismatches, out[1] = first mismatch as rank << 28 | buffer << 24 | sample (valid when out[0] > 0)
+__global__ void __launch_bounds__(256)
+k_p2p_pattern_check(const PatternPeers peers, const PatternBufs geo, const uint32_t gen, const int round, const int world,
+                    unsigned int *__restrict__ out) {
+  const int b = blockIdx.y, r = blockIdx.z;
+  if (r >= world || !peers.buf[b][r]) return;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < geo.count[b]; k += gridDim.x * blockDim.x) {
+    const uint64_t got = peers.buf[b][r][pattern_index(geo.len[b], geo.count[b], k)];    // a plain load, like the transport's
+    if (got != pattern_word(gen, round, r, b, k)) {
+      if (atomicAdd(&out[0], 1u) == 0u) out[1] = ((unsigned)r << 28) | ((unsigned)b << 24) | (unsigned)k;
+    }
+  }
 }
 
 // K3 over the shard: u = cdf(rho)  (:190-192)
@@ -1727,7 +1794,7 @@ int launch_reduce_partials(const double *partials, int64_t rows, int np, double 
 
 int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
                           ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream,
-                          const P2PView *pv, uint32_t seq, bool do_control, bool silent) {
+                          const P2PView *pv, uint32_t seq, bool do_control, int silent) {
   (void)reduce_guarded;   // a guarded reduction is always paired with a guarded control step, which is what decides
   XchgArgs x;
   std::memset(&x, 0, sizeof(x));
@@ -1738,7 +1805,7 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
   // (np <= 256 threads' worth: the kernel gives every component of the row a lane)
   const int block = forced && np <= 256 ? forced : ((rows < 0 && np <= 256) || (np <= 64 && rows >= 0 && rows <= (int64_t)24 * (256 / np))) ? 256 : 1024;
   if (pv) {
-    x.pv = *pv; x.seq = seq; x.silent = silent ? 1 : 0;
+    x.pv = *pv; x.seq = seq; x.silent = silent;
     hipLaunchKernelGGL(k_reduce_control<true>, dim3(1), dim3(block), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
   } else {
     hipLaunchKernelGGL(k_reduce_control<false>, dim3(1), dim3(block), 0, stream, partials, rows, np, stage, cb, a, hist, mbox, x);
@@ -1746,19 +1813,51 @@ int launch_reduce_control(const double *partials, int64_t rows, int np, double *
   return SABC_LAUNCH_RC();
 }
 
-int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, bool silent, hipStream_t stream) {
-  hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, stream, pv, seq, cb, guarded ? 1 : 0, silent ? 1 : 0);
+int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, int silent, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, stream, pv, seq, cb, guarded ? 1 : 0, silent);
   return SABC_LAUNCH_RC();
 }
 
-int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, bool silent, hipStream_t stream) {
-  hipLaunchKernelGGL(k_p2p_commit, dim3(1), dim3(64), 0, stream, pv, call, status, wait ? 1 : 0, cb, silent ? 1 : 0);
+int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, int silent, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_commit, dim3(1), dim3(64), 0, stream, pv, call, status, wait ? 1 : 0, cb, silent);
   return SABC_LAUNCH_RC();
 }
 
-int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, bool silent,
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, int silent,
                         hipStream_t stream) {
-  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(1024), 0, stream, pv, seq, np, in, out, failed, silent ? 1 : 0);
+  hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(1024), 0, stream, pv, seq, np, in, out, failed, silent);
+  return SABC_LAUNCH_RC();
+}
+
+int launch_p2p_leave(const P2PView &pv, uint32_t gen, hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_leave, dim3(1), dim3(64), 0, stream, pv, gen);
+  return SABC_LAUNCH_RC();
+}
+
+static PatternBufs pattern_bufs(double *const buf[3], const int64_t len[3]) {
+  PatternBufs g;
+  for (int b = 0; b < 3; ++b) {
+    g.buf[b] = reinterpret_cast<uint64_t *>(buf[b]);
+    g.len[b] = len[b];
+    g.count[b] = (int32_t)(len[b] < kPatternSamples ? len[b] : kPatternSamples);
+  }
+  return g;
+}
+int p2p_pattern_save_words() { return 3 * kPatternSamples; }
+int launch_p2p_pattern_write(double *const buf[3], const int64_t len[3], double *save, uint32_t gen, int round, int rank, int mode,
+                             hipStream_t stream) {
+  hipLaunchKernelGGL(k_p2p_pattern_write, dim3(kPatternSamples / 256, 3), dim3(256), 0, stream, pattern_bufs(buf, len),
+                     reinterpret_cast<uint64_t *>(save), gen, round, rank, mode);
+  return SABC_LAUNCH_RC();
+}
+int launch_p2p_pattern_check(const double *const peer_buf[3][kMaxPeers], const int64_t len[3], uint32_t gen, int round, int world,
+                             unsigned int *out, hipStream_t stream) {
+  PatternPeers pp;
+  for (int b = 0; b < 3; ++b)
+    for (int r = 0; r < kMaxPeers; ++r) pp.buf[b][r] = reinterpret_cast<const uint64_t *>(peer_buf[b][r]);
+  double *none[3] = {nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_p2p_pattern_check, dim3(kPatternSamples / 256, 3, world), dim3(256), 0, stream, pp, pattern_bufs(none, len), gen,
+                     round, world, out);
   return SABC_LAUNCH_RC();
 }
 

@@ -114,12 +114,22 @@ int launch_control(ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox
 // rows < 0: the shard's own sums are already in `stage`.  do_control = false: the global sums into `stage`, nothing else.
 int launch_reduce_control(const double *partials, int64_t rows, int np, double *stage, bool reduce_guarded,
                           ControlBlock *cb, const ControlArgs &a, double *hist, Mailbox *mbox, hipStream_t stream,
-                          const P2PView *pv = nullptr, uint32_t seq = 0, bool do_control = true, bool silent = false);
+                          const P2PView *pv = nullptr, uint32_t seq = 0, bool do_control = true, int silent = 0);
 // flag barrier between the shards' streams / end-of-call status exchange / a row of known values through the slots
-int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, bool silent, hipStream_t stream);
-int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, bool silent, hipStream_t stream);
-int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, bool silent,
+// (silent: test hook -- 1 = this post is skipped, 2 = it reaches this shard's own slots only)
+int launch_p2p_barrier(const P2PView &pv, uint32_t seq, ControlBlock *cb, bool guarded, int silent, hipStream_t stream);
+int launch_p2p_commit(const P2PView &pv, uint32_t call, int status, bool wait, ControlBlock *cb, int silent, hipStream_t stream);
+int launch_p2p_selftest(const P2PView &pv, uint32_t seq, int np, const double *in, double *out, int *failed, int silent,
                         hipStream_t stream);
+// this shard leaves the group of generation `gen`: a word into every peer's slots
+int launch_p2p_leave(const P2PView &pv, uint32_t gen, hipStream_t stream);
+// self-test of what the transport reads (kernels.hip: k_p2p_pattern_*): buf / len = population buffer 0, 1, rho of this shard
+// (write: mode 0 park + pattern, 1 pattern, 2 put back) or of every shard as mapped here (check: out[0] = mismatches)
+int p2p_pattern_save_words();
+int launch_p2p_pattern_write(double *const buf[3], const int64_t len[3], double *save, uint32_t gen, int round, int rank, int mode,
+                             hipStream_t stream);
+int launch_p2p_pattern_check(const double *const peer_buf[3][kMaxPeers], const int64_t len[3], uint32_t gen, int round, int world,
+                             unsigned int *out, hipStream_t stream);
 // K5a: w_i = exp(-sum_j u_ij delta / ubar_j) into the weight row       :126-127
 int launch_resample_weights(const ModelDesc &m, PopPtrs pp, const ControlBlock *cb, double n_global, double delta,
                             hipStream_t stream);

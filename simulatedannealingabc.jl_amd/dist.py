@@ -97,47 +97,20 @@ def _all_ok(ok, device, group=None):
 def try_p2p(handle, device, group=None, timeout_ms=None):
     """Switch `handle` to the peer-to-peer transport (the shards of one node exchange through each other's HBM: one launch
     per population update instead of reduce -> allreduce -> control; partners and resampled rows read from their owners) if
-    every rank can: world <= 8, all ranks on this host, every peer's memory maps (hipIpc), and the library's self-test --
-    a row of known values through the slots with a bounded wait -- passes everywhere.  The collectives already installed
-    stay as the fallback.  Returns True when the handle now runs peer to peer (the same answer on every rank)."""
+    every rank can: world <= 8, every peer's memory maps (hipIpc) and the library's self-test -- known rows through the slots,
+    and patterns written into the populations read back through the mappings -- passes everywhere.  The agreement between
+    the ranks happens INSIDE the library (sabc_comm_p2p_setup, over the collectives already installed, which stay as the
+    fallback): a Julia or plain-C host gets the same guarantee.  Returns True when the handle now runs peer to peer (the same
+    answer on every rank)."""
     import os
-    import socket
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    ok = 2 <= world <= 8
     if not timeout_ms:
         timeout_ms = float(os.environ.get("SABC_P2P_TIMEOUT_MS", "0") or 0)      # bound of every peer-to-peer wait (default 5000)
-    desc = None
-    if ok:
-        try:
-            desc = handle.p2p_descriptor()
-        except Exception as e:
-            print(f"[sabc] peer-to-peer descriptor failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
-            ok = False
-    box = [None] * world
-    dist.all_gather_object(box, (socket.gethostname(), desc), group=group)
-    ok = ok and all(b[1] is not None for b in box) and len({b[0] for b in box}) == 1
-    if not _all_ok(ok, device, group):
-        return False
-    try:
-        if timeout_ms:
-            handle.p2p_set_timeout(timeout_ms)
-        handle.p2p_init([b[1] for b in box])
-    except Exception as e:
-        print(f"[sabc] peer-to-peer mapping failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
-        ok = False
-    if not _all_ok(ok, device, group):      # somebody could not map a peer: nobody runs the self-test (it would wait for them)
-        handle.p2p_disable()
-        return False
-    try:
-        handle.p2p_selftest()
-    except Exception as e:
-        print(f"[sabc] peer-to-peer self-test failed on rank {dist.get_rank(group)}: {e!r}", flush=True)
-        ok = False
-    if not _all_ok(ok, device, group):
-        handle.p2p_disable()
-        return False
-    return True
+    if timeout_ms:
+        handle.p2p_set_timeout(timeout_ms)
+    ok = handle.p2p_setup()
+    if not ok and handle.p2p_setup_note and os.environ.get("SABC_P2P_VERBOSE"):
+        print(f"[sabc] {handle.p2p_setup_note}", flush=True)
+    return ok
 
 
 def install_collectives(handle, device, group=None, prefer=None, alltoallv=True, p2p=None):

@@ -84,12 +84,19 @@ class SabcHandle:
 
     # ---- lifetime ----
     def close(self):
+        """sabc_destroy.  On the peer-to-peer transport the shard LEAVES its group first (the peers are told, nothing of theirs
+        stays mapped) and what they had mapped is freed once they have acknowledged -- bounded; otherwise it is parked until
+        the process exits (include/sabc_hip.h, LEAVING).  No barrier with the other ranks is needed."""
         if getattr(self, "_h", None):
             self._L.sabc_destroy(self._h)
             self._h = None
 
     def __del__(self):
+        # a finalizer runs at an arbitrary time on each rank and must not wait for peers: what a peer has not released by now
+        # is parked at once
         try:
+            if getattr(self, "_h", None) and hasattr(self._L, "sabc_comm_p2p_set_destroy_wait"):
+                self._L.sabc_comm_p2p_set_destroy_wait(self._h, 0.0)
             self.close()
         except Exception:
             pass
@@ -108,11 +115,16 @@ class SabcHandle:
     def initialize(self, n_simulation):
         self._check(self._L.sabc_initialize(self._h, int(n_simulation)))
 
-    def update(self, *, n_simulation, proposal, v=1.0, delta=0.1, resample=None, checkpoint_history=1):
+    def update(self, *, n_simulation, proposal, v=1.0, delta=0.1, resample=None, checkpoint_history=1, history_phase=0,
+               more_chunks_follow=False):
+        """history_phase / more_chunks_follow: this call is one chunk of an update_population! call the wrapper has cut up for
+        its progress lines -- population updates already done by the earlier chunks; whether another chunk follows (then the
+        final history push of :378-382 is not this call's)."""
         a = UpdateArgs()
         a.n_simulation, a.v, a.delta = int(n_simulation), float(v), float(delta)
         a.resample = float(2 * self.cfg.n_particles if resample is None else resample)
         a.checkpoint_history = int(checkpoint_history)
+        a.history_phase, a.more_chunks_follow = int(history_phase), int(bool(more_chunks_follow))
         a.proposal_kind, a.proposal_p0, a.proposal_p1 = proposal.descriptor()
         self._check(self._L.sabc_update(self._h, C.byref(a)))
 
@@ -162,6 +174,30 @@ class SabcHandle:
 
     def p2p_selftest(self):
         self._check(self._L.sabc_comm_p2p_selftest(self._h))
+
+    def p2p_setup(self) -> bool:
+        """The whole set-up in one collective call (sabc_comm_p2p_setup): descriptors over the installed collectives -> map
+        -> agreement -> self-test -> agreement.  True: every shard now runs peer to peer; False: every shard stays on the
+        collectives (`p2p_setup_note` says why)."""
+        rc = self._L.sabc_comm_p2p_setup(self._h)
+        if rc < 0:
+            self._check(rc)
+        self.p2p_setup_note = self._L.sabc_last_error(self._h).decode("utf-8", "replace") if rc == 0 else ""
+        return rc == 1
+
+    def p2p_set_destroy_wait(self, milliseconds):
+        self._check(self._L.sabc_comm_p2p_set_destroy_wait(self._h, float(milliseconds)))
+
+    def p2p_parked_bytes(self):
+        return int(self._L.sabc_comm_p2p_parked_bytes())
+
+    def p2p_inject_loss(self, n=0):
+        """Test hook: n more posts go out, then one reaches only this shard's own slots (lost on the wire)."""
+        self._check(self._L.sabc_comm_p2p_inject_loss(self._h, int(n)))
+
+    def p2p_inject_stale(self, n=1):
+        """Test hook: this shard's next self-test reads its peers' memory as if a stale line had been served."""
+        self._check(self._L.sabc_comm_p2p_inject_stale(self._h, int(n)))
 
     def p2p_set_timeout(self, milliseconds):
         self._check(self._L.sabc_comm_p2p_set_timeout(self._h, float(milliseconds)))

@@ -61,9 +61,10 @@ struct CUpdateArgs
     resample::Float64
     checkpoint_history::Int64
     proposal_kind::Int32
-    reserved::Int32
+    more_chunks_follow::Int32
     proposal_p0::Float64
     proposal_p1::Float64
+    history_phase::Int64
 end
 
 # ---- proposals: same constructors and errors as src/proposals.jl ----
@@ -300,7 +301,7 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
     pd = (host_prior || source_prior) ? [(Int32(0), 0.0, 1.0, 0.0, 0.0) for _ in 1:length(prior)] : prior_descriptors(prior)
     joint, chol = host_prior ? (Int32(2), Float64[]) : source_prior ? (Int32(3), Float64[]) : prior_chol(prior)
     p = params(f_dist)
-    cfg = Ref(CConfig(5, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
+    cfg = Ref(CConfig(6, device, n_particles, length(pd), n_stats(f_dist), model_id(f_dist), length(p),
                       padtuple(p, MAX_MODEL_PARAMS, Float64),
                       padtuple(first.(pd), MAX_PARA, Int32),
                       padtuple(getindex.(pd, 2), MAX_PARA, Float64), padtuple(getindex.(pd, 3), MAX_PARA, Float64),
@@ -309,8 +310,13 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
                       algorithm == :multi_eps ? 1 : 0, rank, world, 0, v, δ, seed))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:sabc_create, libsabc), Cint, (Ref{CConfig}, Ref{Ptr{Cvoid}}), cfg, h))
+    # A finalizer runs whenever the collector pleases, at a different time on every rank: it must neither free memory a peer
+    # shard may be reading nor wait for peers.  sabc_destroy takes care of the first in any case (the shard LEAVES its
+    # peer-to-peer group in order, include/sabc_hip.h "LEAVING"); a destroy wait of 0 makes it park what a peer has not
+    # released instead of waiting for it.  `close(res)` is the orderly way out: it waits (bounded) and frees.
     finalizer(h) do r
         if r[] != C_NULL
+            ccall((:sabc_comm_p2p_set_destroy_wait, libsabc), Cint, (Ptr{Cvoid}, Cdouble), r[], 0.0)
             ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[])
             delete!(HOST_CALLBACKS, r[])               # the library can no longer call back: release the closure
             r[] = C_NULL
@@ -322,13 +328,13 @@ function create_handle(f_dist::DeviceDistance, prior; n_particles, algorithm, v,
         GC.@preserve comm_id check(h[], ccall((:sabc_comm_init_rccl, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], comm_id))
         check(h[], ccall((:sabc_comm_selftest, libsabc), Cint, (Ptr{Cvoid},), h[]))
         # on top of RCCL: the peer-to-peer transport (the shards of one node exchange through each other's HBM: one launch per
-        # population update instead of reduce -> allreduce -> control).  The descriptors travel over the RCCL allgather just
-        # installed; a rank that cannot map a peer or fails the bounded self-test stays on RCCL -- should the ranks then
-        # disagree, the peer-to-peer ranks' first call times out once and sabc_update repeats it over RCCL by itself.
+        # population update instead of reduce -> allreduce -> control).  ONE collective call: the descriptors travel over
+        # the RCCL allgather just installed, every rank maps its peers and runs the self-test, and the ranks AGREE inside the
+        # library after every step -- either all of them now run peer to peer (1) or all of them stay on RCCL (0): no rank
+        # switches alone and leaves the others to wait out the bound of their first exchange.
         if p2p && world <= 8 && !(f_dist isa HostDistance)
-            rc = ccall((:sabc_comm_p2p_init, libsabc), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), h[], C_NULL)
-            rc == 0 && (rc = ccall((:sabc_comm_p2p_selftest, libsabc), Cint, (Ptr{Cvoid},), h[]))
-            rc == 0 || ccall((:sabc_comm_p2p_disable, libsabc), Cint, (Ptr{Cvoid},), h[])
+            rc = ccall((:sabc_comm_p2p_setup, libsabc), Cint, (Ptr{Cvoid},), h[])
+            rc < 0 && check(h[], rc)
         end
     end
     if f_dist isa DeviceSource
@@ -398,27 +404,39 @@ end
 # Check if a stream is logged (SimulatedAnnealingABC.jl:500)
 is_logging(io) = isa(io, Base.TTY) == false || (get(ENV, "CI", nothing) == "true")
 
-# Progress output needs the device loop to come up for air: the call is split into chunks of population updates.  Chunks
-# are multiples of `checkpoint_history`, which leaves counters, histories and particles exactly as in one call (the final
-# history push of :378-382 then never fires in between).  Same rule as progress_chunk() in ../api.py.
-function progress_chunk(n_pop, cph, show_checkpoint, show_progressbar)
-    chunk = n_pop
+# Progress output needs the device loop to come up for air: `update_population!` is cut into several sabc_update calls.
+# Returns the update counts after which a call ends: every multiple of `show_checkpoint` (:359), every step of the progress
+# bar (a fiftieth of the run), and n_pop.  The cuts may fall anywhere: each call is told how many updates of the loop came
+# before it (history_phase) and whether another follows (more_chunks_follow), so `ix % checkpoint_history` (:367) and the
+# final push (:378-382) see the loop's own numbering -- `show_checkpoint` and `checkpoint_history` are independent moduli,
+# as in the reference.  Same rule as progress_stops() in ../api.py.
+function progress_stops(n_pop, show_checkpoint, show_progressbar)
+    stops = Set{Int}([n_pop])
     if isfinite(show_checkpoint) && show_checkpoint >= 1
-        k = Int(show_checkpoint)
-        k % cph == 0 && (chunk = min(chunk, k))
+        union!(stops, Int(show_checkpoint):Int(show_checkpoint):(n_pop - 1))
     end
     if show_progressbar && n_pop > 0
-        bar = max(cph, (n_pop ÷ 50) ÷ cph * cph)
-        if chunk < n_pop                                # both: a bar step that divides the checkpoint interval
-            while chunk % bar != 0 && bar > cph
-                bar -= cph
-            end
-            chunk % bar == 0 && (chunk = bar)
-        else
-            chunk = min(chunk, bar)
-        end
+        union!(stops, max(n_pop ÷ 50, 1):max(n_pop ÷ 50, 1):(n_pop - 1))
     end
-    max(chunk, 1)
+    sort!(collect(stops))
+end
+
+"""
+    close(res::SABCresult)
+
+Release the device population behind `res` now instead of whenever the collector finalizes it.  On a multi-GPU run this is
+the orderly way out: the shard leaves its peer-to-peer group, waits (bounded) until its peers have unmapped its memory, and
+frees it.  No barrier with the other ranks is needed -- a rank that is still inside `update_population!` when a peer closes
+ends that call over RCCL (or with an error if RCCL is gone too), never with a memory fault.
+"""
+function Base.close(res::SABCresult)
+    r = handle_of(res)
+    if r[] != C_NULL
+        ccall((:sabc_destroy, libsabc), Cvoid, (Ptr{Cvoid},), r[])
+        delete!(HOST_CALLBACKS, r[])
+        r[] = C_NULL
+    end
+    nothing
 end
 
 """
@@ -444,29 +462,27 @@ function update_population!(res::SABCresult, f_dist::DeviceDistance, prior::Dist
                                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), h, θ, res.u, res.ρ))
     kind, p0, p1 = descriptor(proposal)
     n_pop = n_simulation ÷ n_global                                                # :275
-    cph = max(Int(checkpoint_history), 1)
-    chunk = progress_chunk(n_pop, cph, show_checkpoint, show_progressbar)
+    n_pop > 0 && checkpoint_history == 0 && throw(DivideError())                   # `ix % checkpoint_history`, :367
     pmeter = Progress(n_pop; desc="$n_pop population updates:", output=stderr, enabled=show_progressbar)   # :290-291
     t_start = Dates.now()
     done = 0
-    while true
-        todo = n_pop > 0 ? min(chunk, n_pop - done) : 0
+    for stop in progress_stops(n_pop, show_checkpoint, show_progressbar)
+        todo = stop - done
         budget = n_pop > 0 ? todo * n_global : n_simulation                        # a top-up below one update is a no-op (:275)
-        args = Ref(CUpdateArgs(budget, v, δ, resample, checkpoint_history, kind, 0, p0, p1))
+        args = Ref(CUpdateArgs(budget, v, δ, resample, checkpoint_history, kind, stop < n_pop ? 1 : 0, p0, p1, done))
         check(h, ccall((:sabc_update, libsabc), Cint, (Ptr{Cvoid}, Ref{CUpdateArgs}), h, args))
-        done += todo
-        if show_progressbar || (isfinite(show_checkpoint) && done < n_pop)
+        done = stop
+        if show_progressbar || (isfinite(show_checkpoint) && show_checkpoint >= 1)
             eps = Vector{Float64}(undef, MAX_STATS); len = Ref{Int32}(0)
             check(h, ccall((:sabc_get_epsilon, libsabc), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ref{Int32}), h, eps, len))
             ϵ = round.(eps[1:len[]], sigdigits=4)
             show_progressbar && next!(pmeter; step=todo, showvalues=[("ϵ", ϵ)])    # :292,374
-            if isfinite(show_checkpoint) && done < n_pop && done % Int(show_checkpoint) == 0   # :359-364
+            if done > 0 && isfinite(show_checkpoint) && show_checkpoint >= 1 && done % Int(show_checkpoint) == 0   # :359-364
                 eta = ((Dates.now() - t_start) ÷ done) * (n_pop - done)
                 etastr = eta > Dates.Second(1) ? Dates.canonicalize(round(eta, Dates.Second)) : "< 1 Second"
                 @info "Update $done of $n_pop. ϵ: $ϵ, ETA: $(etastr)"; flush(stderr)
             end
         end
-        done >= n_pop && break
     end
     show_progressbar && finish!(pmeter)
     if proposal isa RandomWalk

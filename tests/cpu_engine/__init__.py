@@ -15,7 +15,7 @@ _SRCS = [
     os.path.join(ROOT, "oracle", "sabc_oracle.c"),
 ]
 _DEPS = _SRCS + [os.path.join(ROOT, "simulatedannealingabc.jl_amd", "csrc", f)
-                 for f in ("engine.hpp", "control.hpp", "host_math.hpp", "sabc_types.hpp", "p2p.hpp")] + \
+                 for f in ("engine.hpp", "control.hpp", "host_math.hpp", "sabc_types.hpp", "p2p.hpp", "p2p_setup.hpp")] + \
         [os.path.join(ROOT, "include", "sabc_hip.h"), os.path.join(ROOT, "oracle", "sabc_oracle.h")]
 
 

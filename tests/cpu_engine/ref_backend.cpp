@@ -20,6 +20,7 @@
 #include "../../simulatedannealingabc.jl_amd/csrc/control.hpp"
 #include "../../simulatedannealingabc.jl_amd/csrc/engine.hpp"
 #include "../../simulatedannealingabc.jl_amd/csrc/p2p.hpp"
+#include "../../simulatedannealingabc.jl_amd/csrc/p2p_setup.hpp"
 
 using namespace sabc;
 
@@ -239,7 +240,7 @@ class RefBackend : public Backend {
       xchg_pending_ = false;
       const bool noop = ((a.mode & CTRL_GUARDED) && cb_.halt) || cb_.error == SABC_ERR_COMM;
       if (noop) { post_error_if_any(a); return 0; }
-      if (!p2p_sum_rows(++xseq_)) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; post_error_if_any(a); return 0; }
+      if (!p2p_sum_rows(++xseq_)) { post_error_if_any(a); return 0; }
     }
     if (!control_step(cb_, a, hist_.data(), stage_)) { post_error_if_any(a); return 0; }
     if (a.notify_seq) {
@@ -298,7 +299,7 @@ class RefBackend : public Backend {
       const int64_t r = idx / cap, o = idx - r * cap;
       for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = g[(r * rows_ + row) * cap + o];
     }
-    cur_ = 1 - cur_;
+    flip_cur();
     return 0;
   }
   // the sharded resample (engine.cpp: resample_exchange), same protocol as HipBackend
@@ -342,7 +343,7 @@ class RefBackend : public Backend {
     std::vector<double> &dst = pop_[1 - cur_];
     for (int64_t pos = 0; pos < sh_.n_local; ++pos)
       for (int row = 0; row < rl; ++row) dst[(size_t)row * cap + slot_[(size_t)pos]] = rows_in[pos * rl + row];
-    cur_ = 1 - cur_;
+    flip_cur();
     return 0;
   }
   double last_ess() override { return ess_; }
@@ -372,55 +373,134 @@ class RefBackend : public Backend {
   }
 
   // ---- the peer-to-peer transport of csrc/p2p.hpp between shards living in ONE process (one host thread each): the peers'
-  //      memory is the pointer itself, the slots are atomics, every wait is bounded.  Same protocol as HipBackend's kernels,
-  //      so that engine.cpp's peer-to-peer paths (exchange inside the control step, barrier between the half batches,
-  //      resample and ECDF build over the owners' memory, status exchange, abort, fallback) run where no GPU exists.
+  //      memory is the pointer itself, the slots are atomics, every wait is bounded.  Same protocol as HipBackend's kernels
+  //      -- generation tags, leave words, the host page, the owner's buffer parity -- so that engine.cpp's peer-to-peer paths
+  //      (exchange inside the control step, barrier between the half batches, resample and ECDF build over the owners'
+  //      memory, status exchange, abort, fallback, a shard that leaves) run where no GPU exists.
   bool p2p_active() const override { return p2p_on_; }
   int p2p_exchange_pending() override { xchg_pending_ = true; return 0; }
-  void p2p_disable() override { p2p_on_ = false; xchg_pending_ = false; }
-  void p2p_descriptor(P2PDesc *out) {
+  void p2p_disable() override { p2p_leave(); }
+  const std::string &error() const { return err_; }
+  int p2p_descriptor(P2PDesc *out) {
     std::memset(out, 0, sizeof(*out));
+    p2p_leave();
+    if (fail_export_) { err_ = "test hook: this shard cannot export"; return -1; }
     for (auto &row : slot_seq_) for (auto &x : row) x.store(0);
     for (auto &row : bar_seq_) for (auto &x : row) x.store(0);
     for (auto &x : commit_) x.store(0);
-    xseq_ = bseq_ = call_ = 0; p2p_on_ = false;
+    for (auto &x : leave_) x.store(0);
+    xseq_ = bseq_ = call_ = 0;
     out->magic = kP2PMagic; out->rank = sh_.rank; out->world = sh_.world; out->cap = sh_.cap; out->n_global = sh_.n_global;
     out->d = m_.d; out->s = m_.s;
     out->ptr_slots = (uint64_t)(uintptr_t)this;
+    out->ptr_page = (uint64_t)(uintptr_t)&page_;
+    out->cur = cur_;
+    out->gen_proposal = gen_ >= kP2PMaxGen ? 1u : gen_ + 1u;
+    exported_ = true;
+    return 0;
   }
   int p2p_init(const P2PDesc *all) {
+    uint32_t proposals[kMaxPeers] = {0};
     for (int r = 0; r < sh_.world; ++r) {
-      if (all[r].magic != kP2PMagic || all[r].rank != r || all[r].world != sh_.world) return -1;
-      peers_[r] = (RefBackend *)(uintptr_t)all[r].ptr_slots;
+      if (all[r].magic != kP2PMagic || all[r].rank != r || all[r].world != sh_.world) { err_ = "descriptors do not match"; return -1; }
+      proposals[r] = all[r].gen_proposal;
     }
+    gen_ = p2p_agree_gen(proposals, sh_.world);
+    flips_ = 0;
+    page_.gen.store(gen_); page_.state.store(kP2PNone);
+    mapped_ = true;
+    if (fail_map_) { p2p_leave(); err_ = "test hook: this shard cannot map its peers"; return -1; }
+    for (int r = 0; r < sh_.world; ++r) {
+      peers_[r] = (RefBackend *)(uintptr_t)all[r].ptr_slots;
+      peer_page_[r] = (const P2PHostPage *)(uintptr_t)all[r].ptr_page;
+      peer_cur0_[r] = all[r].cur & 1;
+    }
+    page_.state.store(kP2PActive, std::memory_order_release);
     p2p_on_ = true;
     return 0;
   }
-  void p2p_set_timeout(double ms) { timeout_ms_ = ms; }
-  void p2p_inject_silence(int n) { if (n >= 0) { skip_ = 0; silent_ = n; } else { skip_ = -n; silent_ = 1; } }
-  bool take_silence() {
-    if (skip_ > 0) { --skip_; return false; }
-    if (silent_ > 0) { --silent_; return true; }
-    return false;
+  // p2p.hpp "LEAVES": leaving -> leave words -> (the stream is synchronous here) -> unmap -> released
+  void p2p_leave() {
+    xchg_pending_ = false;
+    p2p_on_ = false;
+    if (!mapped_) return;
+    page_.state.store(kP2PLeaving, std::memory_order_release);
+    for (int r = 0; r < sh_.world; ++r)
+      if (peers_[r]) peers_[r]->leave_[sh_.rank].store(((uint64_t)gen_ << 32) | 1u, std::memory_order_release);
+    for (int r = 0; r < kMaxPeers; ++r) { peers_[r] = nullptr; page_.released[r].store(gen_, std::memory_order_release); }
+    mapped_ = false;
   }
-  template <class A> bool wait_for(A &word, uint64_t want) {
-    const auto t0 = std::chrono::steady_clock::now();
-    while (word.load(std::memory_order_acquire) != want) {
-      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) return false;
-      std::this_thread::yield();
+  bool p2p_peers_present() override {
+    if (!mapped_ || !p2p_on_) return true;
+    for (int r = 0; r < sh_.world; ++r) {
+      if (r == sh_.rank || !peer_page_[r]) continue;
+      if (peer_page_[r]->gen.load(std::memory_order_acquire) != gen_ || peer_page_[r]->state.load(std::memory_order_acquire) != kP2PActive) return false;
     }
     return true;
   }
+  // sabc_destroy: leave, then wait (bounded) for every peer's `released`; false = this object must be parked (a peer may
+  // still hold the pointer)
+  bool p2p_finish() {
+    const P2PHostPage *pages[kMaxPeers];
+    for (int r = 0; r < kMaxPeers; ++r) pages[r] = peer_page_[r];
+    p2p_leave();
+    bool ok = true;
+    if (exported_) {
+      const double wait_ms = destroy_wait_ms_ < 0 ? timeout_ms_ : destroy_wait_ms_;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int r = 0; r < sh_.world; ++r) {
+        if (r == sh_.rank) continue;
+        if (!pages[r] || gen_ == 0) { ok = false; continue; }
+        while (pages[r]->released[sh_.rank].load(std::memory_order_acquire) != gen_ && pages[r]->gen.load(std::memory_order_acquire) <= gen_) {
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > wait_ms) { ok = false; break; }
+          std::this_thread::yield();
+        }
+      }
+    }
+    page_.state.store(kP2PGone, std::memory_order_release);
+    return ok;
+  }
+  void p2p_set_destroy_wait(double ms) { destroy_wait_ms_ = ms; }
+  void p2p_set_timeout(double ms) { timeout_ms_ = ms; }
+  void p2p_inject_silence(int n) { loss_ = false; if (n >= 0) { skip_ = 0; silent_ = n; } else { skip_ = -n; silent_ = 1; } }
+  void p2p_inject_loss(int n) { loss_ = true; skip_ = n > 0 ? n : 0; silent_ = 1; }
+  void p2p_inject_stale(int n) { stale_ = n > 0 ? n : 0; }
+  void p2p_inject_setup_failure(int what) { fail_export_ = what == 1; fail_map_ = what == 2; }
+  int cur_parity() const { return cur_; }
+  int take_silence() {                               // 0 | 1 the post is skipped | 2 it reaches this shard's own slots only
+    if (skip_ > 0) { --skip_; return 0; }
+    if (silent_ > 0) { --silent_; return loss_ ? 2 : 1; }
+    return 0;
+  }
+  uint32_t tag(uint32_t seq) const { return p2p_tag(gen_, seq); }
+  // 0: the word arrived; 1 + r: shard r did not post within the bound; 17 + r: shard r has left the group
+  template <class A> int wait_for(A &word, uint64_t want, int r) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (word.load(std::memory_order_acquire) != want) {
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) return 1 + r;
+      if (leave_[r].load(std::memory_order_acquire) == (((uint64_t)gen_ << 32) | 1u))
+        return word.load(std::memory_order_acquire) == want ? 0 : 17 + r;
+      std::this_thread::yield();
+    }
+    return 0;
+  }
+  void comm_fail(int kind, int failed, uint32_t seq) {
+    cb_.error = SABC_ERR_COMM; cb_.halt = 1;
+    cb_.comm_where = ((kind + (failed > 16 ? 4 : 0)) << 24) | (((failed - 1) & 15) << 20) | (int)(seq & kP2PSeqMask);
+  }
   bool p2p_sum_rows(uint32_t seq) {
     const int W = sh_.world, ring = (int)(seq % kP2PRing);
-    if (!take_silence())
+    const uint32_t t = tag(seq);
+    const int sil = take_silence();
+    if (sil != 1)
       for (int p = 0; p < W; ++p) {
+        if (sil == 2 && p != sh_.rank) continue;
         RefBackend *q = peers_[p];
         for (int c = 0; c < np_; ++c) q->slot_row_[ring][sh_.rank][c] = stage_[c];
-        q->slot_seq_[ring][sh_.rank].store(seq, std::memory_order_release);
+        q->slot_seq_[ring][sh_.rank].store(t, std::memory_order_release);
       }
     for (int r = 0; r < W; ++r)
-      if (!wait_for(slot_seq_[ring][r], (uint64_t)seq)) return false;
+      if (const int f = wait_for(slot_seq_[ring][r], (uint64_t)t, r)) { comm_fail(1, f, seq); return false; }
     for (int c = 0; c < np_; ++c) {
       double a = slot_row_[ring][0][c];
       for (int r = 1; r < W; ++r) a += slot_row_[ring][r][c];               // rank order, like the kernel
@@ -440,31 +520,79 @@ class RefBackend : public Backend {
     const uint32_t seq = ++bseq_;
     if ((guarded && cb_.halt) || cb_.error == SABC_ERR_COMM) return 0;
     const int W = sh_.world, ring = (int)(seq % kP2PRing);
-    if (!take_silence())
-      for (int p = 0; p < W; ++p) peers_[p]->bar_seq_[ring][sh_.rank].store(seq, std::memory_order_release);
+    const uint32_t t = tag(seq);
+    const int sil = take_silence();
+    if (sil != 1)
+      for (int p = 0; p < W; ++p)
+        if (sil != 2 || p == sh_.rank) peers_[p]->bar_seq_[ring][sh_.rank].store(t, std::memory_order_release);
     for (int r = 0; r < W; ++r)
-      if (!wait_for(bar_seq_[ring][r], (uint64_t)seq)) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; return 0; }
+      if (const int f = wait_for(bar_seq_[ring][r], (uint64_t)t, r)) { comm_fail(2, f, seq); return 0; }
     return 0;
   }
   int p2p_commit(int status, bool wait) override {
-    const uint64_t call = ++call_;
+    const uint32_t seq = ++call_;
+    const uint64_t call = tag(seq);
     const uint64_t mine = (status != 0 || cb_.error != 0) ? 1 : 0;
-    if (!take_silence())
-      for (int p = 0; p < sh_.world; ++p) peers_[p]->commit_[sh_.rank].store((call << 8) | mine, std::memory_order_release);
+    const int sil = take_silence();
+    if (sil != 1)
+      for (int p = 0; p < sh_.world; ++p)
+        if (peers_[p] && (sil != 2 || p == sh_.rank)) peers_[p]->commit_[sh_.rank].store((call << 8) | mine, std::memory_order_release);
     if (!wait) return 0;
-    bool failed = false;
-    for (int r = 0; r < sh_.world; ++r) {
+    int failed = 0;
+    for (int r = 0; r < sh_.world && !failed; ++r) {
       const auto t0 = std::chrono::steady_clock::now();
       uint64_t w;
       while (((w = commit_[r].load(std::memory_order_acquire)) >> 8) != call) {
-        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) { failed = true; break; }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > timeout_ms_) { failed = 1 + r; break; }
+        if (leave_[r].load(std::memory_order_acquire) == (((uint64_t)gen_ << 32) | 1u) && (commit_[r].load(std::memory_order_acquire) >> 8) != call) { failed = 17 + r; break; }
         std::this_thread::yield();
       }
-      if (!failed && (w & 0xFF) != 0) failed = true;
+      if (!failed && (w & 0xFF) != 0) failed = 1 + r;
     }
-    if (failed && cb_.error == 0) { cb_.error = SABC_ERR_COMM; cb_.halt = 1; }
+    if (failed && cb_.error == 0) comm_fail(3, failed, seq);
     return 0;
   }
+  // sabc_comm_p2p_selftest: a row through the slots, a barrier, and what the transport reads -- a tagged word in each of
+  // this shard's three buffers, read by every peer through its "mapping", two rounds, the words put back
+  int p2p_selftest() {
+    if (!p2p_on_) { err_ = "the peer-to-peer transport is not initialised"; return -1; }
+    const double keep[3] = {stage_[0], stage_[1], stage_[2]};
+    for (int q = 0; q < 3; ++q) stage_[q] = (double)(sh_.rank + 1) * (q + 1);
+    const int np_keep = np_;
+    np_ = 3;
+    const bool ok = p2p_sum_rows(++xseq_);
+    np_ = np_keep;
+    bool sums_ok = ok;
+    for (int q = 0; ok && q < 3; ++q) sums_ok = sums_ok && stage_[q] == 0.5 * sh_.world * (sh_.world + 1) * (q + 1);
+    for (int q = 0; q < 3; ++q) stage_[q] = keep[q];
+    p2p_barrier(false);
+    double *own[3] = {pop_[0].data(), pop_[1].data(), rho_.data()};
+    double saved[3];
+    int mismatches = 0;
+    for (int round = 1; round <= 2; ++round) {
+      for (int b = 0; b < 3; ++b) {
+        if (round == 1) saved[b] = own[b][0];
+        own[b][0] = pattern(round, sh_.rank, b);
+      }
+      p2p_barrier(false);
+      const int expect = (round == 2 && stale_ > 0) ? 3 : round;
+      for (int r = 0; r < sh_.world && cb_.error == 0; ++r) {
+        const double *theirs[3] = {peers_[r]->pop_[0].data(), peers_[r]->pop_[1].data(), peers_[r]->rho_.data()};
+        for (int b = 0; b < 3; ++b) mismatches += theirs[b][0] != pattern(expect, r, b);
+      }
+      p2p_barrier(false);
+    }
+    if (stale_ > 0) --stale_;
+    for (int b = 0; b < 3; ++b) own[b][0] = saved[b];
+    if (!ok || cb_.error == SABC_ERR_COMM) { err_ = "peer-to-peer self-test: a shard did not post within the bound"; cb_.error = 0; cb_.halt = 0; p2p_on_ = false; return -1; }
+    if (!sums_ok) { err_ = "peer-to-peer self-test: wrong sums came back through the slots"; p2p_on_ = false; return -1; }
+    if (mismatches) { err_ = "peer-to-peer self-test: words read from the shards' memory were not what their owners wrote"; p2p_on_ = false; return -1; }
+    return 0;
+  }
+  double pattern(int round, int rank, int b) const { return 1e6 * gen_ + 1e4 * round + 100.0 * rank + b + 0.5; }
+  // a peer's CURRENT population: the owner's parity at set-up + the flips since (p2p.hpp: P2PDesc::cur)
+  const std::vector<double> &peer_pop_cur(int r) const { return peers_[r]->pop_[(peer_cur0_[r] ^ (int)(flips_ & 1u)) & 1]; }
+  void flip_cur() { cur_ = 1 - cur_; ++flips_; }
   int build_cdf_p2p(int64_t *len_out, int *any_negative) override {
     if (p2p_barrier(false)) return -1;
     const int s = m_.s; const int64_t cap = sh_.cap;
@@ -474,7 +602,7 @@ class RefBackend : public Backend {
   }
   int partner_view_p2p(PartnerView *pv) override {
     pv->direct = 1; pv->base = nullptr; pv->rank_stride = 0; pv->cap = sh_.cap;
-    for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peers_[r]->pop_[cur_].data() : nullptr;
+    for (int r = 0; r < kMaxPeers; ++r) pv->peer[r] = r < sh_.world ? peer_pop_cur(r).data() : nullptr;
     return 0;
   }
   int resample_p2p(double delta, uint64_t iter) override {
@@ -484,7 +612,7 @@ class RefBackend : public Backend {
     std::vector<double> w((size_t)N), cum((size_t)N), bs((size_t)orc_scan_chunks(N));
     for (int64_t gid = 0; gid < N; ++gid) {
       const int64_t r = gid / cap, o = gid - r * cap;
-      w[(size_t)gid] = peers_[r]->pop_[cur_][(size_t)(d + s) * cap + o];
+      w[(size_t)gid] = peer_pop_cur((int)r)[(size_t)(d + s) * cap + o];
     }
     double totals[2];
     orc_weight_scan(w.data(), N, cum.data(), bs.data(), totals);
@@ -495,9 +623,9 @@ class RefBackend : public Backend {
       orc_stream_block(m_.seed, (uint64_t)(sh_.gid0 + li), ORC_PURPOSE_RESAMPLE, iter, 0, w4);
       const int64_t idx = orc_resample_index(cum.data(), bs.data(), N, orc_u52(w4[0], w4[1]) * totals[0]);
       const int64_t r = idx / cap, o = idx - r * cap;
-      for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = peers_[r]->pop_[cur_][(size_t)row * cap + o];
+      for (int row = 0; row < d + s; ++row) dst[(size_t)row * cap + li] = peer_pop_cur((int)r)[(size_t)row * cap + o];
     }
-    cur_ = 1 - cur_;
+    flip_cur();
     return 0;
   }
   int snapshot() override { snap_pop_ = pop_[cur_]; snap_rho_ = rho_; return 0; }
@@ -509,15 +637,22 @@ class RefBackend : public Backend {
 
  private:
   RefBackend *peers_[kMaxPeers] = {nullptr};
+  const P2PHostPage *peer_page_[kMaxPeers] = {nullptr};
+  int peer_cur0_[kMaxPeers] = {0};
+  uint32_t flips_ = 0, gen_ = 0;
+  P2PHostPage page_{};                               // this shard's host page (a member: the shards share the process)
+  bool mapped_ = false, exported_ = false;
   double slot_row_[kP2PRing][kMaxPeers][kMaxPartials] = {};
   std::atomic<uint64_t> slot_seq_[kP2PRing][kMaxPeers] = {};
   std::atomic<uint64_t> bar_seq_[kP2PRing][kMaxPeers] = {};
   std::atomic<uint64_t> commit_[kMaxPeers] = {};
+  std::atomic<uint64_t> leave_[kMaxPeers] = {};
   bool p2p_on_ = false, xchg_pending_ = false;
-  uint32_t xseq_ = 0, bseq_ = 0;
-  uint64_t call_ = 0;
-  double timeout_ms_ = 5000.0;
-  int silent_ = 0, skip_ = 0;
+  uint32_t xseq_ = 0, bseq_ = 0, call_ = 0;
+  double timeout_ms_ = 5000.0, destroy_wait_ms_ = -1.0;
+  int silent_ = 0, skip_ = 0, stale_ = 0;
+  bool fail_export_ = false, fail_map_ = false, loss_ = false;
+  std::string err_;
   std::vector<double> snap_pop_, snap_rho_;
   ModelDesc m_{};
   Shard sh_{};
@@ -573,9 +708,14 @@ int sabc_abi_version(void) { return SABC_ABI_VERSION; }
 const char *sabc_last_global_error(void) { return g_err.c_str(); }
 int sabc_device_count(void) { return 0; }
 
+static std::atomic<int64_t> g_parked{0};
 void sabc_destroy(sabc_handle *h) {
   if (!h) return;
-  delete h->eng; delete h->coll; delete h->be; delete h;
+  // the life cycle of p2p.hpp: leave, wait for the peers' `released`; a backend a peer may still point to is parked
+  const bool free_it = h->be->p2p_finish();
+  delete h->eng; delete h->coll;
+  if (free_it) delete h->be; else g_parked += 1;
+  delete h;
 }
 
 int sabc_create(const sabc_config *cfg, sabc_handle **out) {
@@ -677,12 +817,33 @@ int64_t sabc_collective_calls(const sabc_handle *h) { return h->eng->collective_
 int64_t sabc_kernel_launches(const sabc_handle *) { return 0; }
 
 // the peer-to-peer entry points, over the in-process emulation above (shards = host threads of this process)
-int sabc_comm_p2p_descriptor(sabc_handle *h, void *out) { h->be->p2p_descriptor((P2PDesc *)out); return 0; }
+int sabc_comm_p2p_descriptor(sabc_handle *h, void *out) {
+  if (h->be->p2p_descriptor((P2PDesc *)out)) { h->err = h->be->error(); return SABC_ERR_COMM; }
+  return 0;
+}
 int sabc_comm_p2p_init(sabc_handle *h, const void *all) {
   if (!all || h->be->p2p_init((const P2PDesc *)all)) { h->err = "peer-to-peer descriptors do not match"; return SABC_ERR_COMM; }
   return 0;
 }
-int sabc_comm_p2p_selftest(sabc_handle *) { return 0; }
+int sabc_comm_p2p_selftest(sabc_handle *h) {
+  if (h->be->p2p_selftest()) { h->err = h->be->error(); return SABC_ERR_COMM; }
+  return 0;
+}
+// the product's own set-up sequence (csrc/p2p_setup.hpp) over this backend
+int sabc_comm_p2p_setup(sabc_handle *h) {
+  std::string note;
+  const int rc = p2p_setup_sequence(h->be, h->coll, h->eng->shard(), h->eng->host_mode(), &note);
+  h->err = note;
+  return rc == 1 ? (h->eng->p2p() ? 1 : 0) : rc;
+}
+int sabc_comm_p2p_set_destroy_wait(sabc_handle *h, double ms) { h->be->p2p_set_destroy_wait(ms); return 0; }
+int64_t sabc_comm_p2p_parked_bytes(void) { return g_parked.load(); }          // (here: parked backends)
+int sabc_comm_p2p_inject_stale(sabc_handle *h, int32_t n) { h->be->p2p_inject_stale(n); return 0; }
+int sabc_comm_p2p_inject_loss(sabc_handle *h, int32_t n) { h->be->p2p_inject_loss(n); return 0; }
+// harness only: 1 = this shard's next descriptors cannot be exported, 2 = it cannot map its peers, 0 = back to normal
+int sabc_test_p2p_inject_setup_failure(sabc_handle *h, int32_t what) { h->be->p2p_inject_setup_failure(what); return 0; }
+// harness only: which of its two population buffers the shard stands on
+int sabc_test_cur_parity(const sabc_handle *h) { return h->be->cur_parity(); }
 int sabc_comm_p2p_set_timeout(sabc_handle *h, double ms) { h->be->p2p_set_timeout(ms); return 0; }
 int sabc_comm_p2p_disable(sabc_handle *h) { h->be->p2p_disable(); return 0; }
 int sabc_comm_p2p_active(const sabc_handle *h) { return h->eng->p2p() ? 1 : 0; }

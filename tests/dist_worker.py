@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--silence", type=int, default=0, help="p2p test hook: rank 1 lets this many posts go out, then skips one")
     ap.add_argument("--silence-init", type=int, default=0, help="the same inside sabc_initialize")
     ap.add_argument("--silence-selftest", type=int, default=0, help="rank 1 posts nothing in the transport's self-test (first contact fails)")
+    ap.add_argument("--stale-selftest", type=int, default=0, help="rank 1's self-test reads its peers' memory as if a stale line had been served")
+    ap.add_argument("--scenario", default="", help="destroy-mid-call: rank 1 destroys its handle while rank 0 is inside sabc_update")
     ap.add_argument("--p2p-timeout-ms", type=float, default=0.0)
     ap.add_argument("--host-fdist", type=int, default=0, help="hip engine, case gauss1_small: f_dist as a HOST callable that draws the device simulator's Philox blocks")
     ap.add_argument("--out", required=True)
@@ -71,17 +73,24 @@ def main():
     transport = "none"
     if a.silence_selftest and rank == 1:
         h.p2p_inject_silence(a.silence_selftest)       # that many of rank 1's next posts (row, barrier flag) are skipped
+    if a.stale_selftest and rank == 1:
+        h.p2p_inject_stale(a.stale_selftest)
     if a.p2p_timeout_ms > 0 and a.silence_selftest:
         os.environ["SABC_P2P_TIMEOUT_MS"] = str(a.p2p_timeout_ms)
+    import time
+    t_setup = time.perf_counter()
     if world > 1:
         transport = install_collectives(h, device, alltoallv=bool(a.alltoallv), p2p=bool(a.p2p) if a.engine == "hip" else False)
         assert transport in ("p2p", "rccl", "hooks-nccl", "hooks-gloo"), transport
+    setup_seconds = time.perf_counter() - t_setup
     calls0 = h.collective_calls if a.engine == "hip" else 0       # (the self-test of the base transport used some)
     if a.p2p_timeout_ms > 0 and transport == "p2p":
         h.p2p_set_timeout(a.p2p_timeout_ms)
     if a.silence_init and rank == 1 and transport == "p2p":
         h.p2p_inject_silence(-a.silence_init)
     h.initialize((a.updates + 1) * a.n)
+    if a.scenario == "destroy-mid-call":
+        return destroy_mid_call(a, h, S, dist, rank, d, transport)
     bytes_init = h.comm_bytes
     if a.silence and rank == 1 and transport == "p2p":
         h.p2p_inject_silence(-a.silence)
@@ -100,9 +109,50 @@ def main():
                  comm_bytes=np.array([bytes_init, h.comm_bytes - bytes_init]), transport=np.array(transport),
                  collective_calls=np.array((h.collective_calls - calls0) if a.engine == "hip" else -1),
                  p2p_fallbacks=np.array(h.p2p_fallbacks if a.engine == "hip" else 0),
-                 p2p_active_at_end=np.array(bool(h.p2p_active) if a.engine == "hip" else False))
+                 p2p_active_at_end=np.array(bool(h.p2p_active) if a.engine == "hip" else False),
+                 setup_seconds=np.array(setup_seconds), setup_note=np.array(getattr(h, "p2p_setup_note", "")))
     dist.barrier()
     h.close()
+    dist.destroy_process_group()
+
+
+def destroy_mid_call(a, h, S, dist, rank, d, transport):
+    """Rank 1 destroys its handle while rank 0 is inside sabc_update (tests/test_p2p.py)."""
+    import time
+    from tests.cases import SEED, hip_model_prior, hip_proposal
+    parked0 = h.p2p_parked_bytes()
+    if rank == 0:
+        # whoever takes rank 1 away takes the collectives underneath away with it: hooks that fail at once (with the gloo hooks
+        # left in place the engine's fallback would sit in an allreduce rank 1 never joins)
+        h.set_collectives(lambda ctx, buf, count, stream: -1, lambda ctx, send, recv, count, stream: -1, False)
+    dist.barrier()
+    res = {}
+    if rank == 1:
+        time.sleep(0.3)                                   # rank 0 is inside its call by now
+        t0 = time.perf_counter()
+        h.close()
+        res = dict(close_seconds=time.perf_counter() - t0, parked=h.p2p_parked_bytes() - parked0)
+    else:
+        t0 = time.perf_counter()
+        try:
+            h.update(n_simulation=a.updates * a.n, proposal=hip_proposal(S, a.prop, d), resample=a.resample if a.resample > 0 else None)
+            res = dict(error_code=0, error_text="")
+        except S.SABCError as e:
+            res = dict(error_code=e.code, error_text=str(e))
+        res.update(seconds=time.perf_counter() - t0, p2p_active_at_end=bool(h.p2p_active))
+        h.close()
+        model, prior = hip_model_prior(S, a.case)         # rank 0 carries on alone on the same device
+        alone = S.SabcHandle(n_particles=4096, model=model, prior=prior, seed=SEED, device=0)
+        alone.initialize(3 * 4096)
+        alone.update(n_simulation=2 * 4096, proposal=hip_proposal(S, "rw", d))
+        res["alone_updates"] = alone.counters["n_population_updates"]
+        alone.close()
+    parts = [None] * 2
+    dist.all_gather_object(parts, res)
+    if rank == 0:
+        merged = dict(parts[1], **parts[0])
+        np.savez(a.out, transport=np.array(transport), **{k: np.array(v) for k, v in merged.items()})
+    dist.barrier()
     dist.destroy_process_group()
 
 

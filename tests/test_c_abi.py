@@ -92,4 +92,25 @@ def test_plain_c_p2p_client_matches_the_cpu_engine(demo_p2p, S, gpu, tmp_path, p
     tol = 1e-6 if prop else 1e-9
     np.testing.assert_allclose([float(f[3]), float(f[4])], [ref["eps"][0], th.mean()], rtol=tol)
     np.testing.assert_allclose(float(f[5]), ((th - th.mean()) ** 2).sum(), rtol=1e-6)
-    assert int(f[6]) == 0 and int(f[7]) > 0            # no collective call; kernels were launched
+    assert int(f[6]) == 0 and int(f[7]) > 0 and int(f[8]) == 1     # no collective call by the engine; kernels were launched; p2p on
+
+
+@pytest.mark.gpu
+def test_plain_c_p2p_setup_that_fails_on_one_rank_leaves_both_on_the_collectives(demo_p2p, S, gpu, tmp_path):
+    """First contact goes wrong on ONE rank (its self-test is told to read a stale line).  sabc_comm_p2p_setup makes both
+    ranks agree inside the library -- from plain C, no Python around: both stay on the host's socket collectives, nobody
+    waits out the 5 s bound of a first exchange, and the run is the reference run."""
+    from tests.cases import SEED, y_obs_mean
+    from tests.test_distributed import launch
+    n, k = 8000, 6
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([demo_p2p, str(n), str(k), str(SEED), repr(y_obs_mean()), "1", "stale"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = r.stdout.split()
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case="gauss1_cfg2", alg="single_eps", prop="de", n=n,
+                 updates=k, resample=n // 4)
+    assert [n * (k + 1), int(f[0]), int(f[1]), int(f[2])] == list(ref["counters"])
+    np.testing.assert_allclose([float(f[3]), float(f[4])], [ref["eps"][0], ref["theta"][0].mean()], rtol=1e-6)
+    assert int(f[8]) == 0 and int(f[6]) > k            # not peer to peer; the engine's collectives went over the socket
+    assert float(f[9]) < 3.0                           # the set-up did not wait out a bound

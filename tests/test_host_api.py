@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(S):
     assert len(names) >= 37
     for name in names:
         assert hasattr(L, name), f"{name} is declared in include/sabc_hip.h but not exported"
-    assert L.sabc_abi_version() == 5
+    assert L.sabc_abi_version() == 6
 
 
 def test_host_side_eps_operators_match_oracle(S, O):

@@ -201,24 +201,26 @@ def test_reference_surface_is_kept():
 
 
 def test_progress_chunking_rule():
-    """The rule that splits update_population! into sabc_update chunks (same function in api.py and in the Julia wrapper):
-    chunks are multiples of checkpoint_history, a checkpoint interval is a multiple of the chunk."""
+    """The rule that cuts update_population! into sabc_update calls (same function in api.py and in the Julia wrapper): a call
+    ends at every multiple of show_checkpoint, at every step of the progress bar and at n_pop -- wherever that falls relative
+    to checkpoint_history (history_phase / more_chunks_follow keep the histories those of the uncut call)."""
     import sabc_amd
-    from sabc_amd.api import progress_chunk
+    from sabc_amd.api import progress_stops
     for n_pop in (0, 1, 7, 100, 1000, 12345):
-        for cph in (1, 3, 10):
-            for chk in (float("inf"), 100, 50, 7):
-                for bar in (False, True):
-                    c = progress_chunk(n_pop, cph, chk, bar)
-                    assert c >= 1
-                    if c < n_pop:
-                        assert c % cph == 0
-                        if chk != float("inf") and int(chk) % cph == 0:
-                            assert int(chk) % c == 0
+        for chk in (float("inf"), 100, 50, 7):
+            for bar in (False, True):
+                st = progress_stops(n_pop, chk, bar)
+                assert st == sorted(set(st)) and st[-1] == n_pop and all(0 < x <= n_pop for x in st[:-1])
+                if chk != float("inf"):
+                    assert all(x in st for x in range(int(chk), n_pop, int(chk)))
+                if not bar and chk == float("inf"):
+                    assert st == [n_pop]
     # the Julia text implements the same rule (kept in step by eye; this pins the tokens that matter)
-    body = re.search(r"function progress_chunk\(.*?\nend", jl_source(), re.S).group(0)
-    for tok in ("k % cph == 0", "(n_pop ÷ 50) ÷ cph * cph", "chunk % bar != 0", "max(chunk, 1)"):
+    body = re.search(r"function progress_stops\(.*?\nend", jl_source(), re.S).group(0)
+    for tok in ("Set{Int}([n_pop])", "Int(show_checkpoint):Int(show_checkpoint):(n_pop - 1)", "max(n_pop ÷ 50, 1)", "sort!(collect(stops))"):
         assert tok in body
+    call = re.search(r"CUpdateArgs\(budget.*?\)\)", jl_source()).group(0)
+    assert "stop < n_pop ? 1 : 0" in call and call.rstrip(")").endswith("done")     # more_chunks_follow, history_phase
 
 
 def test_every_capitalised_name_resolves():
@@ -238,7 +240,7 @@ def test_every_capitalised_name_resolves():
     defined |= set(re.findall(r"^(?:function )?(\w+)\(", code, re.M))
     base = {"Int", "Int32", "Int64", "UInt8", "UInt64", "Float64", "Bool", "Cint", "Cvoid", "Cstring", "Ptr", "Ref", "Vector", "Matrix",
             "Array", "Tuple", "NTuple", "NamedTuple", "Union", "Nothing", "Symbol", "String", "Function", "Real", "Integer", "Any", "Dict",
-            "WeakKeyDict", "IO", "Inf", "ENV", "GC", "Threads", "C_NULL", "ArgumentError", "T", "S", "F"}
+            "WeakKeyDict", "IO", "Inf", "ENV", "GC", "Threads", "C_NULL", "ArgumentError", "T", "S", "F", "Cdouble", "DivideError", "Set"}
     greek = {"Σ", "Θ", "R", "L"}                     # local variables of the wrapper
     unknown = sorted({w for w in re.findall(r"(?<![\w.:@$])([A-ZΣΘ]\w*)", code)} - imported - defined - base - greek)
     assert not unknown, unknown

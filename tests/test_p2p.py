@@ -84,8 +84,7 @@ def run_shards_in_one_process(S, case, alg, prop, n, k, resample, world=2, timeo
             res.update(theta=th, u=u, rho=rho, eps=h.eps, counters=h.counters, launches=h.kernel_launches - launches0,
                        syncs=h.host_syncs - syncs0, collective_calls=h.collective_calls, comm=h.comm_bytes, hist=h.history)
             out[rank] = res
-            barrier.wait()                                           # nobody frees memory a peer may still be reading
-            h.close()
+            h.close()                                                # no barrier: sabc_destroy leaves the group in order (p2p.hpp)
         except BaseException as e:                                   # a failing shard must not leave the other at a barrier
             err[rank] = e
             barrier.abort()
@@ -182,6 +181,7 @@ def test_p2p_a_silent_shard_fails_the_call_within_the_bound(S, gpu, tmp_path, pr
     def tamper_mid_call(rank, h, call):
         if rank == 1 and call == silent_call:
             h.p2p_inject_silence(-5)                                 # negative: 5 more posts go out, THEN one is skipped
+
 
     out = run_shards_in_one_process(S, case, "single_eps", prop, n, k, resample=n // 4, timeout_ms=bound_ms,
                                     before_update=tamper_mid_call, calls=2)
@@ -311,3 +311,165 @@ def test_p2p_with_a_simulator_from_source(S, gpu):
         np.testing.assert_array_equal(oa["theta"], ob["theta"])
         np.testing.assert_array_equal(oa["rho"], ob["rho"])
         np.testing.assert_array_equal(oa["eps"], ob["eps"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Life cycle (csrc/p2p.hpp "LEAVES", include/sabc_hip.h "LEAVING"): nothing is freed under a reader, whoever goes first.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prop,posts_before", [("rw", 2), ("rw", 5), ("de", 4), ("de", 8)])
+def test_p2p_set_up_again_after_a_post_was_lost_on_the_wire(S, gpu, tmp_path, prop, posts_before):
+    """Shard 1's post reaches only its own slots (test hook sabc_comm_p2p_inject_loss): shard 0 runs into the bound, shard 1
+    carries on with shard 0's row -- into a resample that flips its population buffers when the step fires one -- and fails
+    one wait later.  After the failed call the shards may stand on different buffer parities; the next set-up's descriptors
+    carry each OWNER's parity and a new generation, so the repeated call reads the right buffers and matches no word of the
+    old set-up: the run is the uninterrupted run."""
+    case, n, k, bound_ms = "gauss1_cfg2", 20_000, 8, 300.0
+
+    def lose_a_post(rank, h, call):
+        if rank == 1 and call == 0:
+            h.p2p_inject_loss(posts_before)
+
+    out = run_shards_in_one_process(S, case, "single_eps", prop, n, k, resample=n // 4, timeout_ms=bound_ms, before_update=lose_a_post,
+                                    calls=2)
+    for o in out:
+        assert [e is not None for e in o["errors"]] == [True, False] and o["errors"][0].code == -22, o["errors"]
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop=prop, n=n,
+                 updates=2 * k, resample=n // 4)
+    check_against_cpu_engine(out, ref, prop)
+
+
+@pytest.mark.parametrize("prop", ["rw", "de"])
+def test_p2p_a_shard_destroyed_while_its_peer_is_inside_a_call_one_process(S, gpu, prop):
+    """Shard 1 (a host thread of this process) is destroyed while shard 0 is in sabc_update -- its kernels reading shard 1's
+    population (DifferentialEvolution partners), its exchange waiting for shard 1's row.  Shard 0's wait ends at the leave
+    word (not the 20 s bound) with SABC_ERR_COMM 'has left the group', the error contract holds, shard 0 leaves too -- which
+    is what lets shard 1's sabc_destroy free its memory with nothing parked -- and the device is fine: a fresh handle runs."""
+    import torch
+    from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+    case, n, k = "gauss1_cfg2", 400_000, 6
+    d = len(MODELS[case]["prior"])
+    descs, out, err = [None, None], [None, None], [None, None]
+    barrier = threading.Barrier(2)
+
+    def shard(rank):
+        try:
+            torch.cuda.set_device(0)
+            model, prior = hip_model_prior(S, case)
+            h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=2)
+            descs[rank] = h.p2p_descriptor()
+            barrier.wait()
+            h.p2p_set_timeout(20_000.0)
+            h.p2p_init(list(descs))
+            barrier.wait()
+            h.p2p_selftest()
+            h.initialize((k + 1) * n)
+            parked0 = h.p2p_parked_bytes()
+            barrier.wait()
+            if rank == 1:
+                time.sleep(0.3)
+                t0 = time.perf_counter()
+                h.close()
+                out[rank] = dict(close_seconds=time.perf_counter() - t0, parked=h.p2p_parked_bytes() - parked0)
+                return
+            before = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.get_population()])
+            t0 = time.perf_counter()
+            with pytest.raises(S.SABCError, match="has left the group") as ei:
+                h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=n // 4)
+            seconds = time.perf_counter() - t0
+            assert ei.value.code == -22 and not h.p2p_active and dict(h.counters) == before[0]
+            np.testing.assert_array_equal(h.eps, before[1])
+            h.set_population(*before[2])
+            h.close()
+            out[rank] = dict(seconds=seconds)
+        except BaseException as e:
+            err[rank] = e
+            barrier.abort()
+
+    ts = [threading.Thread(target=shard, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert all(e is None for e in err), err
+    assert out[0]["seconds"] < 8.0 and out[1]["close_seconds"] < 8.0 and out[1]["parked"] == 0, out
+    model, prior = hip_model_prior(S, case)
+    h = S.SabcHandle(n_particles=4096, model=model, prior=prior, seed=SEED)       # the device is fine
+    h.initialize(2 * 4096)
+    h.update(n_simulation=4096, proposal=hip_proposal(S, "rw", d))
+    assert h.counters["n_population_updates"] == 1
+    h.close()
+
+
+@pytest.mark.parametrize("prop", ["de"])
+def test_p2p_a_rank_destroyed_while_its_peer_is_inside_a_call_two_processes(S, gpu, tmp_path, prop):
+    """The same between two PROCESSES (hipIpc mappings, the host pages in POSIX shared memory): rank 1 destroys its handle
+    while rank 0 is inside sabc_update.  Rank 0 ends with SABC_ERR_COMM within a fraction of the bound -- no GPU memory fault --
+    leaves the group, and rank 1's sabc_destroy returns with its memory freed (nothing parked); rank 0 then runs a fresh
+    single-shard handle on the same device."""
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case="gauss1_cfg2", alg="single_eps", prop=prop, n=400_000,
+                 updates=6, resample=100_000, p2p=1, scenario="destroy-mid-call", **{"p2p-timeout-ms": 20_000})
+    assert str(got["transport"]) == "p2p"
+    assert int(got["error_code"]) == -22 and "has left the group" in str(got["error_text"]), str(got["error_text"])
+    assert float(got["seconds"]) < 8.0 and float(got["close_seconds"]) < 8.0, (got["seconds"], got["close_seconds"])
+    assert int(got["parked"]) == 0 and not bool(got["p2p_active_at_end"])
+    assert int(got["alone_updates"]) == 2                           # rank 0 carried on, alone, on the same GPU
+
+
+def test_p2p_first_contact_reads_the_populations_through_the_mappings(S, gpu, tmp_path):
+    """The self-test's second half: rank 1 is told to read a stale line (test hook sabc_comm_p2p_inject_stale: its second
+    round compares against a pattern nobody wrote).  Its self-test fails ALONE -- rank 0's passes --, the ranks agree inside
+    sabc_comm_p2p_setup, everybody stays on the collectives without a failed first exchange, and the run is the plain run."""
+    case, n, k = "gauss1_cfg2", 8000, 6
+    got = launch(2, str(tmp_path / "hip.npz"), engine="hip", backend="gloo", case=case, alg="single_eps", prop="de", n=n, updates=k,
+                 resample=n // 4, p2p=1, **{"stale-selftest": 1})
+    assert str(got["transport"]) == "hooks-gloo" and int(got["p2p_fallbacks"]) == 0 and not bool(got["p2p_active_at_end"])
+    assert "not what their owners wrote" in str(got["setup_note"]) or "failed on another shard" in str(got["setup_note"])
+    assert float(got["setup_seconds"]) < 4.0                        # nobody waited out the 5 s bound
+    ref = launch(2, str(tmp_path / "cpu.npz"), engine="cpu", backend="gloo", case=case, alg="single_eps", prop="de", n=n, updates=k,
+                 resample=n // 4)
+    assert list(got["counters"]) == list(ref["counters"])
+    np.testing.assert_allclose(got["theta"], ref["theta"], rtol=TOL["de"], atol=TOL["de"] * 1e-2)
+
+
+def test_p2p_self_test_leaves_live_populations_untouched(S, gpu):
+    """A set-up AFTER sabc_initialize (what follows a failed call): the self-test writes its patterns into lines of both
+    population buffers and rho, and puts back what was there -- every particle of both shards is bit for bit what it was."""
+    import torch
+    from tests.cases import SEED, hip_model_prior
+    n = 50_001
+    descs, out, err = [None, None], [None, None], [None, None]
+    barrier = threading.Barrier(2)
+
+    def shard(rank):
+        try:
+            torch.cuda.set_device(0)
+            model, prior = hip_model_prior(S, "gauss2d_cfg3")
+            h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=2)
+            for attempt in range(2):
+                descs[rank] = h.p2p_descriptor()
+                barrier.wait()
+                h.p2p_init(list(descs))
+                barrier.wait()
+                if attempt == 0:
+                    h.p2p_selftest()
+                    h.initialize(n)
+                    before = [a.copy() for a in h.get_population()]
+                    barrier.wait()
+                else:
+                    h.p2p_selftest()
+                    h.p2p_selftest()
+                    after = h.get_population()
+                    for a, b in zip(before, after):
+                        np.testing.assert_array_equal(a, b)
+            out[rank] = True
+            h.close()
+        except BaseException as e:
+            err[rank] = e
+            barrier.abort()
+
+    ts = [threading.Thread(target=shard, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert all(e is None for e in err), err
