@@ -150,11 +150,22 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   }
   const size_t cap = (size_t)sh.cap, N = (size_t)sh.n_global;
   const size_t rows = (size_t)(m.d + m.s + 1);
+  // What peers read over the peer-to-peer transport (p2p.hpp): both population buffers and rho.  On a sharded handle they
+  // live in FINE-GRAINED device memory -- coherent across devices at every access, so a peer's read never depends on what a
+  // kernel boundary does to its caches.  On one GPU that costs nothing measurable (two processes sharing an MI355X, n = 1e6:
+  // 5.48 / 4.99e9 sims/s RandomWalk / DE with plain hipMalloc, 5.49 / 5.03e9 fine-grained); what it
+  // costs a REMOTE reader is unmeasured, its reads (partners, drawn rows: random; the weight rows: once) have little reuse to
+  // lose.  SABC_P2P_FINEGRAINED=0 goes back to plain device memory, visible across devices at kernel boundaries only;
+  // either way sabc_comm_p2p_selftest checks on first contact that peers read what the owners' kernels wrote.
+  static const bool fine = [] { const char *e = std::getenv("SABC_P2P_FINEGRAINED"); return !(e && e[0] == '0'); }();
+  auto pop_alloc = [&](double **p, size_t bytes) {
+    return fine && sh.world > 1 ? hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocFinegrained) : hipMalloc((void **)p, bytes);
+  };
   for (int b = 0; b < 2; ++b) {
-    HB_CHECK(hipMalloc((void **)&pop_[b], rows * cap * sizeof(double)), "hipMalloc(pop)");
+    HB_CHECK(pop_alloc(&pop_[b], rows * cap * sizeof(double)), "hipMalloc(pop)");
     HB_CHECK(hipMemsetAsync(pop_[b], 0, rows * cap * sizeof(double), stream_), "hipMemset(pop)");
   }
-  HB_CHECK(hipMalloc((void **)&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
+  HB_CHECK(pop_alloc(&rho_, (size_t)m.s * cap * sizeof(double)), "hipMalloc(rho)");
   HB_CHECK(hipMemsetAsync(rho_, 0, (size_t)m.s * cap * sizeof(double), stream_), "hipMemset(rho)");
   HB_CHECK(hipMalloc((void **)&coarse_, (size_t)m.s * cdf_coarse_entries(m.s) * sizeof(double)), "hipMalloc(coarse)");
   knot_stride_ = (((int64_t)N + 2 + 15) / 16) * 16;       // every table starts on a 128-byte line
@@ -1022,7 +1033,9 @@ int HipBackend::p2p_init(const P2PDesc *all) {
       peer_slots_[r] = (uint64_t *)(uintptr_t)d.ptr_slots;
       peer_pop_[0][r] = (double *)(uintptr_t)d.ptr_pop[0]; peer_pop_[1][r] = (double *)(uintptr_t)d.ptr_pop[1];
       peer_rho_[r] = (double *)(uintptr_t)d.ptr_rho;
-      peer_page_[r] = (const P2PHostPage *)(uintptr_t)d.ptr_page; peer_page_shm_[r] = false;
+      // (the host page is opened by NAME even here: a mapping of this shard's own, which stays readable after the peer
+      // has destroyed its handle and unmapped its side -- this shard may be polling it for `released` at that moment)
+      if (!open_peer_page(r, d)) return fail("a peer shard's host page could not be opened (POSIX shared memory)");
       continue;
     }
     if (d.device != device_) {                          // another GPU of the node: kernels here must be able to reach it
@@ -1032,11 +1045,7 @@ int HipBackend::p2p_init(const P2PDesc *all) {
         return fail("no peer access between the devices of two shards (is the peer on this node?)");
       }
     }
-    char name[sizeof(d.page_name) + 1];
-    std::memcpy(name, d.page_name, sizeof(d.page_name)); name[sizeof(d.page_name)] = 0;
-    peer_page_[r] = p2p_page_open(name);
-    peer_page_shm_[r] = peer_page_[r] != nullptr;
-    if (!peer_page_[r]) return fail("a peer shard's host page could not be opened (POSIX shared memory; is the peer on this node?)");
+    if (!open_peer_page(r, d)) return fail("a peer shard's host page could not be opened (POSIX shared memory; is the peer on this node?)");
     const unsigned char *from[4] = {d.ipc_slots, d.ipc_pop[0], d.ipc_pop[1], d.ipc_rho};
     void *got[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4; ++i) {
@@ -1053,6 +1062,15 @@ int HipBackend::p2p_init(const P2PDesc *all) {
   page_->state.store(kP2PActive, std::memory_order_release);
   p2p_on_ = true;
   return 0;
+}
+
+bool HipBackend::open_peer_page(int r, const P2PDesc &d) {
+  if (peer_page_shm_[r]) p2p_page_unmap(peer_page_[r]);           // (a page kept from an earlier set-up)
+  char name[sizeof(d.page_name) + 1];
+  std::memcpy(name, d.page_name, sizeof(d.page_name)); name[sizeof(d.page_name)] = 0;
+  peer_page_[r] = p2p_page_open(name);
+  peer_page_shm_[r] = peer_page_[r] != nullptr;
+  return peer_page_[r] != nullptr;
 }
 
 // p2p.hpp "LEAVES".  Safe to call in any state and more than once; never frees anything a peer may have mapped.

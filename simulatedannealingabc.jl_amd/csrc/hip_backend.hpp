@@ -198,6 +198,7 @@ class HipBackend : public Backend {
   double *peer_pop_cur(int r) const { return peer_pop_[(peer_cur0_[r] ^ (int)(flips_ & 1u)) & 1][r]; }
   uint32_t tag(uint32_t seq) const { return p2p_tag(gen_, seq); }
   int selftest_patterns(const P2PView &pv);
+  bool open_peer_page(int r, const P2PDesc &d);
   uint64_t *slots_ = nullptr;                             // this shard's slot area (fine-grained device memory)
   uint64_t *peer_slots_[kMaxPeers] = {nullptr};
   double *peer_pop_[2][kMaxPeers] = {{nullptr}};

@@ -640,7 +640,9 @@ class RefBackend : public Backend {
   const P2PHostPage *peer_page_[kMaxPeers] = {nullptr};
   int peer_cur0_[kMaxPeers] = {0};
   uint32_t flips_ = 0, gen_ = 0;
-  P2PHostPage page_{};                               // this shard's host page (a member: the shards share the process)
+  // this shard's host page.  The shards share the process, so "a mapping of the reader's own" is modelled by never freeing it:
+  // a peer may still be polling it for `released` when this object is deleted
+  P2PHostPage &page_ = *new P2PHostPage();
   bool mapped_ = false, exported_ = false;
   double slot_row_[kP2PRing][kMaxPeers][kMaxPartials] = {};
   std::atomic<uint64_t> slot_seq_[kP2PRing][kMaxPeers] = {};
