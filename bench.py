@@ -34,18 +34,20 @@ def observed_mean():
     return float(np.random.default_rng(SEED).normal(1.5, 1.0, 100).mean())
 
 
-def cpu_baseline(n, updates, threads, warmup=0, steps=0):
+def cpu_baseline(n, updates, threads, warmup=0, steps=0, proposal="randomwalk", shard0=None):
     """The oracle (CPU restatement, NOT the Julia reference: Julia is not installed) on the host
     cores of this box, same workload, bounded sample; update loop only, like `value`.
     The first `warmup` + `steps` updates are issued exactly like the GPU's (same seed, same two calls), so that the
-    posterior moments of the two runs can be compared (BASELINE metric: "posterior-mean L2 vs ref")."""
+    posterior moments of the two runs can be compared (BASELINE metric: "posterior-mean L2 vs ref"); shard0 = number of
+    particles of the first shard of a sharded run: its moments are those of the oracle's same slice (global ids 0 ..)."""
     from oracle import oracle as O
     O.set_threads(threads)
     cfg = O.make_config(n_particles=n, n_para=1, n_stats=1, model_id=O.MODEL_GAUSS_IID,
                         model_params=[100, 1.0, observed_mean(), 0.0], prior=[(O.PRIOR_NORMAL, 0.0, 2.0)], seed=SEED)
     run = O.OracleRun(cfg)
     run.initialize(n)
-    args = lambda k: O.make_update_args(n_simulation=k * n, proposal=(O.PROP_RANDOMWALK, 0.8, 0.0), n_particles=n)
+    prop = {"randomwalk": (O.PROP_RANDOMWALK, 0.8, 0.0), "de": (O.PROP_DIFFEVO, None, 1e-5), "stretch": (O.PROP_STRETCH, 2.0, 0.0)}[proposal]
+    args = lambda k: O.make_update_args(n_simulation=k * n, proposal=prop, n_para=1, n_particles=n)
     t0 = time.perf_counter()
     same = None
     done = 0
@@ -55,7 +57,10 @@ def cpu_baseline(n, updates, threads, warmup=0, steps=0):
             done += k
     if done == warmup + steps and done > 0:
         th = run.theta[0]
-        same = {"mean": float(th.mean()), "var": float(th.var()), "n_accept": int(run.counters["n_accept"]), "updates": done}
+        same = {"mean": float(th.mean()), "var": float(th.var()), "n_accept": int(run.counters["n_accept"]), "updates": done,
+                "n_resampling": int(run.counters["n_resampling"]), "eps": [float(x) for x in np.atleast_1d(run.eps)]}
+        if shard0:
+            same.update(shard0_mean=float(th[:shard0].mean()), shard0_var=float(th[:shard0].var()))
     if updates > done:
         run.update(args(updates - done))
     dt = time.perf_counter() - t0
@@ -413,6 +418,7 @@ def main():
     # (level 2 adds ~4 us per bracket, so this is not part of the timed region): the reduce[-exchange]-control launch and,
     # on the collectives transport, the allreduce between k_reduce_partials and k_control
     exchange = None
+    p2p_active_after_timed = bool(h.p2p_active) if world > 1 else False
     if world > 1 and not args.no_kernel_events:
         say("extra updates with every kernel bracketed")
         h.profile_enable(2)
@@ -424,6 +430,50 @@ def main():
                     "collective_us": (x_ms / x_n * 1e3) if x_n else None, "collectives_timed": x_n,
                     "launches_per_update": (h.kernel_launches - l0) / 10.0, "collective_calls_per_update": (h.collective_calls - c0) / 10.0,
                     "note": "10 extra updates after the timed region, every kernel bracketed by HIP events (not part of `value`)"}
+
+    # ... and the same 10 bracketed updates over the COLLECTIVES underneath (north star: "RCCL allreduce over xGMI for the global
+    # acceptance count, epsilon-schedule update and population covariance"): every rank leaves the peer-to-peer group -- no
+    # barrier needed, a rank that is late finds out at the entry of its call (include/sabc_hip.h, LEAVING) -- and the run goes
+    # on over what install_collectives put underneath.  Otherwise the collectives never get a number on a node where the
+    # peer-to-peer transport comes up.
+    exchange_rccl = None
+    state_after_timed = (dict(c), h.eps.copy())
+    if world > 1 and transport == "p2p" and not args.no_kernel_events:
+        say("leaving the peer-to-peer group: 10 bracketed updates over the collectives underneath")
+        h.p2p_disable()
+        h.profile_enable(2)
+        l0, c0 = h.kernel_launches, h.collective_calls
+        t_x = time.perf_counter()
+        h.update(n_simulation=10 * n, proposal=proposal)
+        torch.cuda.synchronize()
+        t_x = time.perf_counter() - t_x
+        r_ms, r_n = h.profile_get(S._lib.KERNEL_REDUCE)
+        x_ms, x_n = h.profile_get(S._lib.KERNEL_COLLECTIVE)
+        exchange_rccl = {"transport": fallback, "allreduce_us": (x_ms / x_n * 1e3) if x_n else None, "allreduces_timed": x_n,
+                         "reduce_plus_control_us": r_ms / max(r_n, 1) * 1e3, "launches_per_update": (h.kernel_launches - l0) / 10.0,
+                         "collective_calls_per_update": (h.collective_calls - c0) / 10.0, "us_per_update": t_x / 10.0 * 1e6,
+                         "p2p_active": bool(h.p2p_active),
+                         "note": "10 more updates after every rank left the peer-to-peer group (sabc_comm_p2p_disable): k_update -> "
+                                 "k_reduce_partials -> allreduce -> k_control, resamples over allgathers; every kernel bracketed by "
+                                 "HIP events (not part of `value`)"}
+    # N > 1: the same seed and calls on ONE shard of this rank's GPU.  The sharded run is shard-count independent by design
+    # (Philox streams keyed by global particle id, rank-order sums): its accept count has to be this one's
+    n1 = None
+    if world > 1 and rank == 0:
+        say("n1_equivalent: the same calls on one shard")
+        h1 = S.SabcHandle(n_particles=n, model=model, prior=prior, algorithm=alg, seed=SEED, device=device)
+        h1.initialize(n)
+        if W > 0:
+            h1.update(n_simulation=W * n, proposal=proposal)
+        h1.update(n_simulation=K * n, proposal=proposal)
+        c1 = h1.counters
+        e1 = h1.eps
+        n1 = {"n_accept": c1["n_accept"], "n_resampling": c1["n_resampling"],
+              "n_accept_equal": c1["n_accept"] == state_after_timed[0]["n_accept"],
+              "n_resampling_equal": c1["n_resampling"] == state_after_timed[0]["n_resampling"],
+              "eps_rel_err": float(np.max(np.abs(state_after_timed[1] / e1 - 1.0))),
+              "note": "one shard on rank 0's GPU, same seed, same initialize + warm-up + K updates as the sharded timed region"}
+        h1.close()
 
     if rank == 0:
         bytes_per_sim = 8 * (2 * d + 3 * s)                 # 40 B for d = s = 1
@@ -480,7 +530,7 @@ def main():
             # peer-to-peer transport: calls in which a wait ran into its bound and that the engine finished over the
             # collectives underneath (0 = the whole run went peer to peer), and whether it is still on at the end
             "p2p_fallbacks": h.p2p_fallbacks if world > 1 else 0,
-            "p2p_active_at_end": bool(h.p2p_active) if world > 1 else False,
+            "p2p_active_at_end": p2p_active_after_timed,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -510,6 +560,8 @@ def main():
             "launches_per_update": med["kernel_launches"] / K,
             "collective_calls_per_update": med["collective_calls"] / K,
             "exchange": exchange,
+            "exchange_rccl": exchange_rccl,
+            "n1_equivalent": n1,
             "from_profiles": load_from_profiles(n, args.config) if world == 1 else {},
             "kernel_time_frac": (avg_launch_s * real_launches) / dt if launches else None,
             "reduce_us_per_step": red_ms / max(red_n, 1) * 1e3,
@@ -520,20 +572,35 @@ def main():
                       "n_population_updates": c["n_population_updates"], "eps": h.eps.tolist(),
                       "shard0_mean": th.mean(1).tolist(), "shard0_var": th.var(1).tolist(), **analytic},
         }
+        comparable = args.config == "cfg2" and args.algorithm == "single_eps" and args.n_obs == 100
         if not args.no_cpu_baseline and world == 1 and args.config == "cfg2":
             # the GPU box shows 256 logical CPUs but a one-GPU job's CPU share is 16: use that many threads
             threads = min(os.cpu_count() or 1, int(os.environ.get("SABC_CPU_THREADS", "16")))
-            out["cpu_baseline"], same = cpu_baseline(n, max(args.cpu_updates, W + K), threads, W, K)
-            if same and args.proposal == "randomwalk" and args.algorithm == "single_eps" and args.n_obs == 100:
+            out["cpu_baseline"], same = cpu_baseline(n, max(args.cpu_updates, W + K), threads, W, K, proposal=args.proposal)
+            if same and comparable:
                 gm, gv = float(th.mean()), float(th.var())
                 out["posterior_vs_cpu"] = {
                     "gpu_mean": gm, "gpu_var": gv, "cpu_mean": same["mean"], "cpu_var": same["var"],
                     "rel_err_mean": abs(gm / same["mean"] - 1.0), "rel_err_var": abs(gv / same["var"] - 1.0),
                     "n_accept_equal": same["n_accept"] == c["n_accept"], "updates": same["updates"],
                     "note": "same seed, same calls on the CPU restatement (oracle); the north star asks for moments within 1 %"}
+        elif not args.no_cpu_baseline and world > 1 and comparable:
+            # N > 1: the line validates itself.  The oracle runs the SAME initialize + warm-up + K updates (a bounded leg: W + K
+            # updates, a few seconds on rank 0's CPU share while the other ranks wait) -- the accept and resample counts have
+            # to be equal, epsilon and the moments of shard 0 (global particles 0 .. n_local - 1) those of the oracle's slice
+            threads = min(os.cpu_count() or 1, int(os.environ.get("SABC_CPU_THREADS", "16")))
+            cpu, same = cpu_baseline(n, W + K, threads, W, K, proposal=args.proposal, shard0=h.n_local)
+            gm, gv = float(th.mean()), float(th.var())
+            out["posterior_vs_cpu"] = {
+                "shard0_gpu_mean": gm, "shard0_gpu_var": gv, "shard0_cpu_mean": same["shard0_mean"], "shard0_cpu_var": same["shard0_var"],
+                "rel_err_mean": abs(gm / same["shard0_mean"] - 1.0), "rel_err_var": abs(gv / same["shard0_var"] - 1.0),
+                "eps_rel_err": float(np.max(np.abs(state_after_timed[1] / np.array(same["eps"]) - 1.0))),
+                "n_accept_equal": same["n_accept"] == c["n_accept"], "n_resampling_equal": same["n_resampling"] == c["n_resampling"],
+                "updates": same["updates"], "cpu_sims_per_s": cpu["value"], "cpu_cores": cpu["cores"],
+                "note": "same seed, same calls on the CPU restatement (oracle), whole population; moments of shard 0 against the "
+                        "oracle's same slice; the north star asks for moments within 1 %"}
         print(json.dumps(out), flush=True)
-    barrier()                         # handles that map each other's memory are torn down together, and once
-    h.close()
+    h.close()                         # (no barrier: sabc_destroy leaves the peer-to-peer group in order)
     if world > 1:
         barrier()
         dist.destroy_process_group()

@@ -85,9 +85,13 @@ def test_launcher_two_ranks_on_one_gpu(gpu):
 @pytest.mark.gpu
 def test_launcher_two_ranks_peer_to_peer(gpu):
     """The same with the peer-to-peer transport on top of the gloo hooks (two processes mapping each other's memory with
-    hipIpc): the line says so, counts no collective call in the timed region and one reduce-exchange-control launch per update."""
+    hipIpc): the line says so, counts no collective call in the timed region and one reduce-exchange-control launch per update
+    -- and VALIDATES ITSELF: the accept and resample counts equal the oracle's for the same seed and calls
+    (`posterior_vs_cpu`, shard 0's moments against the oracle's same slice) and the one-shard run's on the same GPU
+    (`n1_equivalent`); after the timed region every rank leaves the peer-to-peer group and the collectives underneath get
+    their own numbers (`exchange_rccl`)."""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dist-backend", "gloo", "--p2p", "on", "--steps", "6", "--warmup", "2",
-                        "--n-particles", "200000", "--no-cpu-baseline", "--repeats", "2"], env=_env(), stdout=subprocess.PIPE,
+                        "--n-particles", "200000", "--repeats", "2"], env=_env(), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -98,3 +102,12 @@ def test_launcher_two_ranks_peer_to_peer(gpu):
     ex = out["exchange"]
     assert ex["collective_calls_per_update"] == 0 and ex["reduce_control_launches"] >= 10 and ex["collectives_timed"] == 0
     assert 2.0 <= ex["launches_per_update"] <= 4.0            # k_update + ONE reduce-exchange-control launch (+ a resample's share)
+    pv = out["posterior_vs_cpu"]
+    assert pv["n_accept_equal"] and pv["n_resampling_equal"] and pv["updates"] == 8
+    assert pv["rel_err_mean"] < 1e-9 and pv["rel_err_var"] < 1e-8 and pv["eps_rel_err"] < 1e-9
+    n1 = out["n1_equivalent"]
+    assert n1["n_accept_equal"] and n1["n_resampling_equal"] and n1["eps_rel_err"] < 1e-9 and n1["n_accept"] == out["state"]["n_accept"]
+    xr = out["exchange_rccl"]
+    assert xr["transport"] == "hooks-gloo" and not xr["p2p_active"]
+    assert xr["collective_calls_per_update"] >= 1.0 and xr["allreduces_timed"] >= 10 and xr["allreduce_us"] > 0
+    assert xr["launches_per_update"] >= 3.0                   # k_update + k_reduce_partials + k_control (+ resamples)
