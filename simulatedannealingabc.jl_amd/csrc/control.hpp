@@ -16,7 +16,7 @@ namespace sabc {
 // the multi-eps schedule's epsilons, computed ahead of the step by one lane per statistic (kernels.hip: control_on_copy) from
 // the sums the step is about to take over; the step applies them in order, exactly as it would have computed them
 struct EpsCandidates {
-  double eps[kMaxStats], beta[kMaxStats];
+  double eps[kMaxStats];
   int32_t ok[kMaxStats];                  // 0: mean u of this statistic <= eps() (:107-109)
 };
 
@@ -79,7 +79,6 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
       for (int j = 0; j < s; ++j) {                  // (a failing statistic stops the schedule where eps_multi would have)
         if (!pre->ok[j]) { cb.error = SABC_ERR_ZERO_MEAN_U; break; }                 // :107-109
         cb.eps[j] = pre->eps[j];
-        cb.beta[j] = pre->beta[j];
       }
     } else if (a.algorithm == SABC_ALG_MULTI_EPS) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -88,7 +87,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
       double ubar[kMaxStats];
 #endif
       for (int j = 0; j < s; ++j) ubar[j] = cb.sums[1 + j] / n;
-      if (!hostmath::eps_multi(ubar, s, a.v, cb.eps, cb.beta)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
+      if (!hostmath::eps_multi(ubar, s, a.v, cb.eps)) cb.error = SABC_ERR_ZERO_MEAN_U;   // :107-109
     } else {
       double tot = 0.0;
       for (int j = 0; j < s; ++j) tot += cb.sums[1 + j];

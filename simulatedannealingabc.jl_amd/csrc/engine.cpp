@@ -458,7 +458,6 @@ int Engine::initialize(int64_t n_simulation) {
 int Engine::initialize_body() {
   const int s = m_.s;
   for (int k = 0; k < kMaxPara; ++k) cb_.pivot[k] = 0.0;
-  for (int j = 0; j < kMaxStats; ++j) cb_.beta[j] = 0.0;       // (the multi-eps solve starts cold: a second initialisation is the first one again)
   cb_.n_accept = 0; cb_.hist_rows = 0; cb_.error = 0; cb_.halt = 0; cb_.eps_len = eps_len_;
   hist_capacity_ = 4;
   if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");

@@ -61,36 +61,42 @@ SABC_HD inline double tilted_mean_deriv(double b) {
   return -1.0 / (b * b) + (em + 1.0) / (em * em);
 }
 
-// beta_i of :113: tilted_mean(beta) = ubar_i.  Decreasing in beta, 1/2 at 0, < 1/beta for beta > 0:
-// the root lies in (0, 1/ubar_i].  Newton kept inside the bracket, bisection when it leaves it.
-// `hint` (optional): the root of the previous population update -- mean u moves by a fraction of a percent per update, so
-// the iteration starts two or three steps from its end instead of at the bracket's end (on the single control lane every
-// step is an expm1, ~1 us; a cold start takes 5-14 of them).  The derivative is written so that it stays finite when
-// expm1(b) overflows (b > 709, i.e. mean u < 0.0014, the late stage of every chain): the literal (e + 1) / e^2 is inf / inf
-// there and sent the iteration into ~50 bisection steps per statistic.
-SABC_HD inline double multi_eps_beta(double ub, double hint = 0.0) {
+// beta_i of :113: tilted_mean(beta) = ubar_i.  Decreasing in beta, 1/2 at 0, < 1/beta for beta > 0: the root lies in
+// (0, 1/ubar_i].
+//
+// A FUNCTION OF ubar_i ALONE.  Round 3 started the iteration from the previous update's root and stopped it at a relative
+// step of 4 eps: a warm and a cold start could end on neighbouring doubles, so epsilon depended on the call history (a
+// resumed run, a fresh handle and the oracle start cold) -- an ulp that can flip an accept at the boundary.  Now:
+//   * mean u <= 1/44 (the late stage of every chain): the root is 1 / mean u -- e^-beta is below the last bit of 1/beta, the
+//     equation reads 1/beta = ubar in double precision;
+//   * otherwise a fixed start -- (1 - 2u)/u * p4(u), exact at both ends of (0, 1/2) and within 1e-3 in between -- and a FIXED
+//     number of Newton steps (three: 1e-3 -> 1e-6 -> 1e-12 -> the noise of evaluating the equation itself), each one expm1.
+// No data-dependent stopping, no hint: the same bits wherever and whenever it is evaluated, and as few expm1 as the warm start
+// took at its best (a step is ~1 us on a control lane).  The derivative is written so that it stays finite when expm1
+// overflows (the literal (e + 1) / e^2 is inf / inf there).
+SABC_HD inline double multi_eps_beta(double ub) {
   if (ub == 0.5) return 0.0;
   const bool mirror = ub > 0.5;                      // tilted_mean(-b) = 1 - tilted_mean(b)
-  if (mirror) { ub = 1.0 - ub; hint = -hint; }
-  double lo = 0.0, hi = 1.0 / ub, b = (hint > 0.0 && hint < hi) ? hint : hi;
-  for (int it = 0; it < 200; ++it) {
-    // tilted_mean(b) and tilted_mean_deriv(b) from ONE expm1 (the same expressions as the two functions above: on the
-    // single control lane an expm1 is a few hundred dependent instructions)
-    double tm, td;
-    if (fabs(b) < 1e-2) {
-      tm = tilted_mean(b);
-      td = tilted_mean_deriv(b);
-    } else {
-      const double r = 1.0 / expm1(b);               // 0 when expm1 overflows
-      tm = 1.0 / b - r;
-      td = -1.0 / (b * b) + r * (1.0 + r);           // = (e + 1) / e^2 with e = expm1(b)
+  if (mirror) ub = 1.0 - ub;
+  double b;
+  if (ub <= 1.0 / 44.0) {
+    b = 1.0 / ub;
+  } else {
+    const double g = (((18.08509524 * ub - 19.10561105) * ub + 9.73841092) * ub + 1.63676858) * ub + 1.00652501;
+    b = (1.0 - 2.0 * ub) / ub * g;
+    for (int it = 0; it < 3; ++it) {
+      // tilted_mean(b) and tilted_mean_deriv(b) from ONE expm1 (the same expressions as the two functions above)
+      double tm, td;
+      if (fabs(b) < 1e-2) {
+        tm = tilted_mean(b);
+        td = tilted_mean_deriv(b);
+      } else {
+        const double r = 1.0 / expm1(b);
+        tm = 1.0 / b - r;
+        td = -1.0 / (b * b) + r * (1.0 + r);         // = (e + 1) / e^2 with e = expm1(b)
+      }
+      b -= (tm - ub) / td;
     }
-    const double f = tm - ub;
-    if (f > 0.0) lo = b; else hi = b;
-    double bn = b - f / td;
-    if (!(bn > lo && bn < hi)) bn = lo + 0.5 * (hi - lo);
-    if (bn == b || fabs(bn - b) <= 4.0 * DBL_EPSILON * fabs(bn)) { b = bn; break; }
-    b = bn;
   }
   return mirror ? -b : b;
 }
@@ -112,8 +118,8 @@ SABC_HD inline double eps_multi_cn(int s) {          // (2s+2)! / ((s+1)! (s+2)!
   for (int k = 1; k <= s + 1; ++k) cn = cn * (double)(s + 1 + k) / (double)k;
   return cn / (double)(s + 2);
 }
-// false when ubar_i <= eps() (:107-109); hint / beta_i: the root beta_i of the previous / of this update (multi_eps_beta)
-SABC_HD inline bool eps_multi_one(const double *ubar, int s, double v, double cn, int i, double hint, double *eps_i, double *beta_i) {
+// false when ubar_i <= eps() (:107-109)
+SABC_HD inline bool eps_multi_one(const double *ubar, int s, double v, double cn, int i, double *eps_i) {
   const double ui = ubar[i];
   if (ui <= DBL_EPSILON) return false;
   double num = 1.0, prodq = 1.0;
@@ -123,21 +129,16 @@ SABC_HD inline bool eps_multi_one(const double *ubar, int s, double v, double cn
     prodq *= q;
   }
   const double den = cn * (s + 1) * (ui * pow_half_int(ui, s)) * prodq;   // :112  ui^(1 + s/2)
-  const double beta = multi_eps_beta(ui, hint);
-  *beta_i = beta;
+  const double beta = multi_eps_beta(ui);
   *eps_i = 1.0 / (beta + v * num / den);                                   // :113-114
   return true;
 }
 
 // update_epsilon_multi_eps (:100-117); returns false when some ubar_i <= eps() (:107-109)
-// beta_io (optional, s doubles): in = the betas of the previous update (0 = none), out = this update's
-SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out, double *beta_io = nullptr) {
+SABC_HD inline bool eps_multi(const double *ubar, int s, double v, double *eps_out) {
   const double cn = eps_multi_cn(s);
-  for (int i = 0; i < s; ++i) {
-    double beta;
-    if (!eps_multi_one(ubar, s, v, cn, i, beta_io ? beta_io[i] : 0.0, &eps_out[i], &beta)) return false;
-    if (beta_io) beta_io[i] = beta;
-  }
+  for (int i = 0; i < s; ++i)
+    if (!eps_multi_one(ubar, s, v, cn, i, &eps_out[i])) return false;
   return true;
 }
 

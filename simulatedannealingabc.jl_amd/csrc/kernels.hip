@@ -615,7 +615,7 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
     __syncthreads();
     if ((int)threadIdx.x < a.s) {
       const int i = threadIdx.x;
-      cand.ok[i] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), i, lcb.beta[i], &cand.eps[i], &cand.beta[i]) ? 1 : 0;
+      cand.ok[i] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), i, &cand.eps[i]) ? 1 : 0;
     }
     __syncthreads();
   }

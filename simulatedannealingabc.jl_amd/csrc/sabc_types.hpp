@@ -46,7 +46,7 @@ struct StepArgs {
 // population updates back to back without reading anything back.
 struct ControlBlock {
   double eps[kMaxStats];                 // state.eps (SimulatedAnnealingABC.jl:29)
-  double beta[kMaxStats];                // multi-eps schedule: the roots beta_i of :113 of the last update (where the next solve starts; 0 = none)
+  double beta[kMaxStats];                // unused since round 4 (the multi-eps root is a function of mean u alone: host_math.hpp); keeps the layout
   double chol[kMaxPara * kMaxPara];      // row-major lower Cholesky factor of Sigma (1-D: sqrt(Sigma))
   double sigma[kMaxPara * kMaxPara];     // RandomWalk.Sigma (proposals.jl:26)
   double pivot[kMaxPara];                // shift of the fused moment sums

@@ -180,11 +180,12 @@ int main() {
     assert subprocess.check_output([str(exe)], text=True).strip() == "0"
 
 
-def test_multi_eps_beta_solve_warm_cold_and_overflow(tmp_path):
-    """The root beta_i of the multi-eps schedule (SimulatedAnnealingABC.jl:113; csrc/host_math.hpp: multi_eps_beta): started
-    from the previous update's root (the control step's warm start), from a useless hint or cold, the iteration ends at the
-    same root; where expm1(beta) overflows (mean u < 0.0014: the late stage of every chain) the derivative stays finite and
-    the root is 1 / mean u; the equation holds at the root."""
+def test_multi_eps_beta_is_a_function_of_mean_u_alone(tmp_path):
+    """The root beta_i of the multi-eps schedule (SimulatedAnnealingABC.jl:113; csrc/host_math.hpp: multi_eps_beta) is computed
+    from mean u alone -- a fixed start and a fixed number of Newton steps, no hint from the previous update, no data-dependent
+    stopping --, so epsilon cannot depend on the call history (a warm and a cold start could end an ulp apart).
+    Against a bracketed solve to the last bit it is the root to 1e-12; where e^-beta is below the last bit of 1/beta (mean
+    u <= 1/44, the late stage of every chain; expm1 overflows further out) the root is 1 / mean u; the equation holds."""
     import subprocess
     src = tmp_path / "beta.cpp"
     src.write_text(r'''
@@ -192,19 +193,28 @@ def test_multi_eps_beta_solve_warm_cold_and_overflow(tmp_path):
 #include <cstdlib>
 #include "simulatedannealingabc.jl_amd/csrc/host_math.hpp"
 using namespace sabc::hostmath;
+static double bracketed(double ub) {                                        // bisection on the equation, to the last bit
+  if (ub > 0.5) return -bracketed(1.0 - ub);
+  double lo = 0.0, hi = 1.0 / ub;
+  for (int it = 0; it < 200 && lo < hi; ++it) {
+    const double mid = lo + 0.5 * (hi - lo);
+    if (mid <= lo || mid >= hi) break;
+    if (tilted_mean(mid) - ub > 0.0) lo = mid; else hi = mid;
+  }
+  return 0.5 * (lo + hi);
+}
 int main() {
   double worst = 0.0, worst_tail = 0.0, worst_res = 0.0;
   srand(1);
   for (int t = 0; t < 100000; ++t) {
     double ub = pow(10.0, -7.0 * rand() / RAND_MAX) * 0.45;                 // 4.5e-8 .. 0.45
     if (t % 7 == 0) ub = 0.55 + 0.44 * rand() / RAND_MAX;                   // the mirrored branch (negative beta)
-    const double cold = multi_eps_beta(ub);
-    const double warm = multi_eps_beta(ub, cold * (1.0 + 0.02 * (rand() / (double)RAND_MAX - 0.5)));
-    const double far = multi_eps_beta(ub, cold * 3.0);
-    const double d = fmax(fabs(warm - cold), fabs(far - cold)) / fabs(cold);
+    if (t % 11 == 0) ub = 1.0 / 44.0 * (1.0 + 1e-6 * (rand() / (double)RAND_MAX - 0.5));   // around the switch to the closed form
+    const double b = multi_eps_beta(ub), ref = bracketed(ub);
+    const double d = fabs(b - ref) / fabs(ref);
     if (d > worst) worst = d;
-    if (ub < 1e-3) { const double e = fabs(cold * ub - 1.0); if (e > worst_tail) worst_tail = e; }
-    const double tm = 1.0 / cold - 1.0 / expm1(cold);                       // the equation of :113, literally
+    if (ub < 1e-3) { const double e = fabs(b * ub - 1.0); if (e > worst_tail) worst_tail = e; }
+    const double tm = 1.0 / b - 1.0 / expm1(b);                             // the equation of :113, literally
     const double r = fabs(tm - ub) / ub;
     if (r > worst_res) worst_res = r;
   }
