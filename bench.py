@@ -414,6 +414,7 @@ def main():
     res_ms, res_n = med["res"]
     c = h.counters
     th, _, _ = h.get_population(u=False, rho=False)
+    state_after_timed = (dict(c), h.eps.copy())          # the last timed region's: the extra updates below move on
     # N > 1: what one update costs between the update kernels, measured on 10 MORE updates with every kernel bracketed
     # (level 2 adds ~4 us per bracket, so this is not part of the timed region): the reduce[-exchange]-control launch and,
     # on the collectives transport, the allreduce between k_reduce_partials and k_control
@@ -437,7 +438,6 @@ def main():
     # on over what install_collectives put underneath.  Otherwise the collectives never get a number on a node where the
     # peer-to-peer transport comes up.
     exchange_rccl = None
-    state_after_timed = (dict(c), h.eps.copy())
     if world > 1 and transport == "p2p" and not args.no_kernel_events:
         say("leaving the peer-to-peer group: 10 bracketed updates over the collectives underneath")
         h.p2p_disable()
@@ -569,7 +569,7 @@ def main():
             "host_syncs_in_timed_region": syncs,
             "init_s": t_init,
             "state": {"n_accept": c["n_accept"], "n_resampling": c["n_resampling"],
-                      "n_population_updates": c["n_population_updates"], "eps": h.eps.tolist(),
+                      "n_population_updates": c["n_population_updates"], "eps": state_after_timed[1].tolist(),
                       "shard0_mean": th.mean(1).tolist(), "shard0_var": th.var(1).tolist(), **analytic},
         }
         comparable = args.config == "cfg2" and args.algorithm == "single_eps" and args.n_obs == 100
