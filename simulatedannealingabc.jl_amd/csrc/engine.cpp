@@ -638,7 +638,14 @@ int Engine::update_loop(const sabc_update_args &a) {
   if (be_->history_reserve(hist_capacity_)) return fail(SABC_ERR_HIP, "history buffer allocation failed");
   if (be_->write_control(cb_)) return fail(SABC_ERR_HIP, "writing the control block failed");
 
-  if (a.proposal_kind == SABC_PROP_RANDOMWALK) {                            // update_proposal!, :284
+  // A chunk that CONTINUES an update_population! call (history_phase > 0, the same proposal, the particles untouched since
+  // the previous chunk) starts from the control block as that chunk's last update left it -- Sigma and its factor from the
+  // fused sums of that update (:348), the running sum of rho -- exactly what the uncut call works with at this point.
+  // Recomputing them from a stats pass here would give the same numbers up to the summation order, i.e. an ulp, and the
+  // cut call would no longer be the uncut call bit for bit.
+  const bool continuation = a.history_phase > 0 && !population_replaced_ && last_prop_kind_ == a.proposal_kind &&
+                            last_prop_p0_ == a.proposal_p0 && last_prop_p1_ == a.proposal_p1;
+  if (a.proposal_kind == SABC_PROP_RANDOMWALK && !continuation) {           // update_proposal!, :284
     if (population_replaced_) {                                             // the pivot of the last call may be far off
       if ((rc = stats_reduce())) return rc;
       if ((rc = control(CTRL_PIVOT, &a, a.v))) return rc;                   // centre the moment sums first
@@ -646,7 +653,7 @@ int Engine::update_loop(const sabc_update_args &a) {
     if ((rc = stats_reduce())) return rc;
     if ((rc = control(CTRL_PROPOSAL, &a, a.v))) return rc;
   }
-  if (n_pop > 0 && a.proposal_kind != SABC_PROP_RANDOMWALK && !host_mode_) {
+  if (n_pop > 0 && a.proposal_kind != SABC_PROP_RANDOMWALK && !host_mode_ && !continuation) {
     // the update steps only report the CHANGE of sum(rho): start the running sum from the population as it stands (the
     // caller may have replaced it with sabc_set_population since the last call)
     if ((rc = stats_reduce())) return rc;
@@ -717,6 +724,7 @@ int Engine::update_loop(const sabc_update_args &a) {
   if ((rc = sync_control())) return rc;
   if ((rc = drain_history())) return rc;
   population_replaced_ = false;                                             // the pivot now follows the population
+  if (n_pop > 0) { last_prop_kind_ = a.proposal_kind; last_prop_p0_ = a.proposal_p0; last_prop_p1_ = a.proposal_p1; }
   n_simulation_ += n_updates;                                               // :391
   n_population_updates_ += n_pop;                                           // :394
   return 0;

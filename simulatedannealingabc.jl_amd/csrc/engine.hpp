@@ -198,6 +198,8 @@ class Engine {
   std::string err_;
   bool initialized_ = false;
   bool population_replaced_ = true;                 // the particles may lie anywhere relative to ControlBlock::pivot
+  int last_prop_kind_ = -1;                         // the proposal of the last call that ran an update (a chunk that continues it
+  double last_prop_p0_ = 0.0, last_prop_p1_ = 0.0;  // starts from the control block as it stands: update_loop)
 
   int np_ = 0, eps_len_ = 1;
   bool host_mode_ = false;                          // f_dist (SABC_MODEL_HOST) and / or the prior (prior_joint = 2) are host callbacks

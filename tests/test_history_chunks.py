@@ -28,11 +28,12 @@ def oracle_histories(O, name, n, total, cph, prop, d):
     return run
 
 
+@pytest.mark.parametrize("prop", ["de", "rw"])
 @pytest.mark.parametrize("total,cph,cuts", [(13, 3, (7,)), (14, 3, (7,)), (12, 3, (7,)), (13, 5, (2, 4, 6, 8, 10, 12)), (9, 4, (9,)),
                                             (10, 1, (3, 6)), (7, 10, (2, 5)), (6, -3, (4,))])
-def test_host_engine_chunks_keep_the_uncut_history(S, O, total, cph, cuts):
+def test_host_engine_chunks_keep_the_uncut_history(S, O, total, cph, cuts, prop):
     from tests import cpu_engine
-    name, n, prop = "gauss2_2stats", 300, "de"
+    name, n = "gauss2_2stats", 300
     d = len(MODELS[name]["prior"])
     model, prior = hip_model_prior(S, name)
     H = cpu_engine.handle_class()
@@ -47,6 +48,9 @@ def test_host_engine_chunks_keep_the_uncut_history(S, O, total, cph, cuts):
     assert a.counters == b.counters
     for x, y in zip(a.history, b.history):
         np.testing.assert_array_equal(x, y)                  # the same rows, the same numbers
+    for x, y in zip(a.get_population(), b.get_population()):
+        np.testing.assert_array_equal(x, y)                  # ... and the same particles, bit for bit: a chunk that continues a call
+                                                             # starts from the control block as the previous chunk left it
     expected = 1 + total // abs(cph) + (1 if total % abs(cph) else 0)
     assert len(a.history[0]) == expected
     if run is not None:
