@@ -618,6 +618,120 @@ __device__ __forceinline__ void gk_simulate_wave_ranks_x2(const ModelDesc &m, co
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 4: FOUR particles per wave at a time, one per row of 16 lanes, 8 of a particle's 128 values per lane.
+//
+// What the counters said of the two-values-per-lane network above (profiles/r03_pmc_sq_cfg4.csv): 82 % VALU busy, 44 % of the
+// wave-cycles parked -- and per simulated particle ~3 x as many instructions in the sort as in the generator: 18 of its 24
+// compare-exchange steps cross lanes, each one two moves, a compare and two selects PER ELEMENT.  With element e = 8 l + r
+// (l = lane in the row, r = register) the three lowest distances are between REGISTERS -- 15 of the 24 steps never leave the
+// lane, and a local compare-exchange is a v_min_f64 + a v_max_f64 -- and the remaining 9 pair lanes at distance 1, 2, 4, 8
+// inside a row of 16: DPP quad_perm / ds_swizzle, no v_permlane, no second LDS round trip.  A cross-lane step is ONE v_min_f64
+// per element by keeping the values SIGNED: with y = x in ascending and -x in descending lanes (the direction of a stage
+// is a lane bit from runs of 8 on) every step of a stage orders ascending; and with t = y in the lane that keeps the
+// minimum and -y in the lane that keeps the maximum both lanes evaluate min(t_own, -t_partner) (the negation is a source
+// modifier): min(y_a, y_b) below, -max(y_a, y_b) above -- already in the sign the upper lane stores.  Between two steps the
+// sign pattern changes by the XOR of two lane bits: one v_xor_b32 on the high word per element (13 such flips in all).
+// Per 4 particles: 120 (local) + 168 (cross-lane, + 48 ds_swizzle) + 104 (flips) + 10 (block maxima) VALU instructions, i.e.
+// ~100 per particle where the network above takes ~250.  The order statistics are the same numbers: a sorting network
+// permutes, and min / max of doubles that are never NaN select.
+//
+// The wanted ranks have to be multiples of 16 (BASELINE config 4: 16, 48, 80, 112): after the final merge's steps at element
+// distance 64, 32, 16 every pair of lanes (2 b, 2 b + 1) holds the ranks 16 b + 1 .. 16 b + 16, whose maximum is the order
+// statistic of rank 16 (b + 1).  Other ranks take the network above.
+__device__ __forceinline__ double gk_min_neg(double a, double b) {            // min(a, -b); (inline asm: a __builtin_fmin on
+  double r;                                                                   // a shuffled value is preceded by a canonicalising
+  asm("v_min_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));                     // v_max_f64 x, x)
+  return r;
+}
+__device__ __forceinline__ double gk_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double gk_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// compare-exchange between the registers at distance 2^J of one lane; DESC_BIT >= 0: pairs whose lower index has that bit set
+// order descending (the first two stages, whose direction is a register bit), -1: all ascending (on the signed values)
+template <int J, int DESC_BIT>
+__device__ __forceinline__ void gk_local_step(double (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i & (1 << J)) continue;
+    const double a = v[i], b = v[i | (1 << J)];
+    const double lo = gk_min(a, b), hi = gk_max(a, b);
+    const bool desc = DESC_BIT >= 0 && ((i >> (DESC_BIT < 0 ? 0 : DESC_BIT)) & 1);
+    v[i] = desc ? hi : lo;
+    v[i | (1 << J)] = desc ? lo : hi;
+  }
+}
+// ... with the lane at distance DIST of the row: every element becomes min(own, -partner's) (see above)
+template <int DIST>
+__device__ __forceinline__ void gk_cross_step(double (&v)[8]) {
+  double p[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) p[i] = xor_lane<DIST>(v[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = gk_min_neg(v[i], p[i]);
+}
+__device__ __forceinline__ void gk_flip(double (&v)[8], int sign_mask) {      // sign_mask: 0x80000000 in the lanes that change sign
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = __hiloint2double(__double2hiint(v[i]) ^ sign_mask, __double2loint(v[i]));
+}
+
+// Particle `my` (one per row of 16 lanes; the rows of a wave may hold the same particle) of the wave's staging area: its 128
+// draws, the wanted order statistics -- ranks 16 (b + 1) -- to rp_lds[my][j]: the order statistic of the NORMALS where the
+// quantile function is increasing (the caller maps it: gk_rho_of_normal), else rho_j itself.
+template <int S>
+__device__ __forceinline__ void gk_simulate_rows4(const ModelDesc &m, const double (*thp_lds)[4], double (*rp_lds)[S], const int my,
+                                                  const uint64_t pid, const uint64_t iter) {
+  const int lane = threadIdx.x & 63, rl = lane & 15;
+  const int n_draws = (int)m.p[0];
+  const double c = m.p[1];
+  double th[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) th[k] = thp_lds[my][k];
+  const bool inc = gk_increasing(th, c);                // uniform over the row
+  double v[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) box_muller(stream_block(m.seed, pid, PURPOSE_SIM, iter, (uint32_t)(4 * rl + t)), v[2 * t], v[2 * t + 1]);
+  if (!inc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = gk_quantile(th, c, v[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 8 * rl + i < n_draws ? v[i] : INFINITY;
+  // lane bits of the row as sign masks
+  const int b0 = (lane & 1) << 31, b1 = (lane & 2) << 30, b2 = (lane & 4) << 29, b3 = (lane & 8) << 28;
+  // runs of 2 and 4: direction = a register bit
+  gk_local_step<0, 1>(v);
+  gk_local_step<1, 2>(v); gk_local_step<0, 2>(v);
+  // runs of 8: descending in the lanes with bit 0 -- stored negated from here on (sign pattern in brackets)
+  gk_flip(v, b0);                                                                             // [b0]
+  gk_local_step<2, -1>(v); gk_local_step<1, -1>(v); gk_local_step<0, -1>(v);
+  // runs of 16
+  gk_flip(v, b1); gk_cross_step<1>(v);                                                        // [b1 ^ b0]
+  gk_flip(v, b0); gk_local_step<2, -1>(v); gk_local_step<1, -1>(v); gk_local_step<0, -1>(v);  // [b1]
+  // runs of 32
+  gk_flip(v, b2); gk_cross_step<2>(v);                                                        // [b2 ^ b1]
+  gk_flip(v, b1 ^ b0); gk_cross_step<1>(v);                                                   // [b2 ^ b0]
+  gk_flip(v, b0); gk_local_step<2, -1>(v); gk_local_step<1, -1>(v); gk_local_step<0, -1>(v);  // [b2]
+  // runs of 64
+  gk_flip(v, b3); gk_cross_step<4>(v);                                                        // [b3 ^ b2]
+  gk_flip(v, b2 ^ b1); gk_cross_step<2>(v);                                                   // [b3 ^ b1]
+  gk_flip(v, b1 ^ b0); gk_cross_step<1>(v);                                                   // [b3 ^ b0]
+  gk_flip(v, b0); gk_local_step<2, -1>(v); gk_local_step<1, -1>(v); gk_local_step<0, -1>(v);  // [b3]
+  // the final merge (all ascending), element distance 64, 32, 16 only
+  gk_cross_step<8>(v);                                                                        // [b3]
+  gk_flip(v, b3 ^ b2); gk_cross_step<4>(v);                                                   // [b2]
+  gk_flip(v, b2 ^ b1); gk_cross_step<2>(v);                                                   // [b1]
+  gk_flip(v, b1);                                                                             // [0]: the values themselves
+  // lanes (2 b, 2 b + 1) hold the ranks 16 b + 1 .. 16 b + 16: their maximum is the order statistic of rank 16 (b + 1)
+  double bm = gk_max(gk_max(gk_max(v[0], v[1]), gk_max(v[2], v[3])), gk_max(gk_max(v[4], v[5]), gk_max(v[6], v[7])));
+  bm = gk_max(bm, xor_lane<1>(bm));
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int lane_of_block = (((int)m.p[2 + j] >> 4) - 1) * 2;             // (uniform)
+    if (rl == lane_of_block) rp_lds[my][j] = inc ? bm : finite_or_big(fabs(bm - m.p[2 + S + j]));
+  }
+}
+
 #endif  // !__HIPCC_RTC__
 
 // stochastic Lotka-Volterra, Euler-Maruyama; rho = |mean/sd of prey and predator paths - obs|

@@ -52,6 +52,9 @@ constexpr int kGkReps = SABC_GK_REPS;
 #ifndef SABC_GK_PAIR
 #define SABC_GK_PAIR 1
 #endif
+#ifndef SABC_GK_ROWS4
+#define SABC_GK_ROWS4 1
+#endif
 constexpr int kGkUpdatePerBlock = kGkPerBlock * kGkReps;
 
 // per-wave staging of what phase 1 (propose + simulate) hands to phase 2 (ECDF) and 3 (accept)
@@ -147,6 +150,22 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
   // Particles outside the prior's support are not simulated (:314): the wave walks the set bits of `todo`.
   {
     unsigned long long todo = __ballot(mine && st.lpp[lane] > -INFINITY);
+    // wanted ranks that are all multiples of 16 (BASELINE config 4): FOUR particles at a time, one per row of 16 lanes, eight
+    // values per lane -- 15 of the network's 24 steps stay inside the lane (device_models.hpp: gk_simulate_rows4)
+    bool rows4 = SABC_GK_ROWS4 != 0;                     // uniform
+#pragma unroll
+    for (int j = 0; j < S; ++j) rows4 = rows4 && (((int)m.p[2 + j]) & 15) == 0 && (int)m.p[2 + j] >= 16;
+    while (rows4 && todo) {
+      int idx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (todo) { idx[q] = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+        else idx[q] = idx[q - 1 < 0 ? 0 : q - 1];        // fewer than four left: the last one again (it writes the same values)
+      }
+      const int row = lane >> 4;
+      const int my = row == 0 ? idx[0] : row == 1 ? idx[1] : row == 2 ? idx[2] : idx[3];
+      gk_simulate_rows4<S>(m, st.thp, st.rp, my, (uint64_t)(pp.gid0 + act_lo + t0 + my), c.iter);
+    }
     while (todo) {                                       // uniform over the wave
       const int ia = __ffsll((long long)todo) - 1;
       todo &= todo - 1;

@@ -54,6 +54,13 @@ MODELS = {
     # themselves (below it sorts the normals and maps the wanted ranks: device_models.hpp, gk_increasing)
     "gk_c09": dict(model=("GandK", dict(n_draws=100, c=0.9, ranks=(10, 40, 60, 95), obs=(1.5, 2.8, 3.4, 7.0))),
                    prior=[("U", 0.0, 10.0)] * 4, s=4),
+    # ... and the two together with wanted ranks that are multiples of 16 -- the four-particles-per-wave network of round 4
+    # (device_models.hpp: gk_simulate_rows4) sorting the DATA, and with fewer than 128 draws (the tail of the 128 is +inf;
+    # rank 112 lies behind the 100 draws: an infinite order statistic, a distance of 1e30)
+    "gk_c09_blocks": dict(model=("GandK", dict(n_draws=128, c=0.9, ranks=(16, 48, 80, 112), obs=(1.6, 2.7, 3.7, 6.9))),
+                          prior=[("U", 0.0, 10.0)] * 4, s=4),
+    "gk_short_blocks": dict(model=("GandK", dict(n_draws=100, c=0.8, ranks=(16, 32, 64, 96), obs=(1.9, 2.3, 3.2, 6.0))),
+                            prior=[("U", 0.0, 10.0)] * 4, s=4),
     # BASELINE config 5
     "lv_cfg5": dict(model=("LotkaVolterra", dict(n_steps=256, dt=0.05, σ=0.1, x0=50.0, y0=50.0, obs=(18.0, 17.0, 14.0, 12.0))),
                     prior=[("U", 0.0, 2.0), ("U", 0.0, 0.1), ("U", 0.0, 2.0)], s=4),
