@@ -68,8 +68,14 @@ struct GkStage {
 
 // 4 workgroups per CU (<= 128 VGPRs, 68 B of scratch outside the sort): 850 -> 755 us at n = 1e6 against 3 per CU (144 VGPRs,
 // no scratch) -- the sort waits on lane exchanges, so the extra wave pays; 5 per CU spills inside the loop (1030 us)
-template <int PROP>
-__global__ void __launch_bounds__(kBlock, 4)
+// ROWS4: every wanted rank is a multiple of 16 (the host looks: launch_update) -- the simulations run four particles at a time
+// on the network of gk_simulate_rows4 only; the two-values-per-lane network stays out of this instantiation (and its
+// registers with it: SABC_GK_ROWS4_WAVES workgroups per CU)
+#ifndef SABC_GK_ROWS4_WAVES
+#define SABC_GK_ROWS4_WAVES 4
+#endif
+template <int PROP, bool ROWS4>
+__global__ void __launch_bounds__(kBlock, ROWS4 ? SABC_GK_ROWS4_WAVES : 4)
 k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
             const PartnerView pv, const int64_t act_lo, const int64_t act_n, double *__restrict__ partials) {
   constexpr int D = kGkD, S = kGkS, NP = n_partials(D, S), PW = kGkParticlesPerWave;
@@ -152,10 +158,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
     unsigned long long todo = __ballot(mine && st.lpp[lane] > -INFINITY);
     // wanted ranks that are all multiples of 16 (BASELINE config 4): FOUR particles at a time, one per row of 16 lanes, eight
     // values per lane -- 15 of the network's 24 steps stay inside the lane (device_models.hpp: gk_simulate_rows4)
-    bool rows4 = SABC_GK_ROWS4 != 0;                     // uniform
-#pragma unroll
-    for (int j = 0; j < S; ++j) rows4 = rows4 && (((int)m.p[2 + j]) & 15) == 0 && (int)m.p[2 + j] >= 16;
-    while (rows4 && todo) {
+    while (ROWS4 && todo) {
       int idx[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -166,7 +169,7 @@ k_update_gk(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict_
       const int my = row == 0 ? idx[0] : row == 1 ? idx[1] : row == 2 ? idx[2] : idx[3];
       gk_simulate_rows4<S>(m, st.thp, st.rp, my, (uint64_t)(pp.gid0 + act_lo + t0 + my), c.iter);
     }
-    while (todo) {                                       // uniform over the wave
+    while (!ROWS4 && todo) {                             // uniform over the wave
       const int ia = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
 #if SABC_GK_PAIR
@@ -1732,10 +1735,17 @@ int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb,
   }
   if (m.model_id == SABC_MODEL_GK) {
     const dim3 g((unsigned)update_rows(m, act_n));
-    switch (c.prop_kind) {
-      case SABC_PROP_RANDOMWALK: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_RANDOMWALK>), g); break;
-      case SABC_PROP_DIFFEVO: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_DIFFEVO>), g); break;
-      case SABC_PROP_STRETCH: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_STRETCH>), g); break;
+    // wanted ranks that are all multiples of 16 (BASELINE config 4): FOUR particles at a time, one per row of 16 lanes, eight
+    // values per lane -- 15 of the network's 24 steps stay inside the lane (device_models.hpp: gk_simulate_rows4)
+    bool rows4 = SABC_GK_ROWS4 != 0;
+    for (int j = 0; j < kGkS; ++j) rows4 = rows4 && (((int)m.p[2 + j]) & 15) == 0 && (int)m.p[2 + j] >= 16 && (int)m.p[2 + j] <= 128;
+    switch (c.prop_kind * 2 + (rows4 ? 1 : 0)) {
+      case SABC_PROP_RANDOMWALK * 2: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_RANDOMWALK, false>), g); break;
+      case SABC_PROP_RANDOMWALK * 2 + 1: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_RANDOMWALK, true>), g); break;
+      case SABC_PROP_DIFFEVO * 2: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_DIFFEVO, false>), g); break;
+      case SABC_PROP_DIFFEVO * 2 + 1: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_DIFFEVO, true>), g); break;
+      case SABC_PROP_STRETCH * 2: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_STRETCH, false>), g); break;
+      case SABC_PROP_STRETCH * 2 + 1: SABC_LAUNCH_UPDATE((k_update_gk<SABC_PROP_STRETCH, true>), g); break;
       default: return (int)hipErrorInvalidValue;
     }
     return SABC_LAUNCH_RC();
