@@ -98,10 +98,12 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
   SABC_CTRL_MARK(11);
   if (a.mode & CTRL_HISTORY) {                                                       // :367-372
     if (cb.hist_rows < a.hist_capacity) {
-      double *row = hist + cb.hist_rows * (cb.eps_len + 2 * s);
-      for (int i = 0; i < cb.eps_len; ++i) row[i] = cb.eps[i];
-      for (int j = 0; j < s; ++j) row[cb.eps_len + j] = cb.sums[1 + j] / n;
-      for (int j = 0; j < s; ++j) row[cb.eps_len + s + j] = cb.sums[1 + s + j] / n;
+      if (hist) {                                    // (nullptr: a workgroup of k_update_persistent that only keeps the count)
+        double *row = hist + cb.hist_rows * (cb.eps_len + 2 * s);
+        for (int i = 0; i < cb.eps_len; ++i) row[i] = cb.eps[i];
+        for (int j = 0; j < s; ++j) row[cb.eps_len + j] = cb.sums[1 + j] / n;
+        for (int j = 0; j < s; ++j) row[cb.eps_len + s + j] = cb.sums[1 + s + j] / n;
+      }
       cb.hist_rows += 1;
     } else {
       cb.error = SABC_ERR_STATE;

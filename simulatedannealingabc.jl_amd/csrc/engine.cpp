@@ -222,7 +222,7 @@ int Engine::stats_reduce() {
   return global_reduce(rows);
 }
 
-int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool notify, double threshold, int64_t *seq_out) {
+ControlArgs Engine::control_args(int32_t mode, const sabc_update_args *a, double v, double threshold) const {
   ControlArgs c;
   std::memset(&c, 0, sizeof(c));
   c.mode = mode;
@@ -233,11 +233,16 @@ int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool noti
   c.n_global = (double)sh_.n_global;
   c.v = v;
   c.hist_capacity = hist_capacity_;
-  c.notify_seq = notify ? ++notify_seq_ : 0;
   c.resample_threshold = threshold;
   // update steps of the device-coded simulators report the change of sum(rho); stats passes (and the host-callback
   // mode, whose sums come from a stats pass) the sum itself
   c.rho_is_delta = ((mode & CTRL_ACCUMULATE) && !host_mode_) ? 1 : 0;
+  return c;
+}
+
+int Engine::control(int32_t mode, const sabc_update_args *a, double v, bool notify, double threshold, int64_t *seq_out) {
+  ControlArgs c = control_args(mode, a, v, threshold);
+  c.notify_seq = notify ? ++notify_seq_ : 0;
   if (seq_out) *seq_out = c.notify_seq;
   if (be_->control(c)) return fail(SABC_ERR_HIP, "control kernel failed");
   return 0;
@@ -273,6 +278,8 @@ int Engine::sync_control() {
                     kind[k & 3], cb_.comm_where & 0xFFFFF, (cb_.comm_where >> 20) & 15);
       return fail(SABC_ERR_COMM, buf);
     }
+    case SABC_ERR_HIP: return fail(SABC_ERR_HIP, "the persistent update kernel's grid barrier ran into its bound (its workgroups were not all "
+                                                 "resident: is the device full of other persistent kernels?  SABC_PERSISTENT=0 takes the launch chain)");
     default: return fail(cb_.error, "error raised by the device-side control step");
   }
 }
@@ -560,6 +567,49 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
   return global_reduce(rows, guarded);
 }
 
+// The loop of :294-375 on a small shard: the backend runs the updates in one launch (body -> sums -> control step, per update,
+// inside the kernel) until the resample test of :340 fires; the host then resamples (:341), finishes that update's control
+// step and launches the rest.  Same kernels' arithmetic, same control step, same history cadence as the chain below.
+int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase) {
+  const int32_t after_update = CTRL_PROPOSAL | CTRL_EPSILON | CTRL_PIVOT;   // :348-354
+  StepArgs c;
+  std::memset(&c, 0, sizeof(c));
+  c.prop_kind = a.proposal_kind; c.prop_p0 = a.proposal_p0; c.prop_p1 = a.proposal_p1;
+  PartnerView pv_a, pv_b;                                                   // partners of half batch A: the second halves; of B: the first
+  std::memset(&pv_a, 0, sizeof(pv_a));
+  std::memset(&pv_b, 0, sizeof(pv_b));
+  int rc;
+  int64_t ix = 1;
+  while (ix <= n_pop) {
+    if (a.proposal_kind != SABC_PROP_RANDOMWALK) {                          // (the population buffers flip on a resample)
+      if ((rc = partner_source(1, &pv_a))) return rc;
+      if ((rc = partner_source(0, &pv_b))) return rc;
+    }
+    c.iter = (uint64_t)(n_population_updates_ + ix);
+    const double threshold = (double)(n_resampling_ + 1) * a.resample;      // :340
+    const ControlArgs ctrl = control_args(CTRL_ACCUMULATE | CTRL_CHECK | after_update, &a, a.v, threshold);
+    int64_t done = 0;
+    int halted = 0, error = 0;
+    if (be_->update_persistent(c, ctrl, pv_a, pv_b, ix, phase, cph, n_pop - ix + 1, &done, &halted, &error))
+      return fail(SABC_ERR_HIP, "persistent update kernel failed");
+    host_syncs_ += 1;
+    persistent_launches_ += 1;
+    if (error) { cb_.error = error; return sync_control(); }
+    if (done < 1 || done > n_pop - ix + 1) return fail(SABC_ERR_HIP, "persistent update kernel reported an impossible update count");
+    const int64_t last = ix + done - 1;
+    if (halted) {
+      // n_accept >= (n_resampling + 1) * resample after update `last` (:340): resample, then the part of its control step
+      // that was skipped
+      if ((rc = resample(a.delta, (uint64_t)(n_population_updates_ + last)))) return rc;          // :341
+      n_resampling_ += 1;                                                                         // :342
+      const int32_t hist = ((phase + last) % cph == 0) ? (int32_t)CTRL_HISTORY : 0;
+      if ((rc = control(CTRL_CLEAR_HALT | after_update | hist, &a, a.v))) return rc;
+    }
+    ix = last + 1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // update_population!(), :251-402
 // ------------------------------------------------------------------------------------------
@@ -666,6 +716,11 @@ int Engine::update_loop(const sabc_update_args &a) {
         return fail(SABC_ERR_BAD_CONFIG, "too few particles in a half batch for this proposal");
   }
 
+  // Small shards with a device-coded simulator: the whole loop of :294-375 in ONE launch per stretch between two resamples
+  // (kernels.hip: k_update_persistent) instead of a chain of launches per update
+  if (n_pop > 0 && !host_mode_ && sh_.world == 1 && be_->persistent_supported(a.proposal_kind)) {
+    if ((rc = update_loop_persistent(a, n_pop, cph, phase))) return rc;
+  } else {
   // The loop of :294-375 with the host two updates ahead of the device.  Every update is enqueued as
   //   k_update (x1 or x2) -> k_reduce_partials -> [allreduce] -> k_control(ACCUMULATE | CHECK | ...)
   // where the control step evaluates the resample test of :340 ON THE DEVICE.  If it does not fire, the
@@ -714,6 +769,7 @@ int Engine::update_loop(const sabc_update_args &a) {
       next_enqueue = ix + 1;
     }
     ++next_confirm;
+  }
   }
   // :378-382 -- `last_checkpoint_epsilon != n_population_updates` is `the loop's last update was not a checkpoint`; only the
   // call that ends the loop stores the last value

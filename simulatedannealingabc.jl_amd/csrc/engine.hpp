@@ -60,6 +60,15 @@ class Backend {
   // eps, the Cholesky factor and the pivot are read from the control block.
   virtual int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                            int64_t *rows_out) = 0;
+  // K4 for small shards: `count` population updates in ONE launch, starting with update ix0 of the call (global index
+  // c.iter) -- per update the body, the sums and the control step `ctrl` (+ a history row by the cadence (phase + ix) % cph),
+  // until the resample test fires or an error is raised.  Blocks until the launch has ended; done = updates completed (the
+  // last of them the one that halted), halted / error from the control block.  persistent_supported: this backend has such a
+  // form for this proposal on its shard (the engine then takes it instead of a launch chain per update).
+  virtual bool persistent_supported(int /*prop_kind*/) const { return false; }
+  virtual int update_persistent(const StepArgs &, const ControlArgs &, const PartnerView &, const PartnerView &, int64_t /*ix0*/,
+                                int64_t /*phase*/, int64_t /*cph*/, int64_t /*count*/, int64_t * /*done*/, int * /*halted*/,
+                                int * /*error*/) { return -1; }
   virtual int stats(int64_t *rows_out) = 0;
   // -> ControlBlock::sums; guarded: part of a queued-ahead step (no-op while ControlBlock::halt is set)
   virtual int reduce_partials(int64_t rows, bool guarded) = 0;
@@ -157,6 +166,7 @@ class Engine {
   void set_collectives(Collectives *c) { coll_ = c; }
   // how often update() had to wait for the device (one per run-ahead window), for measurement
   int64_t host_syncs() const { return host_syncs_; }
+  int64_t persistent_launches() const { return persistent_launches_; }
   // bytes that landed in this shard's receive buffers through collectives so far (allreduce: the vector; allgather: all
   // blocks; alltoallv: what arrived)
   int64_t comm_bytes() const { return comm_bytes_; }
@@ -186,6 +196,7 @@ class Engine {
   int partner_source(int inactive_half, PartnerView *pv);
   int enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded);
   int update_loop(const sabc_update_args &a);       // update() minus the error contract
+  int update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase);   // small shards: one launch
   int update_once(const sabc_update_args &a);       // update_loop + the error contract; update() adds the transport fallback
   int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
@@ -207,7 +218,8 @@ class Engine {
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
-  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0, persistent_launches_ = 0;
+  ControlArgs control_args(int32_t mode, const sabc_update_args *a, double v, double threshold) const;
   int p2p_check_peers();                            // p2p: a peer has left the group? (entry of a call, nothing launched yet)
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
   void p2p_abort(int rc);                           // ... and after a failure (rc: what the call returns)

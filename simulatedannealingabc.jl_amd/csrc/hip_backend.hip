@@ -31,7 +31,16 @@ std::atomic<int64_t> g_parked_bytes{0};       // device memory kept because a pe
     if (e_) return check((hipError_t)e_, (what));  \
   } while (0)
 
+static double persist_timeout_ms() {
+  static const double ms = [] { const char *e = std::getenv("SABC_PERSISTENT_TIMEOUT_MS"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2000.0; }();
+  return ms;
+}
+
 HipBackend::HipBackend(int device) : device_(device) {
+  // shards up to this many particles run the population updates of a call in ONE launch (kernels.hip: k_update_persistent);
+  // SABC_PERSISTENT=0 (or SABC_PERSISTENT_MAX=0) keeps the launch chain per update at every size
+  if (const char *e = std::getenv("SABC_PERSISTENT_MAX")) persist_max_ = std::atoll(e);
+  if (const char *e = std::getenv("SABC_PERSISTENT")) { if (e[0] == '0') persist_max_ = 0; }
   // (tests lower the limit to reach the two-launch form -- k_reduce_partials, then the control / exchange launch -- at small n)
   if (const char *e = std::getenv("SABC_FUSE_REDUCE_MAX")) {
     const long long v = std::atoll(e);
@@ -94,6 +103,7 @@ HipBackend::~HipBackend() {
   if (mbox_host_) (void)hipHostFree(mbox_host_);
   if (totals_host_) (void)hipHostFree(totals_host_);
   rtc_release(&rtc_);
+  if (persist_sync_) (void)hipFree(persist_sync_);
   if (slots_) (void)hipFree(slots_);
   if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
   if (snap_pop_) (void)hipFree(snap_pop_);
@@ -610,6 +620,41 @@ int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t l
   }
   HB_LAUNCH(launch_update(m_, c, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv, lo, cnt, partials_, row0, stream_, ev0, ev1, rtc()), "k_update");
   *rows_out = rows;
+  return 0;
+}
+
+// Small shards: the updates of a call in one launch (kernels.hip: k_update_persistent).  Not under a profile level that
+// wants every kernel bracketed (the launch chain is what such a run measures), not for run-time compiled simulators.
+bool HipBackend::persistent_supported(int prop_kind) const {
+  if (persist_max_ <= 0 || sh_.world != 1 || sh_.n_local > persist_max_ || prof_ >= 2 || rtc()) return false;
+  const int64_t wg = persistent_workgroups(m_, prop_kind, sh_.n_local);
+  return wg > 0 && 2 * wg <= partial_rows_;
+}
+
+int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, const PartnerView &pv_a, const PartnerView &pv_b, int64_t ix0,
+                                  int64_t phase, int64_t cph, int64_t count, int64_t *done, int *halted, int *error) {
+  if (pending_rows_ >= 0 && flush_reduce()) return -1;
+  if (!persist_sync_) HB_CHECK(hipMalloc((void **)&persist_sync_, 2 * sizeof(unsigned long long)), "hipMalloc(grid barrier)");
+  HB_CHECK(hipMemsetAsync(persist_sync_, 0, 2 * sizeof(unsigned long long), stream_), "hipMemset(grid barrier)");
+  PersistArgs pa;
+  std::memset(&pa, 0, sizeof(pa));
+  pa.iter0 = c.iter;
+  pa.ix0 = ix0; pa.phase = phase; pa.cph = cph;
+  pa.act_n = sh_.n_local; pa.half = sh_.n_local / 2;
+  pa.count = (int32_t)(count > (int64_t)1 << 30 ? (int64_t)1 << 30 : count);
+  pa.prop_p0 = c.prop_p0; pa.prop_p1 = c.prop_p1;
+  pa.ctrl = ctrl;
+  pa.sync = persist_sync_;
+  pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
+  prof_begin(SABC_KERNEL_UPDATE);
+  HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, partials_, hist_dev_, mbox_dev_,
+                                     sums_stage_, stream_), "k_update_persistent");
+  prof_end(SABC_KERNEL_UPDATE);
+  ControlBlock cb;
+  if (read_control(&cb)) return -1;
+  *done = cb.persist_done;
+  *halted = cb.halt;
+  *error = cb.error;
   return 0;
 }
 

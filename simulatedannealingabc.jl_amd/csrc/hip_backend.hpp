@@ -39,6 +39,9 @@ class HipBackend : public Backend {
   int cdf_population() override;
   int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                    int64_t *rows_out) override;
+  bool persistent_supported(int prop_kind) const override;
+  int update_persistent(const StepArgs &c, const ControlArgs &ctrl, const PartnerView &pv_a, const PartnerView &pv_b, int64_t ix0,
+                        int64_t phase, int64_t cph, int64_t count, int64_t *done, int *halted, int *error) override;
   int stats(int64_t *rows_out) override;
   int reduce_partials(int64_t rows, bool guarded) override;
   int control(const ControlArgs &a) override;
@@ -224,6 +227,8 @@ class HipBackend : public Backend {
   double *p2p_test_dev_ = nullptr;
   double *snap_pop_ = nullptr, *snap_rho_ = nullptr;     // device-side copy of the particles at the entry of a call
   int64_t launches_ = 0;
+  int64_t persist_max_ = 65536;                           // shards up to this many particles run their updates in one launch (0: never)
+  unsigned long long *persist_sync_ = nullptr;            // the grid barrier's counter and abort flag
   int prof_ = 0, prof_open_ = -1;
   unsigned prof_tick_ = 0;
   struct EvPair { hipEvent_t a, b; };

@@ -97,6 +97,22 @@ int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream
 int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const RtcKernels *rtc = nullptr);
+// K4 for SMALL shards, the updates of a call in ONE launch (kernels.hip: k_update_persistent): what one launch is asked to do
+struct PersistArgs {
+  uint64_t iter0;                // global index of the launch's first population update (RNG counter word)
+  int64_t ix0, phase, cph;       // ... which is update ix0 of the call; update ix appends a history row iff (phase + ix) % cph == 0
+  int64_t act_n, half;           // particles of the shard; size of the first half batch (DifferentialEvolution / StretchMove)
+  int32_t count, reserved;       // updates to run (the launch stops early when the resample test fires or an error is raised)
+  double prop_p0, prop_p1;
+  ControlArgs ctrl;              // the control step of every update: ACCUMULATE | CHECK | PROPOSAL | EPSILON | PIVOT (history by cadence)
+  unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag; zeroed before the launch
+  uint64_t timeout_ticks;        // bound of a wait at the grid barrier (wall clock)
+};
+// workgroups of the launch (all of them have to be resident at once) or 0 when this model / shape has no persistent form
+int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n);
+int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
+                             PartnerView pv_a, PartnerView pv_b, double *partials, double *hist, Mailbox *mbox, double *stage,
+                             hipStream_t stream);
 // number of partial rows launch_update() writes for act_n particles (depends on the kernel's granularity)
 int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0

@@ -53,6 +53,7 @@ struct ControlBlock {
   double sums[1 + 2 * kMaxStats + kMaxPara + kMaxPara * (kMaxPara + 1) / 2];   // last global sums
   int64_t n_accept;                      // state.n_accept
   int64_t hist_rows;                     // rows appended to the device history buffer
+  int64_t persist_done;                  // k_update_persistent: population updates this launch has completed (-1: it never got there)
   int32_t error;                         // 0 or a SABC_ERR_* raised on the device
   int32_t eps_len;
   int32_t halt;                          // set when the resample test (:340) fires: queued-ahead kernels become no-ops

@@ -95,6 +95,121 @@ __device__ __forceinline__ const double *shard_block(const ShardBlocks &b, int64
 // K4: propose -> prior gate -> simulate -> distance -> ECDF -> annealed MH accept -> store,
 //     + fused block partials.   SimulatedAnnealingABC.jl:308-331
 // ------------------------------------------------------------------------------------------
+// the coarse level of the ECDF tables into LDS: all reads first, then the LDS writes -- one trip to memory at the front of
+// the workgroup's life instead of one per pass
+template <int S>
+__device__ __forceinline__ void load_coarse_index(const CdfPtrs &cdf, double (&cidx)[S][cdf_coarse_entries(S)]) {
+  constexpr int kUpdateBlock = update_block_threads(S), kCoarse = cdf_coarse_entries(S);
+  static_assert((S * kCoarse / 2) % kUpdateBlock == 0, "whole passes of 16 bytes per thread");
+  constexpr int kPasses = S * kCoarse / 2 / kUpdateBlock;
+  const double2 *src = reinterpret_cast<const double2 *>(cdf.coarse);
+  double2 *dst = reinterpret_cast<double2 *>(&cidx[0][0]);
+  double2 tmp[kPasses];
+#pragma unroll
+  for (int q = 0; q < kPasses; ++q) tmp[q] = src[threadIdx.x + q * kUpdateBlock];
+#pragma unroll
+  for (int q = 0; q < kPasses; ++q) dst[threadIdx.x + q * kUpdateBlock] = tmp[q];
+}
+
+// The per-particle body, :308-331, for local particle li (global id gid) at population update `iter`; eps, the Cholesky
+// factor and the pivot come from *cb -- the control block in memory (k_update: scalar loads) or a workgroup's LDS copy of it
+// (k_update_persistent); the particle's moment terms go to acc.
+template <int MODEL, int D, int S, int PROP, class CB>
+__device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
+                                                const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
+                                                const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
+                                                double (&acc)[n_partials(D, S)]) {
+  constexpr int kCoarse = cdf_coarse_entries(S);
+  // rho is NOT read here: an update step reports the CHANGE of sum(rho) (rho' - rho of the accepted particles, read where
+  // they are overwritten); the control step adds it to the running sum (ControlArgs::rho_is_delta).  8 s n bytes less
+  // read per launch: the old distance of a particle that is not accepted is never needed.
+  double th[D], u[S], drho[S];
+#pragma unroll
+  for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+#pragma unroll
+  for (int j = 0; j < S; ++j) { u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li]; drho[j] = 0.0; }
+
+  // ---- proposal (:311) ----
+  double thp[D];
+  double logf = 0.0;
+  if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
+    NormalStream ns(m.seed, gid, PURPOSE_PROP, iter);
+    double z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) z[k] = ns.next();
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
+      thp[k] = th[k] + a;
+    }
+  } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
+    uint64_t i1 = 0, i2 = 0;
+    for (uint32_t a = 0;; ++a) {                 // :103-107, redraw both until distinct
+      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, iter, a);
+      i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
+      i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
+      if (i1 != i2 || a > 64u) break;
+    }
+    double z0, z1;
+    box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, iter, 0), z0, z1);
+    const double gamma = prop_p0 * (1.0 + prop_p1 * z0);      // :110
+    const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+  } else {                                       // StretchMove, proposals.jl:137-148
+    const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, iter, 0);
+    const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
+    const double U = u52(w.z, w.w);
+    const double a = prop_p0;
+    const double tt = (a - 1.0) * U + 1.0;
+    const double z = tt * tt / a;                                          // :144
+    const double *p = partner_ptr(pv, ip);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double pk = p[(int64_t)k * pv.cap];
+      thp[k] = pk + z * (th[k] - pk);                                      // :147
+    }
+    logf = log(z) * (double)(D - 1);                                       // :146
+  }
+
+  // ---- acceptance probability (:314-322) ----
+  const double lpp = prior_logpdf<D>(m, thp);
+  double log_accept = -INFINITY;
+  double up[S], rp[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
+  if (lpp > -INFINITY) {
+    Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);                          // :315
+    double a = 0.0;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
+                               cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
+      const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
+      a += (u[j] - up[j]) / e;                                             // :319
+    }
+    log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
+  }
+
+  // ---- accept / store (:324-329) ----
+  const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, iter, 0);
+  const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
+  if (accepted) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      u[j] = up[j];
+      drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
+      pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+      pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+    }
+  }
+  moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
+}
+
 template <int MODEL, int D, int S, int PROP>
 __global__ void __launch_bounds__(update_block_threads(S), update_min_waves(S))
 k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ cb, const PopPtrs pp, const CdfPtrs cdf,
@@ -104,17 +219,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
   rng_tables_load();
   constexpr int kUpdateBlock = update_block_threads(S), kCoarse = cdf_coarse_entries(S);
   __shared__ double cidx[S][kCoarse];      // coarse level of the ECDF tables, 8 or 16 KB per statistic
-  {   // all reads first, then the LDS writes: one trip to memory at the front of the workgroup's life instead of one per pass
-    static_assert((S * kCoarse / 2) % kUpdateBlock == 0, "whole passes of 16 bytes per thread");
-    constexpr int kPasses = S * kCoarse / 2 / kUpdateBlock;
-    const double2 *src = reinterpret_cast<const double2 *>(cdf.coarse);
-    double2 *dst = reinterpret_cast<double2 *>(&cidx[0][0]);
-    double2 tmp[kPasses];
-#pragma unroll
-    for (int q = 0; q < kPasses; ++q) tmp[q] = src[threadIdx.x + q * kUpdateBlock];
-#pragma unroll
-    for (int q = 0; q < kPasses; ++q) dst[threadIdx.x + q * kUpdateBlock] = tmp[q];
-  }
+  load_coarse_index<S>(cdf, cidx);
   __syncthreads();                         // publishes both the generator tables and the index
   double acc[NP];
 #pragma unroll
@@ -123,95 +228,7 @@ k_update(const ModelDesc m, const StepArgs c, const ControlBlock *__restrict__ c
   const int64_t t = (int64_t)blockIdx.x * kUpdateBlock + threadIdx.x;
   if (t < act_n) {
     const int64_t li = act_lo + t;
-    const uint64_t gid = (uint64_t)(pp.gid0 + li);
-    // rho is NOT read here: an update step reports the CHANGE of sum(rho) (rho' - rho of the accepted particles, read where
-    // they are overwritten); the control step adds it to the running sum (ControlArgs::rho_is_delta).  8 s n bytes less
-    // read per launch: the old distance of a particle that is not accepted is never needed.
-    double th[D], u[S], drho[S];
-#pragma unroll
-    for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li]; drho[j] = 0.0; }
-
-    // ---- proposal (:311) ----
-    double thp[D];
-    double logf = 0.0;
-    if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
-      NormalStream ns(m.seed, gid, PURPOSE_PROP, c.iter);
-      double z[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) z[k] = ns.next();
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        double a = 0.0;
-#pragma unroll
-        for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
-        thp[k] = th[k] + a;
-      }
-    } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
-      uint64_t i1 = 0, i2 = 0;
-      for (uint32_t a = 0;; ++a) {                 // :103-107, redraw both until distinct
-        const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, a);
-        i1 = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);
-        i2 = mulhi64(pack64(w.z, w.w), (uint64_t)pv.m_total);
-        if (i1 != i2 || a > 64u) break;
-      }
-      double z0, z1;
-      box_muller(stream_block(m.seed, gid, PURPOSE_PROP2, c.iter, 0), z0, z1);
-      const double gamma = c.prop_p0 * (1.0 + c.prop_p1 * z0);      // :110
-      const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
-#pragma unroll
-      for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
-    } else {                                       // StretchMove, proposals.jl:137-148
-      const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, c.iter, 0);
-      const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
-      const double U = u52(w.z, w.w);
-      const double a = c.prop_p0;
-      const double tt = (a - 1.0) * U + 1.0;
-      const double z = tt * tt / a;                                          // :144
-      const double *p = partner_ptr(pv, ip);
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double pk = p[(int64_t)k * pv.cap];
-        thp[k] = pk + z * (th[k] - pk);                                      // :147
-      }
-      logf = log(z) * (double)(D - 1);                                       // :146
-    }
-
-    // ---- acceptance probability (:314-322) ----
-    const double lpp = prior_logpdf<D>(m, thp);
-    double log_accept = -INFINITY;
-    double up[S], rp[S];
-#pragma unroll
-    for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
-    if (lpp > -INFINITY) {
-      Sim<MODEL, D, S>::run(m, thp, gid, c.iter, rp);                        // :315
-      double a = 0.0;
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
-                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
-        const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
-        a += (u[j] - up[j]) / e;                                             // :319
-      }
-      log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
-    }
-
-    // ---- accept / store (:324-329) ----
-    const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, c.iter, 0);
-    const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
-    if (accepted) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
-#pragma unroll
-      for (int j = 0; j < S; ++j) {
-        u[j] = up[j];
-        drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
-        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
-        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
-      }
-    }
-    moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
+    update_particle<MODEL, D, S, PROP>(m, c.iter, c.prop_p0, c.prop_p1, cb, pp, cdf, pv, cidx, li, (uint64_t)(pp.gid0 + li), acc);
   }
   block_reduce_store<NP, kUpdateBlock>(acc, partials + (int64_t)blockIdx.x * NP);
 }
