@@ -186,6 +186,11 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
     const int64_t per_half = update_rows(m, (sh.cap + 1) / 2) + 1, whole = update_rows(m, sh.cap);
     partial_rows_ = 2 * per_half > whole ? 2 * per_half : whole;
     if (partial_rows_ < n_blocks(sh.cap)) partial_rows_ = n_blocks(sh.cap);
+    // (k_update_persistent double-buffers one row per workgroup by the update's parity)
+    for (int prop = 0; prop < 3; ++prop) {
+      const int64_t wg = persistent_workgroups(m, prop, sh.cap);
+      if (2 * wg > partial_rows_) partial_rows_ = 2 * wg;
+    }
     partial_rows_ += 4;
   }
   HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");

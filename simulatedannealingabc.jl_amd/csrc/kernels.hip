@@ -750,7 +750,12 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       target += (unsigned long long)nwg;
       if (!grid_barrier(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
       const int64_t li = pa.half + t;
-      if (li < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc);
+      double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
+      if (li < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
     }
     // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead writes the row of update
     // u + 1 while a slow one still reads those of update u (it cannot get two ahead: the barrier of u + 1 needs everybody)
@@ -1866,16 +1871,22 @@ int64_t update_rows(const ModelDesc &m, int64_t act_n) {
     else hipLaunchKernelGGL((KERNEL), (GRID), block, 0, stream, m, c, cb, pp, cdf, pv, act_lo, act_n, out);      \
   } while (0)
 
-// the persistent form exists for the built-in simulators with one lane per particle; its workgroups must all be resident
-// at once: at most kPersistMaxWorkgroups of them (one per CU)
-constexpr int64_t kPersistMaxWorkgroups = 256;
+// the persistent form exists for the built-in simulators with one lane per particle.  Its workgroups must all be resident at
+// once (<= 256: one per CU), and it pays only while there are FEW of them: every workgroup arrives at one counter and reads
+// every workgroup's row, so a step of the barrier costs ~0.13 us per workgroup (RandomWalk, cfg2, per update: 4 workgroups
+// 17.9 us, 20: 19.9, 40: 22.1, 64: 25.8, 245: 50.6 -- the launch chain is flat at 23.5; DE at 32 workgroups per half
+// batch 38.1 against 41.0, at 64: 47.4 against 41.3).  Default: up to 48 workgroups (SABC_PERSISTENT_WG overrides, <= 256).
+static int64_t persist_max_workgroups() {
+  static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 48; return x < 0 ? 0 : x > 256 ? 256 : x; }();
+  return v;
+}
 int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n) {
   if (!(m.model_id == SABC_MODEL_GAUSS_IID || m.model_id == SABC_MODEL_GAUSS2D || m.model_id == SABC_MODEL_LV)) return 0;
   if (prop_kind < 0 || prop_kind > 2 || act_n < 2) return 0;
   const int64_t B = update_block_threads(m.s);
   const int64_t per_launch = prop_kind == SABC_PROP_RANDOMWALK ? act_n : act_n - act_n / 2;     // the larger half batch
   const int64_t wg = (per_launch + B - 1) / B;
-  return wg <= kPersistMaxWorkgroups ? wg : 0;
+  return wg <= persist_max_workgroups() ? wg : 0;
 }
 
 int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,

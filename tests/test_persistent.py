@@ -1,0 +1,75 @@
+"""Small shards run the population updates of a call in ONE launch (kernels.hip: k_update_persistent): every workgroup keeps
+the control block, the ECDF index and the generator tables in LDS and loops over the updates itself -- body, a grid barrier,
+the sums over all workgroups' rows, the control step on its own copy -- until the resample test fires.  Same Philox streams,
+same per-particle arithmetic, same control step as the launch chain (k_update -> k_reduce_control per update): the same
+accept and resample counts, particles and epsilon to rounding (the rows are summed in another order); and both equal the
+oracle (tests/test_gpu_parity.py runs at sizes that take the persistent form by default)."""
+import numpy as np
+import pytest
+
+from tests.cases import MODELS, SEED, hip_model_prior, hip_proposal
+
+pytestmark = pytest.mark.gpu
+
+
+def run(S, name, alg, prop, n, k, monkeypatch, persistent, calls=1, resample=None):
+    monkeypatch.setenv("SABC_PERSISTENT", "1" if persistent else "0")
+    monkeypatch.setenv("SABC_PERSISTENT_MAX", "65536")
+    monkeypatch.setenv("SABC_PERSISTENT_WG", "256")      # (the default keeps the form to <= 48 workgroups, where it pays)
+    model, prior = hip_model_prior(S, name)
+    d = len(MODELS[name]["prior"])
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED,
+                     algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
+    h.initialize((calls * k + 1) * n)
+    l0 = h.kernel_launches
+    for _ in range(calls):
+        h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=resample or n // 3, checkpoint_history=3)
+    out = dict(zip(("theta", "u", "rho"), h.get_population()), eps=h.eps, counters=dict(h.counters), hist=h.history,
+               launches=h.kernel_launches - l0, sigma=h.proposal_sigma)
+    h.close()
+    return out
+
+
+@pytest.mark.parametrize("name,alg,prop,n", [("gauss1_cfg2", "single_eps", "rw", 1000), ("gauss1_cfg2", "single_eps", "de", 1001),
+                                             ("gauss2_2stats", "multi_eps", "stretch", 5000), ("gauss2d_cfg3", "multi_eps", "rw", 3000),
+                                             ("gauss2d_cfg3", "single_eps", "de", 20_001), ("lv_cfg5", "single_eps", "rw", 700),
+                                             ("gauss1_uniform", "single_eps", "de", 130), ("gauss2_meansd", "multi_eps", "rw", 40_000)])
+def test_one_launch_equals_the_launch_chain(S, gpu, monkeypatch, name, alg, prop, n):
+    k = 14
+    a = run(S, name, alg, prop, n, k, monkeypatch, persistent=False, calls=2)
+    b = run(S, name, alg, prop, n, k, monkeypatch, persistent=True, calls=2)
+    assert a["counters"] == b["counters"] and a["counters"]["n_resampling"] >= 3
+    tol = 1e-10 if prop == "rw" else 1e-6                 # (DE / Stretch compound an ulp by ~(1 + 2 gamma) per update)
+    for key in ("theta", "u", "rho", "eps", "sigma"):
+        np.testing.assert_allclose(b[key], a[key], rtol=tol, atol=tol * 1e-2)
+    for x, y in zip(a["hist"], b["hist"]):
+        assert x.shape == y.shape
+        np.testing.assert_allclose(y, x, rtol=tol)
+    # the chain launches >= 2 kernels per update; the persistent form one per stretch between two resamples
+    resamples = a["counters"]["n_resampling"] - 1
+    assert a["launches"] >= 2 * 2 * k
+    assert b["launches"] <= 2 * (resamples + 1) + 8 * resamples + 12, (b["launches"], resamples)
+
+
+def test_one_launch_stops_where_the_host_has_to_act(S, gpu, monkeypatch):
+    """A resample threshold that fires after EVERY update: each launch does exactly one update, the host resamples, the next
+    launch continues -- the same run as the chain; and a threshold that never fires: the whole call is one launch."""
+    name, n, k = "gauss1_cfg2", 2000, 9
+    a = run(S, name, "single_eps", "rw", n, k, monkeypatch, persistent=False, resample=1)
+    b = run(S, name, "single_eps", "rw", n, k, monkeypatch, persistent=True, resample=1)
+    assert a["counters"] == b["counters"] and b["counters"]["n_resampling"] == 1 + k
+    np.testing.assert_allclose(b["theta"], a["theta"], rtol=1e-10)
+    c = run(S, name, "single_eps", "rw", n, k, monkeypatch, persistent=True, resample=10 ** 9)
+    assert c["counters"]["n_resampling"] == 1 and c["launches"] <= 6     # entry statistics + ONE update launch + the last history row
+
+
+def test_large_shards_keep_the_launch_chain(S, gpu, monkeypatch):
+    monkeypatch.delenv("SABC_PERSISTENT", raising=False)
+    monkeypatch.delenv("SABC_PERSISTENT_MAX", raising=False)
+    model, prior = hip_model_prior(S, "gauss1_cfg2")
+    h = S.SabcHandle(n_particles=300_000, model=model, prior=prior, seed=SEED)
+    h.initialize(300_000)
+    l0 = h.kernel_launches
+    h.update(n_simulation=5 * 300_000, proposal=hip_proposal(S, "rw", 1))
+    assert h.kernel_launches - l0 >= 10
+    h.close()
