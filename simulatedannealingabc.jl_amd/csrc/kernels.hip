@@ -689,9 +689,13 @@ k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, co
 // launched (persistent_workgroups) --; should they not be (a device full of somebody else's persistent kernels) the poll
 // runs into its bound, raises the abort flag for everyone and the call fails with SABC_ERR_HIP instead of hanging.
 // ------------------------------------------------------------------------------------------
+// FENCE: the workgroups also exchange PARTICLES through memory (DifferentialEvolution / StretchMove partners): a release
+// before and an acquire after -- a write-back and an invalidate of the XCD's L2.  The partial rows alone need neither: they are
+// written and read with agent-scope accesses, which go past the caches (a RandomWalk update keeps its L2 contents).
+template <bool FENCE>
 __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const unsigned long long target, const uint64_t ticks, int *stop) {
-  __threadfence();                                     // release: this thread's stores (particles, the partial row)
-  __syncthreads();
+  if (FENCE) __threadfence();                          // release: this thread's stores to the population
+  __syncthreads();                                     // (every wave's stores have been acknowledged: s_waitcnt before s_barrier)
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t t0 = (uint64_t)wall_clock64();
@@ -710,7 +714,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const uns
     *stop = bad;
   }
   __syncthreads();
-  __threadfence();                                     // acquire: what the other workgroups released
+  if (FENCE) __threadfence();                          // acquire: what the other workgroups released
   return *stop == 0;
 }
 
@@ -723,6 +727,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   __shared__ double cidx[S][kCoarse];
   __shared__ double sums[kMaxPartials];
   __shared__ double sm[B];
+  __shared__ double my_row[NP];
   __shared__ int stop;
   __shared__ EpsCandidates cand;
   __shared__ double ubar_s[kMaxStats];
@@ -745,24 +750,27 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
       if (t < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
     } else {
-      if (t < pa.half) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
-      // half batch B reads what half batch A wrote -- in every workgroup (:300-304)
+      if (t < pa.half) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+      // half batch B reads what half batch A wrote -- in every workgroup (:300-304); the particles other workgroups read go past
+      // the caches (update_kernel.hpp: PAST_CACHES), so the barrier needs no fence
       target += (unsigned long long)nwg;
-      if (!grid_barrier(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
+      if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
       const int64_t li = pa.half + t;
       double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
-      if (li < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
+      if (li < pa.act_n) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
     }
     // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead writes the row of update
     // u + 1 while a slow one still reads those of update u (it cannot get two ahead: the barrier of u + 1 needs everybody)
     double *rows = partials + (int64_t)(u & 1) * nwg * NP;
-    block_reduce_store<NP, B>(acc, rows + (int64_t)blockIdx.x * NP);
+    block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out with agent-scope stores, past the caches)
+    __syncthreads();
+    if ((int)threadIdx.x < NP) __hip_atomic_store(rows + (int64_t)blockIdx.x * NP + threadIdx.x, my_row[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     target += (unsigned long long)nwg;
-    if (!grid_barrier(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
+    if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
     // every workgroup: the sum over all rows, thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
     // order -- the same bits in every workgroup
     {
@@ -770,7 +778,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
       double v = 0.0;
       if (g < G)
-        for (int r = g; r < nwg; r += G) v += rows[(int64_t)r * NP + c];
+        for (int r = g; r < nwg; r += G) v += __hip_atomic_load(rows + (int64_t)r * NP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sm[threadIdx.x] = v;
       __syncthreads();
       if ((int)threadIdx.x < NP) {
@@ -1872,12 +1880,13 @@ int64_t update_rows(const ModelDesc &m, int64_t act_n) {
   } while (0)
 
 // the persistent form exists for the built-in simulators with one lane per particle.  Its workgroups must all be resident at
-// once (<= 256: one per CU), and it pays only while there are FEW of them: every workgroup arrives at one counter and reads
-// every workgroup's row, so a step of the barrier costs ~0.13 us per workgroup (RandomWalk, cfg2, per update: 4 workgroups
-// 17.9 us, 20: 19.9, 40: 22.1, 64: 25.8, 245: 50.6 -- the launch chain is flat at 23.5; DE at 32 workgroups per half
-// batch 38.1 against 41.0, at 64: 47.4 against 41.3).  Default: up to 48 workgroups (SABC_PERSISTENT_WG overrides, <= 256).
+// once: at most 256 of them, one per CU (SABC_PERSISTENT_WG lowers that).  Measured against the launch chain, cfg2, us per
+// population update (tools/sweep_small.sh): RandomWalk n = 1000: 16.3 | 22.6, 5000: 17.0 | 23.4, 10 000: 17.7 | 23.5, 16 384:
+// 18.3 | 23.5, 32 768: 19.2 | 23.7, 62 500: 22.0 | 23.8; DifferentialEvolution 1000: 29.9 | 39.5, 16 384: 33.6 | 41.1, 62 500:
+// 38.4 | 41.5.  (A first version fenced every barrier -- a write-back and an invalidate of the L2 per update -- and lost from
+// 64 workgroups on: 25.8 us at n = 16 384, 50.6 at 62 500; what crosses between workgroups now goes past the caches.)
 static int64_t persist_max_workgroups() {
-  static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 48; return x < 0 ? 0 : x > 256 ? 256 : x; }();
+  static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 256; return x < 0 ? 0 : x > 256 ? 256 : x; }();
   return v;
 }
 int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n) {

@@ -114,7 +114,21 @@ __device__ __forceinline__ void load_coarse_index(const CdfPtrs &cdf, double (&c
 // The per-particle body, :308-331, for local particle li (global id gid) at population update `iter`; eps, the Cholesky
 // factor and the pivot come from *cb -- the control block in memory (k_update: scalar loads) or a workgroup's LDS copy of it
 // (k_update_persistent); the particle's moment terms go to acc.
-template <int MODEL, int D, int S, int PROP, class CB>
+// PAST_CACHES (k_update_persistent with DifferentialEvolution / StretchMove): the workgroups of ONE launch read each other's
+// particles update after update, and the per-XCD L2s are not coherent with each other -- partners are read and accepted
+// particles written with agent-scope accesses, which go past the caches, instead of a write-back and an invalidate of the L2
+// at every grid barrier.  (A workgroup's own particles are only ever written by itself: plain loads.)
+template <bool PAST_CACHES>
+__device__ __forceinline__ double particle_load(const double *p) {
+  return PAST_CACHES ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool PAST_CACHES>
+__device__ __forceinline__ void particle_store(double *p, double v) {
+  if (PAST_CACHES) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, class CB>
 __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
                                                 const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
                                                 const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
@@ -157,7 +171,8 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     const double gamma = prop_p0 * (1.0 + prop_p1 * z0);      // :110
     const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
 #pragma unroll
-    for (int k = 0; k < D; ++k) thp[k] = th[k] + gamma * (p1[(int64_t)k * pv.cap] - p2[(int64_t)k * pv.cap]);
+    for (int k = 0; k < D; ++k)
+      thp[k] = th[k] + gamma * (particle_load<PAST_CACHES>(p1 + (int64_t)k * pv.cap) - particle_load<PAST_CACHES>(p2 + (int64_t)k * pv.cap));
   } else {                                       // StretchMove, proposals.jl:137-148
     const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, iter, 0);
     const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
@@ -168,7 +183,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     const double *p = partner_ptr(pv, ip);
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      const double pk = p[(int64_t)k * pv.cap];
+      const double pk = particle_load<PAST_CACHES>(p + (int64_t)k * pv.cap);
       thp[k] = pk + z * (th[k] - pk);                                      // :147
     }
     logf = log(z) * (double)(D - 1);                                       // :146
@@ -198,7 +213,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
   const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
   if (accepted) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = thp[k]; pp.pop[(int64_t)k * pp.cap + li] = thp[k]; }
+    for (int k = 0; k < D; ++k) { th[k] = thp[k]; particle_store<PAST_CACHES>(pp.pop + (int64_t)k * pp.cap + li, thp[k]); }   // (partners read theta)
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       u[j] = up[j];

@@ -15,7 +15,6 @@ pytestmark = pytest.mark.gpu
 def run(S, name, alg, prop, n, k, monkeypatch, persistent, calls=1, resample=None):
     monkeypatch.setenv("SABC_PERSISTENT", "1" if persistent else "0")
     monkeypatch.setenv("SABC_PERSISTENT_MAX", "65536")
-    monkeypatch.setenv("SABC_PERSISTENT_WG", "256")      # (the default keeps the form to <= 48 workgroups, where it pays)
     model, prior = hip_model_prior(S, name)
     d = len(MODELS[name]["prior"])
     h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED,
