@@ -284,7 +284,7 @@ static int compile_only(const char *hip_source, int32_t d, int32_t s, char *log_
   if (!hip_source) { g_err = "null device simulator source"; return SABC_ERR_BAD_CONFIG; }
   std::string log;
   size_t cs = 0;
-  const int rc = rtc_compile(hip_source, d, s, rtc_default_csrc_dir(), nullptr, &log, &cs, user_prior);
+  const int rc = rtc_compile(hip_source, d, s, rtc_default_csrc_dir(), nullptr, &log, &cs, user_prior, /*with_persistent=*/persistent_fits(d, s));
   if (log_out && log_cap > 0) { std::snprintf(log_out, (size_t)log_cap, "%s", log.c_str()); }
   if (rc) { g_err = "compiling the device simulator failed:\n" + log; return SABC_ERR_BAD_CONFIG; }
   return 0;

@@ -187,8 +187,11 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
     partial_rows_ = 2 * per_half > whole ? 2 * per_half : whole;
     if (partial_rows_ < n_blocks(sh.cap)) partial_rows_ = n_blocks(sh.cap);
     // (k_update_persistent double-buffers one row per workgroup by the update's parity)
+    // (a simulator from source is registered after this: sized as if its compiled unit has the form)
+    RtcKernels assume;
+    assume.persistent[0] = assume.persistent[1] = assume.persistent[2] = (hipFunction_t)(uintptr_t)1;
     for (int prop = 0; prop < 3; ++prop) {
-      const int64_t wg = persistent_workgroups(m, prop, sh.cap);
+      const int64_t wg = persistent_workgroups(m, prop, sh.cap, &assume);
       if (2 * wg > partial_rows_) partial_rows_ = 2 * wg;
     }
     partial_rows_ += 4;
@@ -547,7 +550,9 @@ int HipBackend::register_device_simulator(const char *hip_source) {
   if (stream_) HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
   rtc_release(&rtc_);
   std::string log;
-  if (rtc_build(hip_source, m_.d, m_.s, rtc_default_csrc_dir(), &rtc_, &log, m_.prior_joint == 3)) {
+  // (the one-launch form of small shards -- k_update_persistent -- is compiled only for handles that can take it)
+  const bool small = persist_max_ > 0 && sh_.world == 1 && sh_.n_local <= persist_max_ && persistent_fits(m_.d, m_.s);
+  if (rtc_build(hip_source, m_.d, m_.s, rtc_default_csrc_dir(), &rtc_, &log, m_.prior_joint == 3, small)) {
     err_ = "compiling the device simulator failed:\n" + log;
     return -1;
   }
@@ -628,11 +633,12 @@ int HipBackend::update_range(const StepArgs &c, const PartnerView &pv, int64_t l
   return 0;
 }
 
-// Small shards: the updates of a call in one launch (kernels.hip: k_update_persistent).  Not under a profile level that
-// wants every kernel bracketed (the launch chain is what such a run measures), not for run-time compiled simulators.
+// Small shards: the updates of a call in one launch (persistent_kernel.hpp: k_update_persistent; for a simulator from source
+// the run-time compiled instantiation).  Not under a profile level that wants every kernel bracketed (the launch chain is
+// what such a run measures).
 bool HipBackend::persistent_supported(int prop_kind) const {
-  if (persist_max_ <= 0 || sh_.world != 1 || sh_.n_local > persist_max_ || prof_ >= 2 || rtc()) return false;
-  const int64_t wg = persistent_workgroups(m_, prop_kind, sh_.n_local);
+  if (persist_max_ <= 0 || sh_.world != 1 || sh_.n_local > persist_max_ || prof_ >= 2) return false;
+  const int64_t wg = persistent_workgroups(m_, prop_kind, sh_.n_local, rtc());
   return wg > 0 && 2 * wg <= partial_rows_;
 }
 
@@ -653,7 +659,7 @@ int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, co
   pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
   prof_begin(SABC_KERNEL_UPDATE);
   HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, partials_, hist_dev_, mbox_dev_,
-                                     sums_stage_, stream_), "k_update_persistent");
+                                     sums_stage_, stream_, rtc()), "k_update_persistent");
   prof_end(SABC_KERNEL_UPDATE);
   ControlBlock cb;
   if (read_control(&cb)) return -1;

@@ -4,11 +4,18 @@
 // code for the single-lane control kernel (k_control in kernels.hip, so that a population update
 // needs no host round trip) and as plain C++ for the operator entry points and the CPU engine tests.
 #pragma once
+#if !defined(__HIPCC_RTC__)                // (hipRTC: no standard headers, the HIP runtime is pre-included)
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#endif
+#ifndef DBL_EPSILON
+#define DBL_EPSILON 2.2204460492503131e-16
+#endif
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC_RTC__)
+#define SABC_HD __host__ __device__
+#elif defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define SABC_HD __host__ __device__
 #else

@@ -29,6 +29,7 @@ __device__ __forceinline__ void rc_mark(int i) {
 #endif
 #include "control.hpp"
 #include "p2p.hpp"
+#include "persistent_kernel.hpp"
 #include "update_kernel.hpp"
 
 namespace sabc {
@@ -594,28 +595,6 @@ k_reduce_partials(const double *__restrict__ partials, const int64_t rows, const
   if (threadIdx.x == 0) sums[c] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-// The state hand-over between two population updates (control.hpp), one lane -- on an LDS copy of the control
-// block: the step is a chain of dependent reads and writes of the block, each of which would be a round trip to
-// L2 (~1 us); the workgroup loads the 7 KB block once, lane 0 works on the copy, the workgroup writes it back.
-static_assert(sizeof(ControlBlock) % 8 == 0, "copied as 8-byte words");
-static_assert(kMaxPartials <= 1024, "the reduce-and-control kernels give every component of a row of sums a lane");
-constexpr int kControlWords = (int)(sizeof(ControlBlock) / 8);
-
-// the workgroup's loads of the block; the caller puts a barrier between this and control_on_copy()
-__device__ __forceinline__ void control_load(ControlBlock &lcb, const ControlBlock *cb) {
-  for (int i = threadIdx.x; i < kControlWords; i += blockDim.x)
-    reinterpret_cast<uint64_t *>(&lcb)[i] = reinterpret_cast<const uint64_t *>(cb)[i];
-}
-
-__device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a, const ControlBlock &lcb) {
-  Mailbox *mbox = ring + (a.notify_seq % kMailboxRing);
-  uint64_t w0, w1;
-  mailbox_pack(a.notify_seq, lcb.n_accept, lcb.error, lcb.halt, &w0, &w1);
-  // one 8-byte store each, straight to the host's pinned memory; nothing to order them against (sabc_types.hpp)
-  __hip_atomic_store(const_cast<uint64_t *>(&mbox->w0), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store(const_cast<uint64_t *>(&mbox->w1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, ControlBlock *cb, const ControlArgs &a,
                                                 double *hist, Mailbox *ring, const double *sums, double *stage) {
   // the multi-eps schedule (:100-117): one lane per statistic computes its epsilon from the sums the step is about to take
@@ -666,162 +645,6 @@ k_control(ControlBlock *cb, const ControlArgs a, double *hist, Mailbox *ring, co
   for (int i = threadIdx.x; i < np; i += blockDim.x) sums[i] = sums_in[i];
   __syncthreads();
   control_on_copy(lcb, ran, cb, a, hist, ring, sums, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------
-// Small shards: the population updates of a call in ONE launch.
-//
-// At n <= 62 500 a population update cost 22-25 us whatever n: one wave's 50 serial Philox + Box-Muller
-// pairs (~12 us), the 5.7 us reduce-and-control launch, and the gaps between dependent launches -- at the sizes the
-// reference's documentation works with (n_particles = 1000, 5000: docs/src/usage.md:39-45, example.md:190-198) the launch
-// chain is half of the time.  Here every workgroup keeps the control block, the ECDF coarse index and the generator tables
-// in LDS for the whole call and loops over the updates itself:
-//   body (k_update's own, update_particle) -> partial row -> GRID BARRIER -> every workgroup sums ALL partial rows in the
-//   same fixed order and runs the control step on its own copy (the same numbers everywhere: nothing to broadcast) -> next
-// -- one barrier per update (two for DifferentialEvolution / StretchMove, whose second half batch reads what the first
-// wrote in other workgroups), no launch, no host.  Workgroup 0 appends the history rows and writes the control block back
-// at the end.  The loop stops where the host has to act: the resample test of :340 fires (ControlBlock::halt), or an error.
-// Same Philox streams, same per-particle arithmetic, the same control step: the parity suites are the test.
-//
-// The barrier: an agent-scope release, one atomic increment of a monotone counter, a bounded poll, an agent-scope acquire
-// (the per-XCD L2s are not coherent with each other: what a workgroup on another XCD wrote is visible after its write-back
-// and this one's invalidate).  All workgroups have to be resident at once -- at most one per CU's worth of particles is
-// launched (persistent_workgroups) --; should they not be (a device full of somebody else's persistent kernels) the poll
-// runs into its bound, raises the abort flag for everyone and the call fails with SABC_ERR_HIP instead of hanging.
-// ------------------------------------------------------------------------------------------
-// FENCE: the workgroups also exchange PARTICLES through memory (DifferentialEvolution / StretchMove partners): a release
-// before and an acquire after -- a write-back and an invalidate of the XCD's L2.  The partial rows alone need neither: they are
-// written and read with agent-scope accesses, which go past the caches (a RandomWalk update keeps its L2 contents).
-template <bool FENCE>
-__device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const unsigned long long target, const uint64_t ticks, int *stop) {
-  if (FENCE) __threadfence();                          // release: this thread's stores to the population
-  __syncthreads();                                     // (every wave's stores have been acknowledged: s_waitcnt before s_barrier)
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t t0 = (uint64_t)wall_clock64();
-    int bad = 0;
-    for (uint32_t polls = 1; __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++polls) {
-      if ((polls & 15u) == 0) {
-        if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { bad = 1; break; }
-        if ((uint64_t)wall_clock64() - t0 > ticks) {
-          __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          bad = 1;
-          break;
-        }
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    *stop = bad;
-  }
-  __syncthreads();
-  if (FENCE) __threadfence();                          // acquire: what the other workgroups released
-  return *stop == 0;
-}
-
-template <int MODEL, int D, int S, int PROP>
-__global__ void __launch_bounds__(update_block_threads(S))
-k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, const PopPtrs pp, const CdfPtrs cdf, const PartnerView pv_a,
-                    const PartnerView pv_b, double *__restrict__ partials, double *hist, Mailbox *ring, double *__restrict__ stage) {
-  constexpr int NP = n_partials(D, S), B = update_block_threads(S), kCoarse = cdf_coarse_entries(S);
-  __shared__ ControlBlock lcb;
-  __shared__ double cidx[S][kCoarse];
-  __shared__ double sums[kMaxPartials];
-  __shared__ double sm[B];
-  __shared__ double my_row[NP];
-  __shared__ int stop;
-  __shared__ EpsCandidates cand;
-  __shared__ double ubar_s[kMaxStats];
-  rng_tables_load();
-  load_coarse_index<S>(cdf, cidx);
-  control_load(lcb, cb);
-  if (threadIdx.x == 0) stop = 0;
-  __syncthreads();
-  const int nwg = (int)gridDim.x;
-  const int64_t t = (int64_t)blockIdx.x * B + threadIdx.x;
-  unsigned long long target = 0;
-  int done = 0;
-  bool barrier_failed = __hip_atomic_load(&pa.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;   // (uniform)
-  for (int u = 0; u < pa.count && !barrier_failed; ++u) {
-    const uint64_t iter = pa.iter0 + (uint64_t)u;
-    double acc[NP];
-#pragma unroll
-    for (int q = 0; q < NP; ++q) acc[q] = 0.0;
-    if (PROP == SABC_PROP_RANDOMWALK) {
-      // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
-      if (t < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
-    } else {
-      if (t < pa.half) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
-      // half batch B reads what half batch A wrote -- in every workgroup (:300-304); the particles other workgroups read go past
-      // the caches (update_kernel.hpp: PAST_CACHES), so the barrier needs no fence
-      target += (unsigned long long)nwg;
-      if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
-      const int64_t li = pa.half + t;
-      double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
-#pragma unroll
-      for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
-      if (li < pa.act_n) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
-#pragma unroll
-      for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
-    }
-    // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead writes the row of update
-    // u + 1 while a slow one still reads those of update u (it cannot get two ahead: the barrier of u + 1 needs everybody)
-    double *rows = partials + (int64_t)(u & 1) * nwg * NP;
-    block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out with agent-scope stores, past the caches)
-    __syncthreads();
-    if ((int)threadIdx.x < NP) __hip_atomic_store(rows + (int64_t)blockIdx.x * NP + threadIdx.x, my_row[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    target += (unsigned long long)nwg;
-    if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
-    // every workgroup: the sum over all rows, thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
-    // order -- the same bits in every workgroup
-    {
-      constexpr int G = B / NP;
-      const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
-      double v = 0.0;
-      if (g < G)
-        for (int r = g; r < nwg; r += G) v += __hip_atomic_load(rows + (int64_t)r * NP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sm[threadIdx.x] = v;
-      __syncthreads();
-      if ((int)threadIdx.x < NP) {
-        double a = sm[threadIdx.x];
-        for (int gg = 1; gg < G; ++gg) a += sm[gg * NP + threadIdx.x];
-        sums[threadIdx.x] = a;
-      }
-      __syncthreads();
-    }
-    // the control step (control.hpp) on this workgroup's copy of the control block; the history cadence of engine.cpp
-    ControlArgs a = pa.ctrl;
-    a.notify_seq = 0;
-    if ((pa.phase + pa.ix0 + (int64_t)u) % pa.cph == 0) a.mode |= CTRL_HISTORY;                           // :367
-    for (int q = threadIdx.x; q < NP; q += B) control_take_sum(lcb, a, sums, q);
-    a.mode |= CTRL_KEEP_SUMS;
-    __syncthreads();
-    const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
-    if (multi) {
-      if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = lcb.sums[1 + threadIdx.x] / a.n_global;
-      __syncthreads();
-      if ((int)threadIdx.x < a.s) {
-        const int i = threadIdx.x;
-        cand.ok[i] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), i, &cand.eps[i]) ? 1 : 0;
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) (void)control_step(lcb, a, blockIdx.x == 0 ? hist : nullptr, sums, multi ? &cand : nullptr);
-    __syncthreads();
-    done = u + 1;
-    if (lcb.halt || lcb.error) break;                  // the resample test fired (:340), or the step raised an error: the host's turn
-  }
-  if (blockIdx.x == 0) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      lcb.persist_done = done;
-      if (barrier_failed && lcb.error == 0) { lcb.error = SABC_ERR_HIP; lcb.halt = 1; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kControlWords; i += B)
-      reinterpret_cast<uint64_t *>(cb)[i] = reinterpret_cast<const uint64_t *>(&lcb)[i];
-    if (stage && (int)threadIdx.x < NP) stage[threadIdx.x] = sums[threadIdx.x];
-    if (threadIdx.x == 0 && pa.ctrl.notify_seq != 0) mailbox_post(ring, pa.ctrl, lcb);
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1889,9 +1712,14 @@ static int64_t persist_max_workgroups() {
   static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 256; return x < 0 ? 0 : x > 256 ? 256 : x; }();
   return v;
 }
-int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n) {
-  if (!(m.model_id == SABC_MODEL_GAUSS_IID || m.model_id == SABC_MODEL_GAUSS2D || m.model_id == SABC_MODEL_LV)) return 0;
+int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc) {
   if (prop_kind < 0 || prop_kind > 2 || act_n < 2) return 0;
+  if (m.model_id == SABC_MODEL_USER) {                 // a simulator from source: compiled with it (rtc.cpp), where its shape fits
+    if (!rtc || !rtc->persistent[prop_kind]) return 0;
+  } else if (!(m.model_id == SABC_MODEL_GAUSS_IID || m.model_id == SABC_MODEL_GAUSS2D || m.model_id == SABC_MODEL_LV)) {
+    return 0;
+  }
+  if (!persistent_fits(m.d, m.s)) return 0;
   const int64_t B = update_block_threads(m.s);
   const int64_t per_launch = prop_kind == SABC_PROP_RANDOMWALK ? act_n : act_n - act_n / 2;     // the larger half batch
   const int64_t wg = (per_launch + B - 1) / B;
@@ -1900,10 +1728,13 @@ int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n) 
 
 int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
                              PartnerView pv_a, PartnerView pv_b, double *partials, double *hist, Mailbox *mbox, double *stage,
-                             hipStream_t stream) {
-  const int64_t wg = persistent_workgroups(m, prop_kind, pa.act_n);
+                             hipStream_t stream, const RtcKernels *rtc) {
+  const int64_t wg = persistent_workgroups(m, prop_kind, pa.act_n, rtc);
   if (wg <= 0) return (int)hipErrorInvalidValue;
   const dim3 grid((unsigned)wg), block((unsigned)update_block_threads(m.s));
+  if (m.model_id == SABC_MODEL_USER)
+    return module_launch(rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist,
+                         mbox, stage);
 #define PCALLP(M, D, S, P) hipLaunchKernelGGL((k_update_persistent<M, D, S, P>), grid, block, 0, stream, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage)
 #define PCALL(M, D, S)                                                          \
   switch (prop_kind) {                                                          \

@@ -86,17 +86,6 @@ constexpr int64_t kFuseReduceMaxDoubles = SABC_FUSE_REDUCE_MAX;
 
 inline int64_t n_blocks(int64_t n) { return (n + kBlock - 1) / kBlock; }
 
-#if !defined(__HIPCC_RTC__)
-// K1: theta_i ~ prior, rho_i = f_dist(theta_i)                       SimulatedAnnealingABC.jl:172-179
-int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream, const RtcKernels *rtc = nullptr);
-// K3: u_ij = cdf_j(rho_ij) for the whole shard                        :190-192
-int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
-// K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
-// writes one partial row per block at partials[(row0 + blockIdx) * np]
-// ev0 / ev1: optional timing events carried by the kernel's own dispatch packet
-int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
-                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
-                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const RtcKernels *rtc = nullptr);
 // K4 for SMALL shards, the updates of a call in ONE launch (kernels.hip: k_update_persistent): what one launch is asked to do
 struct PersistArgs {
   uint64_t iter0;                // global index of the launch's first population update (RNG counter word)
@@ -108,11 +97,29 @@ struct PersistArgs {
   unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag; zeroed before the launch
   uint64_t timeout_ticks;        // bound of a wait at the grid barrier (wall clock)
 };
+// does k_update_persistent<.., D, S, ..> fit the 160 KB of LDS of a CU?  (its static LDS: the ECDF coarse index, the generator
+// tables, the block reduction, a copy of the control block, the sums)  Shapes that do not keep the launch chain.
+constexpr bool persistent_fits(int d, int s) {
+  return (long)s * cdf_coarse_entries(s) * 8 + 3072 + (long)(update_block_threads(s) / 64 + 2) * n_partials(d, s) * 8 +
+         (long)update_block_threads(s) * 8 + (long)sizeof(ControlBlock) + (long)kMaxPartials * 8 + 2048 <= 156 * 1024;
+}
+
+#if !defined(__HIPCC_RTC__)
+// K1: theta_i ~ prior, rho_i = f_dist(theta_i)                       SimulatedAnnealingABC.jl:172-179
+int launch_prior_simulate(const ModelDesc &m, PopPtrs pp, hipStream_t stream, const RtcKernels *rtc = nullptr);
+// K3: u_ij = cdf_j(rho_ij) for the whole shard                        :190-192
+int launch_cdf_population(const ModelDesc &m, PopPtrs pp, CdfPtrs cdf, hipStream_t stream);
+// K4: the per-particle body for `act_n` particles starting at local index act_lo;  :308-331
+// writes one partial row per block at partials[(row0 + blockIdx) * np]
+// ev0 / ev1: optional timing events carried by the kernel's own dispatch packet
+int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb, PopPtrs pp, CdfPtrs cdf, PartnerView pv,
+                  int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
+                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const RtcKernels *rtc = nullptr);
 // workgroups of the launch (all of them have to be resident at once) or 0 when this model / shape has no persistent form
-int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n);
+int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc = nullptr);
 int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
                              PartnerView pv_a, PartnerView pv_b, double *partials, double *hist, Mailbox *mbox, double *stage,
-                             hipStream_t stream);
+                             hipStream_t stream, const RtcKernels *rtc = nullptr);
 // number of partial rows launch_update() writes for act_n particles (depends on the kernel's granularity)
 int64_t update_rows(const ModelDesc &m, int64_t act_n);
 // moment sums of the current shard (no update): same partial layout, n_accept = 0

@@ -64,7 +64,7 @@ void anchor() {}
 // sabc() call makes one) loads the module without paying the ~2 s of compilation again
 struct CachedModule {
   std::vector<char> code;
-  std::string lowered[7];
+  std::string lowered[10];
 };
 std::mutex g_cache_mutex;
 std::map<std::string, CachedModule> g_cache;
@@ -87,14 +87,15 @@ void rtc_release(RtcKernels *k) {
 }
 
 int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-              bool user_prior) {
-  return rtc_compile(user_source, d, s, csrc_dir, out, log, nullptr, user_prior);
+              bool user_prior, bool with_persistent) {
+  return rtc_compile(user_source, d, s, csrc_dir, out, log, nullptr, user_prior, with_persistent);
 }
 
 // out == nullptr: compile only (needs no device); code_size (optional) receives the size of the code object
 int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-                size_t *code_size, bool user_prior) {
-  constexpr int kKernels = 7;
+                size_t *code_size, bool user_prior, bool with_persistent) {
+  constexpr int kMaxKernels = 10;
+  const int kKernels = with_persistent ? 10 : 7;
   HiprtcApi *api = hiprtc_api();
   if (!api) { *log = "libhiprtc.so could not be loaded: simulators from source need the hipRTC of ROCm"; return -1; }
   if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_SOURCE_STATS) { *log = "n_para / n_stats out of range (a simulator from source: d <= 16, s <= 16)"; return -1; }
@@ -110,21 +111,22 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
                 "  }\n"
                 "};\n"
                 "}  // namespace sabc\n");
-  std::string src = "#include \"update_kernel.hpp\"\n#line 1 \"f_dist.hip\"\n";
+  std::string src = std::string("#include \"update_kernel.hpp\"\n") + (with_persistent ? "#include \"persistent_kernel.hpp\"\n" : "") + "#line 1 \"f_dist.hip\"\n";
   src += user_source;
   src += tail;
 
-  char name[8][96];   // kKernels <= 8
+  char name[10][112];   // kKernels <= 10
   std::snprintf(name[0], sizeof(name[0]), "sabc::k_prior_simulate<%d, %d, %d>", SABC_MODEL_USER, d, s);
   for (int p = 0; p < 3; ++p) std::snprintf(name[1 + p], sizeof(name[1 + p]), "sabc::k_update<%d, %d, %d, %d>", SABC_MODEL_USER, d, s, p);
   std::snprintf(name[4], sizeof(name[4]), "sabc::k_simulate_batch<%d, %d, %d>", SABC_MODEL_USER, d, s);
   std::snprintf(name[5], sizeof(name[5]), "sabc::k_stats<%d, %d>", d, s);
   std::snprintf(name[6], sizeof(name[6]), "sabc::k_prior_op_t<%d>", d);
+  for (int p = 0; p < 3; ++p) std::snprintf(name[7 + p], sizeof(name[7 + p]), "sabc::k_update_persistent<%d, %d, %d, %d>", SABC_MODEL_USER, d, s, p);
   // extra compiler flags (e.g. -DSABC_NO_BITOP3: the two-instruction form of the Philox round's three-input XOR)
   const char *extra_env = std::getenv("SABC_RTC_EXTRA_FLAGS");
   const std::string extra = extra_env ? extra_env : "";
 
-  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + "," + extra + "\n" + user_source;
+  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + (with_persistent ? ",1L" : "") + "," + extra + "\n" + user_source;
   if (out) {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto hit = g_cache.find(cache_key);
@@ -132,7 +134,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       RtcKernels k;
       k.d = d; k.s = s;
       if (hipModuleLoadData(&k.module, hit->second.code.data()) != hipSuccess) { *log = "hipModuleLoadData of the cached simulator failed"; return -1; }
-      hipFunction_t *slots[kKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op};
+      hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
+                                        &k.persistent[0], &k.persistent[1], &k.persistent[2]};
       for (int i = 0; i < kKernels; ++i)
         if (hipModuleGetFunction(slots[i], k.module, hit->second.lowered[i].c_str()) != hipSuccess) {
           *log = std::string("kernel not found in the cached module: ") + name[i];
@@ -204,7 +207,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
     api->DestroyProgram(&prog);
     return -1;
   }
-  hipFunction_t *slots[kKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op};
+  hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
+                                        &k.persistent[0], &k.persistent[1], &k.persistent[2]};
   CachedModule entry;
   for (int i = 0; i < kKernels; ++i) {
     const char *lowered = nullptr;

@@ -13,6 +13,7 @@ struct RtcKernels {
   hipFunction_t simulate_batch = nullptr;      // k_simulate_batch<USER, D, S>
   hipFunction_t stats = nullptr;               // k_stats<D, S>
   hipFunction_t prior_op = nullptr;            // k_prior_op_t<D>
+  hipFunction_t persistent[3] = {nullptr, nullptr, nullptr};   // k_update_persistent<USER, D, S, PROP> (persistent_kernel.hpp)
   int d = 0, s = 0;
 };
 
@@ -21,11 +22,13 @@ struct RtcKernels {
 // ) for gfx950 and loads the kernels for (d, s).  `csrc_dir` holds update_kernel.hpp and what it includes.
 // Returns 0 or -1 with the compiler log / error text in `log`.
 // user_prior: the source also defines sabc_user_prior_sample / sabc_user_prior_logpdf (sabc_config::prior_joint = 3).
+// with_persistent: also compile k_update_persistent<USER, D, S, PROP> (small shards: the updates of a call in one launch;
+// it roughly doubles the compile time, so only handles that can take the form ask for it)
 int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-              bool user_prior = false);
+              bool user_prior = false, bool with_persistent = false);
 // the same with out == nullptr stopping after the compiler (no device needed): a syntax / interface check of a source
 int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
-                size_t *code_size, bool user_prior = false);
+                size_t *code_size, bool user_prior = false, bool with_persistent = false);
 void rtc_release(RtcKernels *k);
 // directory of this shared library + "/csrc" (the headers ship next to the library)
 std::string rtc_default_csrc_dir();

@@ -72,3 +72,24 @@ def test_large_shards_keep_the_launch_chain(S, gpu, monkeypatch):
     h.update(n_simulation=5 * 300_000, proposal=hip_proposal(S, "rw", 1))
     assert h.kernel_launches - l0 >= 10
     h.close()
+
+
+def test_a_simulator_from_source_takes_the_one_launch_form_too(S, O, gpu, monkeypatch):
+    """k_update_persistent is compiled with the user's HIP source like k_update is (persistent_kernel.hpp through hipRTC): a
+    model that exists only as source runs its small populations in one launch per stretch, and equals its launch-chain run."""
+    from tests.test_user_simulator import GAUSS_IID_SRC
+    n, k = 3000, 10
+    outs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SABC_PERSISTENT", mode)
+        model = S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, 1.4, 0.0])
+        h = S.SabcHandle(n_particles=n, model=model, prior=S.Normal(0.0, 2.0), seed=SEED)
+        h.initialize((k + 1) * n)
+        l0 = h.kernel_launches
+        h.update(n_simulation=k * n, proposal=hip_proposal(S, "de", 1), resample=n // 2)
+        outs.append(dict(theta=h.get_population()[0], counters=dict(h.counters), eps=h.eps, launches=h.kernel_launches - l0))
+        h.close()
+    a, b = outs
+    assert a["counters"] == b["counters"] and a["counters"]["n_resampling"] >= 2
+    np.testing.assert_allclose(b["theta"], a["theta"], rtol=1e-6, atol=1e-9)
+    assert a["launches"] >= 3 * k and b["launches"] < a["launches"] // 2

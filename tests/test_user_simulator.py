@@ -66,18 +66,13 @@ def test_compiler_errors_are_reported(S):
         S.DeviceSource("// nothing here", 2, 3).compile_check()
 
 
-@pytest.fixture(autouse=True)
-def launch_chain_for_both(monkeypatch):
-    """This module compares kernels compiled from source with the built-in ones BIT FOR BIT.  Small shards of the built-in
-    simulators run their updates in one launch (k_update_persistent), whose sums over the workgroups' rows are taken in
-    another order than the launch chain's -- the same numbers to an ulp, not to the bit; the run-time compiled kernels have
-    no such form.  Both sides take the launch chain here (tests/test_persistent.py compares the two forms)."""
-    monkeypatch.setenv("SABC_PERSISTENT", "0")
-
-
 @pytest.mark.gpu
+@pytest.mark.parametrize("persistent", ["0", "1"])
 @pytest.mark.parametrize("prop", ["rw", "de", "stretch"])
-def test_gauss_iid_from_source_is_bit_identical_to_the_built_in(S, gpu, prop):
+def test_gauss_iid_from_source_is_bit_identical_to_the_built_in(S, gpu, monkeypatch, prop, persistent):
+    """The same kernel templates, compiled at build time for the built-in simulator and at run time for the one from source:
+    the launch chain (k_update) and the one-launch form of small shards (k_update_persistent) alike."""
+    monkeypatch.setenv("SABC_PERSISTENT", persistent)
     n, k, ybar = 20_000, 12, 1.4
     prior = S.Normal(0.0, 2.0)
     runs = []
