@@ -10,9 +10,9 @@ for step in "$@"; do
   case $step in
     p2p) timeout -k 10 600 python -m pytest tests/test_p2p.py -q -m gpu > gpurun_out/${TAG}_p2p.log 2>&1; echo "p2p rc=$?"; tail -3 gpurun_out/${TAG}_p2p.log ;;
     bench1) timeout -k 10 300 python bench.py > gpurun_out/${TAG}_bench1.json 2> gpurun_out/${TAG}_bench1.err; echo "bench1 rc=$?" ;;
-    bench2p2p) timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --p2p on --no-cpu-baseline > gpurun_out/${TAG}_bench2_p2p.json 2> gpurun_out/${TAG}_bench2_p2p.err; echo "bench2 p2p rc=$?" ;;
+    bench2p2p) timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --p2p on > gpurun_out/${TAG}_bench2_p2p.json 2> gpurun_out/${TAG}_bench2_p2p.err; echo "bench2 p2p rc=$?" ;;
     bench2gloo) timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --p2p off --no-cpu-baseline --repeats 2 > gpurun_out/${TAG}_bench2_gloo.json 2> gpurun_out/${TAG}_bench2_gloo.err; echo "bench2 gloo rc=$?" ;;
-    bench2de) timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --p2p on --proposal de --no-cpu-baseline > gpurun_out/${TAG}_bench2_p2p_de.json 2> gpurun_out/${TAG}_bench2_p2p_de.err; echo "bench2 de rc=$?" ;;
+    bench2de) timeout -k 10 300 python bench.py --gpus 2 --dist-backend gloo --p2p on --proposal de > gpurun_out/${TAG}_bench2_p2p_de.json 2> gpurun_out/${TAG}_bench2_p2p_de.err; echo "bench2 de rc=$?" ;;
     ipclegacy) HSA_ENABLE_IPC_MODE_LEGACY=1 timeout -k 10 200 python -m pytest tests/test_p2p.py -q -m gpu -k "over_hip_ipc and rw" > gpurun_out/${TAG}_ipc_legacy1.log 2>&1; echo "ipc legacy=1 rc=$?"; tail -5 gpurun_out/${TAG}_ipc_legacy1.log ;;
     trace2) SABC_BENCH_TRACE=1 timeout -k 10 200 python bench.py --gpus 2 --dist-backend gloo --p2p on --no-cpu-baseline --repeats 2 --steps 20 > gpurun_out/${TAG}_trace2.json 2> gpurun_out/${TAG}_trace2.err; echo "trace2 rc=$?"; grep -v amdgpu.ids gpurun_out/${TAG}_trace2.err | tail -30 ;;
     hosttests) timeout -k 10 600 python -m pytest tests/test_gpu_host_fdist.py tests/test_host_prior.py -q -m gpu -x > gpurun_out/${TAG}_hosttests.log 2>&1; echo "hosttests rc=$?"; tail -5 gpurun_out/${TAG}_hosttests.log ;;
