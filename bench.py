@@ -99,7 +99,7 @@ def load_from_profiles(workload_n, config="cfg2"):
     try:
         import csv
         import subprocess
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             name = f"{tag}_pmc_sq_{config}.csv"
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
