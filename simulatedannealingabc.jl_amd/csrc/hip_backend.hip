@@ -31,9 +31,10 @@ std::atomic<int64_t> g_parked_bytes{0};       // device memory kept because a pe
     if (e_) return check((hipError_t)e_, (what));  \
   } while (0)
 
-static double persist_timeout_ms() {
-  static const double ms = [] { const char *e = std::getenv("SABC_PERSISTENT_TIMEOUT_MS"); const double v = e ? std::atof(e) : 0.0; return v > 0 ? v : 2000.0; }();
-  return ms;
+static double persist_timeout_ms() {                 // (read per launch: tests change it)
+  const char *e = std::getenv("SABC_PERSISTENT_TIMEOUT_MS");
+  const double v = e ? std::atof(e) : 0.0;
+  return v > 0 ? v : 2000.0;
 }
 
 HipBackend::HipBackend(int device) : device_(device) {
@@ -657,6 +658,7 @@ int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, co
   pa.ctrl = ctrl;
   pa.sync = persist_sync_;
   pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
+  if (const char *e = std::getenv("SABC_PERSISTENT_TEST_ABSENT_WG")) pa.test_absent_wg = std::atoi(e);     // (tests/test_persistent.py)
   prof_begin(SABC_KERNEL_UPDATE);
   HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, partials_, hist_dev_, mbox_dev_,
                                      sums_stage_, stream_, rtc()), "k_update_persistent");

@@ -91,7 +91,8 @@ struct PersistArgs {
   uint64_t iter0;                // global index of the launch's first population update (RNG counter word)
   int64_t ix0, phase, cph;       // ... which is update ix0 of the call; update ix appends a history row iff (phase + ix) % cph == 0
   int64_t act_n, half;           // particles of the shard; size of the first half batch (DifferentialEvolution / StretchMove)
-  int32_t count, reserved;       // updates to run (the launch stops early when the resample test fires or an error is raised)
+  int32_t count;                 // updates to run (the launch stops early when the resample test fires or an error is raised)
+  int32_t test_absent_wg;        // test hook: 1 + the index of a workgroup that leaves at once, as if it had never become resident
   double prop_p0, prop_p1;
   ControlArgs ctrl;              // the control step of every update: ACCUMULATE | CHECK | PROPOSAL | EPSILON | PIVOT (history by cadence)
   unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag; zeroed before the launch

@@ -95,6 +95,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   __shared__ int stop;
   __shared__ EpsCandidates cand;
   __shared__ double ubar_s[kMaxStats];
+  if (pa.test_absent_wg != 0 && (int)blockIdx.x == pa.test_absent_wg - 1) return;   // (test hook: this workgroup never arrives)
   rng_tables_load();
   load_coarse_index<S>(cdf, cidx);
   control_load(lcb, cb);

@@ -95,3 +95,36 @@ def test_a_simulator_from_source_takes_the_one_launch_form_too(S, O, gpu, monkey
     assert a["counters"] == b["counters"] and a["counters"]["n_resampling"] >= 2
     np.testing.assert_allclose(b["theta"], a["theta"], rtol=1e-6, atol=1e-9)
     assert b["launches"] < a["launches"] and a["quiet"] >= 3 * k and b["quiet"] <= 6, (a["launches"], b["launches"], a["quiet"], b["quiet"])
+
+
+def test_a_workgroup_that_never_arrives_fails_the_call_within_the_bound(S, gpu, monkeypatch):
+    """The grid barrier's wait is bounded like every wait of this library.  Test hook: workgroup 1 of the launch leaves at once,
+    as if it had never become resident (a device full of somebody else's persistent kernels).  The others run into the bound
+    (50 ms here), raise the abort flag, and the call returns SABC_ERR_HIP -- nothing hangs; the error contract of sabc_update
+    holds (counters, epsilon as at entry; the handle refuses updates until the particles are restored), and after restoring
+    them the same handle repeats the call to exactly the run of a fresh handle."""
+    import time
+    name, n, k = "gauss1_cfg2", 2000, 6                  # 8 workgroups
+    model, prior = hip_model_prior(S, name)
+    h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+    h.initialize((k + 1) * n)
+    before = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.get_population()])
+    monkeypatch.setenv("SABC_PERSISTENT_TIMEOUT_MS", "50")
+    monkeypatch.setenv("SABC_PERSISTENT_TEST_ABSENT_WG", "2")
+    t0 = time.perf_counter()
+    with pytest.raises(S.SABCError, match="grid barrier") as ei:
+        h.update(n_simulation=k * n, proposal=hip_proposal(S, "rw", 1))
+    assert ei.value.code == -21 and time.perf_counter() - t0 < 5.0
+    assert dict(h.counters) == before[0]
+    np.testing.assert_array_equal(h.eps, before[1])
+    with pytest.raises(S.SABCError, match="half-updated"):
+        h.update(n_simulation=n, proposal=hip_proposal(S, "rw", 1))
+    monkeypatch.delenv("SABC_PERSISTENT_TEST_ABSENT_WG")
+    h.set_population(*before[2])
+    h.update(n_simulation=k * n, proposal=hip_proposal(S, "rw", 1))
+    ref = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+    ref.initialize((k + 1) * n)
+    ref.update(n_simulation=k * n, proposal=hip_proposal(S, "rw", 1))
+    assert dict(h.counters) == dict(ref.counters)
+    np.testing.assert_array_equal(h.get_population()[0], ref.get_population()[0])
+    h.close(); ref.close()
