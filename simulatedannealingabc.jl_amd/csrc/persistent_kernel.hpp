@@ -142,8 +142,20 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       constexpr int G = B / NP;
       const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
       double v = 0.0;
-      if (g < G)
-        for (int r = g; r < nwg; r += G) v += __hip_atomic_load(rows + (int64_t)r * NP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g < G) {
+        // eight rows in flight per trip (each load goes to memory: issued one after the other, a thread's rows were as many
+        // dependent round trips -- what made a step of this loop cost ~1 us per 50 workgroups); added in row order
+        for (int r0 = g; r0 < nwg; r0 += 8 * G) {
+          double xx[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = r0 + e * G;
+            xx[e] = r < nwg ? __hip_atomic_load(rows + (int64_t)r * NP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v += xx[e];
+        }
+      }
       sm[threadIdx.x] = v;
       __syncthreads();
       if ((int)threadIdx.x < NP) {
