@@ -610,15 +610,15 @@ def main():
                 out["posterior_vs_cpu"] = {"error": repr(e)}
             gm, gv = float(th.mean()), float(th.var())
             if same:
-              out["posterior_vs_cpu"] = {
-                "expected_equal": args.proposal == "randomwalk",      # (DE / Stretch: the shard-local two-colouring, see n1_equivalent)
-                "shard0_gpu_mean": gm, "shard0_gpu_var": gv, "shard0_cpu_mean": same["shard0_mean"], "shard0_cpu_var": same["shard0_var"],
-                "rel_err_mean": abs(gm / same["shard0_mean"] - 1.0), "rel_err_var": abs(gv / same["shard0_var"] - 1.0),
-                "eps_rel_err": float(np.max(np.abs(state_after_timed[1] / np.array(same["eps"]) - 1.0))),
-                "n_accept_equal": same["n_accept"] == c["n_accept"], "n_resampling_equal": same["n_resampling"] == c["n_resampling"],
-                "updates": same["updates"], "cpu_sims_per_s": cpu["value"], "cpu_cores": cpu["cores"],
-                "note": "same seed, same calls on the CPU restatement (oracle), whole population; moments of shard 0 against the "
-                        "oracle's same slice; the north star asks for moments within 1 %"}
+                out["posterior_vs_cpu"] = {
+                    "expected_equal": args.proposal == "randomwalk",      # (DE / Stretch: the shard-local two-colouring, see n1_equivalent)
+                    "shard0_gpu_mean": gm, "shard0_gpu_var": gv, "shard0_cpu_mean": same["shard0_mean"], "shard0_cpu_var": same["shard0_var"],
+                    "rel_err_mean": abs(gm / same["shard0_mean"] - 1.0), "rel_err_var": abs(gv / same["shard0_var"] - 1.0),
+                    "eps_rel_err": float(np.max(np.abs(state_after_timed[1] / np.array(same["eps"]) - 1.0))),
+                    "n_accept_equal": same["n_accept"] == c["n_accept"], "n_resampling_equal": same["n_resampling"] == c["n_resampling"],
+                    "updates": same["updates"], "cpu_sims_per_s": cpu["value"], "cpu_cores": cpu["cores"],
+                    "note": "same seed, same calls on the CPU restatement (oracle), whole population; moments of shard 0 against the "
+                            "oracle's same slice; the north star asks for moments within 1 %"}
         print(json.dumps(out), flush=True)
     h.close()                         # (no barrier: sabc_destroy leaves the peer-to-peer group in order)
     if world > 1:
