@@ -83,6 +83,8 @@ class HipBackend : public Backend {
   int p2p_init(const P2PDesc *all);                 // maps every peer's slots, populations and rho; switches the transport on
   int p2p_selftest();
   int p2p_leave();                                  // p2p.hpp "LEAVES": leaving -> leave words -> drain -> unmap -> released
+  // the group has agreed that every shard has left and unmapped (p2p_setup.hpp): nothing exported is mapped anywhere
+  void p2p_forget_export() { if (!mapped_) exported_ = false; }
   void p2p_set_destroy_wait(double ms) { destroy_wait_ms_ = ms; }
   void p2p_inject_stale(int n) { p2p_stale_ = n > 0 ? n : 0; }
   static int64_t parked_bytes();

@@ -4,8 +4,8 @@
 // first exchange before falling back), whatever the host language is.
 //
 // A template over the backend so that tests/cpu_engine runs the very same sequence where no GPU exists.  BE needs:
-// p2p_descriptor(P2PDesc *), p2p_init(const P2PDesc *), p2p_selftest(), p2p_disable(), gather_buffer(), to_backend(),
-// to_host(), error().
+// p2p_descriptor(P2PDesc *), p2p_init(const P2PDesc *), p2p_selftest(), p2p_disable(), p2p_forget_export(), gather_buffer(),
+// to_backend(), to_host(), error().
 #pragma once
 #include <cstring>
 #include <string>
@@ -53,6 +53,11 @@ int p2p_setup_sequence(BE *be, Collectives *coll, const Shard &sh, bool host_mod
   bool all_ok = false;
   auto stay = [&](const char *step) {              // every shard leaves: whatever it had mapped is unmapped, the peers are told
     be->p2p_disable();
+    // ... and once EVERY shard has (one more agreement, as a barrier: leaving closes the mappings before it returns) nobody
+    // holds a mapping of anybody's memory: what was exported for this set-up can be freed by sabc_destroy without waiting for
+    // acknowledgements that a shard which never got to know its peers' host pages could not even read
+    bool all_left = false;
+    if (p2p_all_agree(be, coll, true, &all_left, note) == 0 && all_left) be->p2p_forget_export();
     *note = std::string("peer-to-peer set-up: ") + step + (why.empty() ? std::string(" failed on another shard") : ": " + why) +
             " -- every shard stays on the collectives";
     return 0;

@@ -460,6 +460,7 @@ class RefBackend : public Backend {
     page_.state.store(kP2PGone, std::memory_order_release);
     return ok;
   }
+  void p2p_forget_export() { if (!mapped_) exported_ = false; }
   void p2p_set_destroy_wait(double ms) { destroy_wait_ms_ = ms; }
   void p2p_set_timeout(double ms) { timeout_ms_ = ms; }
   void p2p_inject_silence(int n) { loss_ = false; if (n >= 0) { skip_ = 0; silent_ = n; } else { skip_ = -n; silent_ = 1; } }

@@ -427,7 +427,11 @@ def test_engine_set_up_in_one_call_with_the_shards_agreeing(S, tmp_path, trouble
             res = dict(ok=ok, note=h.p2p_setup_note, seconds=seconds, theta=th, u=u, rho=rho, eps=h.eps, counters=h.counters,
                        hist=h.history, collective_calls=h.collective_calls - calls0, fallbacks=h.p2p_fallbacks)
             barrier.wait()
+            parked0 = h.p2p_parked_bytes()
+            t0 = time.perf_counter()
             h.close()
+            # a set-up that ended with every shard on the collectives leaves nothing to acknowledge: no wait, nothing parked
+            res.update(close_seconds=time.perf_counter() - t0, parked=h.p2p_parked_bytes() - parked0)
             return res
         except BaseException:
             under.barrier.abort()
@@ -440,6 +444,8 @@ def test_engine_set_up_in_one_call_with_the_shards_agreeing(S, tmp_path, trouble
         assert all(o["collective_calls"] == 0 for o in out)
     else:
         assert all(o["collective_calls"] > k and "stays on the collectives" in o["note"] for o in out), [o["note"] for o in out]
+        assert all(o["close_seconds"] < 1.0 for o in out), [o["close_seconds"] for o in out]
+        assert sum(o["parked"] for o in out) == 0, [o["parked"] for o in out]
         assert all(o["seconds"] < (5.0 if trouble != "silent" else 10 * bound_ms * 1e-3 + 2.0) for o in out), [o["seconds"] for o in out]
     ref = launch(2, str(tmp_path / "ref.npz"), engine="cpu", backend="gloo", case=case, alg=alg, prop=prop, n=n, updates=k, resample=n // 4)
     check(out, ref)
