@@ -213,6 +213,9 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   totals_host_[0] = totals_host_[1] = 0.0;
   HB_CHECK(hipHostGetDevicePointer((void **)&totals_host_dev_, totals_host_, 0), "hipHostGetDevicePointer(totals)");
   HB_CHECK(hipMalloc((void **)&meta_dev_, 2 * kMaxStats * sizeof(int64_t)), "hipMalloc(meta)");
+  int khz = 0;                                          // rate of the constant wall clock every bounded wait counts in
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) == hipSuccess && khz > 0) wall_clock_khz_ = khz;
+  else (void)hipGetLastError();
   return 0;
 }
 
