@@ -3,9 +3,12 @@
 #include "rtc.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -69,6 +72,112 @@ struct CachedModule {
 std::mutex g_cache_mutex;
 std::map<std::string, CachedModule> g_cache;
 
+// ---- the same across processes: code objects on disk ----
+// Compiling a simulator costs 2-5 s (the fused kernels with the user's code inlined, x 3 proposals, + the one-launch form of
+// small shards) -- every sabc() of every process paid it again.  The code object and the kernels' lowered names are kept
+// under $SABC_RTC_CACHE_DIR | $XDG_CACHE_HOME/sabc_hip | ~/.cache/sabc_hip, keyed by a hash of EVERYTHING that goes into the
+// compilation: the in-process cache key (shape, flags, the user's source), the text of every header of csrc/ the unit
+// includes (a rebuilt or different library never finds another one's code) and this library's ABI version.
+// SABC_RTC_CACHE=0 switches it off.  A file that does not parse (truncated, foreign) is ignored and overwritten.
+uint64_t fnv1a(const void *data, size_t n, uint64_t h) {
+  const unsigned char *p = static_cast<const unsigned char *>(data);
+  for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+uint64_t headers_hash(const std::string &csrc_dir) {
+  static std::mutex m;
+  static std::map<std::string, uint64_t> memo;
+  std::lock_guard<std::mutex> lock(m);
+  auto hit = memo.find(csrc_dir);
+  if (hit != memo.end()) return hit->second;
+  static const char *files[] = {"update_kernel.hpp", "persistent_kernel.hpp", "device_models.hpp", "device_rng.hpp", "rng_tables.inc",
+                                "kernels.hpp", "control.hpp", "host_math.hpp", "prior_math.hpp", "sabc_types.hpp", "p2p.hpp",
+                                "../../include/sabc_hip.h"};
+  uint64_t h = 14695981039346656037ull;
+  for (const char *f : files) {
+    const std::string path = csrc_dir + "/" + f;
+    FILE *fp = std::fopen(path.c_str(), "rb");
+    h = fnv1a(f, std::strlen(f), h);
+    if (!fp) continue;
+    char buf[1 << 14];
+    size_t k;
+    while ((k = std::fread(buf, 1, sizeof(buf), fp)) > 0) h = fnv1a(buf, k, h);
+    std::fclose(fp);
+  }
+  memo[csrc_dir] = h;
+  return h;
+}
+
+std::string disk_cache_dir() {
+  if (const char *e = std::getenv("SABC_RTC_CACHE")) { if (e[0] == '0') return std::string(); }
+  std::string dir;
+  if (const char *e = std::getenv("SABC_RTC_CACHE_DIR")) dir = e;
+  else if (const char *x = std::getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/sabc_hip";
+  else if (const char *home = std::getenv("HOME")) dir = std::string(home) + "/.cache/sabc_hip";
+  if (dir.empty()) return dir;
+  for (size_t i = 1; i <= dir.size(); ++i)             // mkdir -p
+    if (i == dir.size() || dir[i] == '/') (void)::mkdir(dir.substr(0, i).c_str(), 0700);
+  return dir;
+}
+
+std::string disk_cache_path(const std::string &cache_key, const std::string &csrc_dir) {
+  const std::string dir = disk_cache_dir();
+  if (dir.empty()) return dir;
+  uint64_t h = fnv1a(cache_key.data(), cache_key.size(), 14695981039346656037ull);
+  const uint64_t hh = headers_hash(csrc_dir);
+  const int abi = SABC_ABI_VERSION;
+  h = fnv1a(&hh, sizeof(hh), h);
+  h = fnv1a(&abi, sizeof(abi), h);
+  uint64_t h2 = fnv1a(cache_key.data(), cache_key.size(), 0x9E3779B97F4A7C15ull ^ hh);      // 128 bits in the name
+  char name[64];
+  std::snprintf(name, sizeof(name), "/%016llx%016llx.sabcrtc", (unsigned long long)h, (unsigned long long)h2);
+  return dir + name;
+}
+
+constexpr uint64_t kDiskMagic = 0x5341424352544331ull;   // "SABCRTC1"
+
+bool disk_cache_load(const std::string &path, int n_kernels, CachedModule *out) {
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) return false;
+  bool ok = false;
+  uint64_t head[3] = {0, 0, 0};                        // magic, kernels, code bytes
+  if (std::fread(head, sizeof(head), 1, fp) == 1 && head[0] == kDiskMagic && head[1] == (uint64_t)n_kernels && head[2] > 0 &&
+      head[2] < ((uint64_t)1 << 30)) {
+    ok = true;
+    for (int i = 0; ok && i < n_kernels; ++i) {
+      uint32_t len = 0;
+      ok = std::fread(&len, sizeof(len), 1, fp) == 1 && len > 0 && len < 4096;
+      if (ok) { out->lowered[i].assign(len, '\0'); ok = std::fread(&out->lowered[i][0], 1, len, fp) == len; }
+    }
+    if (ok) { out->code.resize((size_t)head[2]); ok = std::fread(out->code.data(), 1, out->code.size(), fp) == out->code.size(); }
+    uint64_t tail = 0;                                 // the file was written to its end
+    ok = ok && std::fread(&tail, sizeof(tail), 1, fp) == 1 && tail == (kDiskMagic ^ head[2]);
+  }
+  std::fclose(fp);
+  return ok;
+}
+
+void disk_cache_store(const std::string &path, int n_kernels, const CachedModule &m) {
+  char tmp[32];
+  std::snprintf(tmp, sizeof(tmp), ".%d.tmp", (int)getpid());
+  const std::string t = path + tmp;
+  FILE *fp = std::fopen(t.c_str(), "wb");
+  if (!fp) return;
+  const uint64_t head[3] = {kDiskMagic, (uint64_t)n_kernels, (uint64_t)m.code.size()};
+  bool ok = std::fwrite(head, sizeof(head), 1, fp) == 1;
+  for (int i = 0; ok && i < n_kernels; ++i) {
+    const uint32_t len = (uint32_t)m.lowered[i].size();
+    ok = std::fwrite(&len, sizeof(len), 1, fp) == 1 && std::fwrite(m.lowered[i].data(), 1, len, fp) == len;
+  }
+  ok = ok && std::fwrite(m.code.data(), 1, m.code.size(), fp) == m.code.size();
+  const uint64_t tail = kDiskMagic ^ head[2];
+  ok = ok && std::fwrite(&tail, sizeof(tail), 1, fp) == 1;
+  ok = (std::fclose(fp) == 0) && ok;
+  if (ok) ok = std::rename(t.c_str(), path.c_str()) == 0;       // (a reader never sees a partial file)
+  if (!ok) (void)std::remove(t.c_str());
+}
+
 }  // namespace
 
 std::string rtc_default_csrc_dir() {
@@ -126,7 +235,15 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   const char *extra_env = std::getenv("SABC_RTC_EXTRA_FLAGS");
   const std::string extra = extra_env ? extra_env : "";
 
-  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + (with_persistent ? ",1L" : "") + "," + extra + "\n" + user_source;
+  // (the launch geometry the library was built with is part of what is compiled: a variant library must not find another's code)
+#define SABC_RTC_STR2(x) #x
+#define SABC_RTC_STR(x) SABC_RTC_STR2(x)
+  static const char *geometry = SABC_RTC_STR(SABC_UPDATE_BLOCK) "," SABC_RTC_STR(SABC_UPDATE_BLOCK_MS) "," SABC_RTC_STR(SABC_CDF_COARSE) ","
+                                SABC_RTC_STR(SABC_CDF_COARSE_MS) "," SABC_RTC_STR(SABC_UPDATE_MIN_WAVES) "," SABC_RTC_STR(SABC_UPDATE_MIN_WAVES_MS);
+#undef SABC_RTC_STR
+#undef SABC_RTC_STR2
+  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + (with_persistent ? ",1L" : "") + "," + extra + "," +
+                                geometry + "\n" + user_source;
   if (out) {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     auto hit = g_cache.find(cache_key);
@@ -145,6 +262,29 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       if (code_size) *code_size = hit->second.code.size();
       *out = k;
       return 0;
+    }
+  }
+  const std::string disk_path = out ? disk_cache_path(cache_key, csrc_dir) : std::string();
+  if (out && !disk_path.empty()) {
+    CachedModule entry;
+    if (disk_cache_load(disk_path, kKernels, &entry)) {
+      RtcKernels k;
+      k.d = d; k.s = s;
+      bool ok = hipModuleLoadData(&k.module, entry.code.data()) == hipSuccess;
+      hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
+                                           &k.persistent[0], &k.persistent[1], &k.persistent[2]};
+      for (int i = 0; ok && i < kKernels; ++i) ok = hipModuleGetFunction(slots[i], k.module, entry.lowered[i].c_str()) == hipSuccess;
+      if (ok) {
+        if (code_size) *code_size = entry.code.size();
+        {
+          std::lock_guard<std::mutex> lock(g_cache_mutex);
+          g_cache.emplace(cache_key, std::move(entry));
+        }
+        *out = k;
+        return 0;
+      }
+      (void)hipGetLastError();                         // a code object this device does not take: compile afresh, overwrite
+      rtc_release(&k);
     }
   }
   void *prog = nullptr;
@@ -223,6 +363,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   }
   api->DestroyProgram(&prog);
   entry.code = std::move(code);
+  if (!disk_path.empty()) disk_cache_store(disk_path, kKernels, entry);
   {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     g_cache.emplace(cache_key, std::move(entry));

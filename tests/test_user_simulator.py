@@ -5,8 +5,12 @@ reference's "any closure" (SimulatedAnnealingABC.jl:164,175,315) and a device pa
 CPU: the compiler stage alone (hipRTC needs no device).  GPU: the Gaussian i.i.d. simulator registered from source must
 reproduce the compiled-in one BIT FOR BIT (same kernel template, same Philox streams, same reductions), and a simulator
 that exists nowhere else in the repository must agree with the oracle driving the same arithmetic from Python."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from tests.cases import SEED, hip_proposal, oracle_proposal
 
@@ -377,3 +381,48 @@ def test_host_prior_next_to_a_simulator_from_source(S, gpu, prop):
     np.testing.assert_allclose(res.population, ref.population, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(res.ρ, ref.ρ, rtol=1e-9, atol=1e-12)
     assert sum(outside) > 0                              # the gate was exercised: some proposals left the support
+
+
+@pytest.mark.gpu
+def test_compiled_simulators_are_kept_on_disk(S, gpu, tmp_path):
+    """Compiling a simulator costs seconds, and every sabc() of every process paid them again.  The code object is kept under
+    SABC_RTC_CACHE_DIR, keyed by everything that goes into the compilation (shape, flags, the user's source, the text of the
+    headers, the ABI): a second PROCESS creates its handle in a fraction of the time and runs to the same numbers; a file that
+    does not parse is ignored and replaced; SABC_RTC_CACHE=0 compiles every time."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import sabc_amd as S
+from tests.test_user_simulator import GAUSS_IID_SRC
+t0 = time.perf_counter()
+model = S.DeviceSource(GAUSS_IID_SRC + "\n// cache test %s\n", 1, 1, [100, 1.0, 1.4, 0.0])
+h = S.SabcHandle(n_particles=3000, model=model, prior=S.Normal(0.0, 2.0), seed=7)
+create = time.perf_counter() - t0
+h.initialize(4 * 3000)
+h.update(n_simulation=3 * 3000, proposal=S.DifferentialEvolution(n_para=1))
+print(json.dumps(dict(create=create, n_accept=h.counters["n_accept"], mean=float(h.get_population()[0].mean()))))
+''' % (ROOT, tmp_path.name)
+    cache = tmp_path / "rtc_cache"
+
+    def run(**env):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SABC_RTC_CACHE_DIR=str(cache), **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    first = run()
+    files = sorted(cache.glob("*.sabcrtc"))
+    assert len(files) == 1 and files[0].stat().st_size > 10_000
+    second = run()
+    assert (second["n_accept"], second["mean"]) == (first["n_accept"], first["mean"])
+    assert second["create"] < 0.5 * first["create"], (first["create"], second["create"])     # (seconds of compilation against a file read)
+    files[0].write_bytes(files[0].read_bytes()[:1000])                  # a truncated file: ignored, compiled afresh, replaced
+    third = run()
+    assert (third["n_accept"], third["mean"]) == (first["n_accept"], first["mean"]) and third["create"] > 2 * second["create"]
+    assert sorted(cache.glob("*.sabcrtc"))[0].stat().st_size > 10_000
+    off = run(SABC_RTC_CACHE="0")
+    assert off["create"] > 2 * second["create"] and off["n_accept"] == first["n_accept"]
