@@ -495,6 +495,10 @@ def main():
         # timing events (sabc_profile_enable level 1), `launches` of them came back
         real_launches = K if args.proposal == "randomwalk" else 2 * K
         dts = sorted(x["dt"] for x in samples)
+        if h.persistent_launches > 0:
+            # a small shard: the updates of the call ran in ONE launch (k_update_persistent) -- there is no per-update kernel
+            # duration to price against a roofline; the line carries the step time only
+            launches = 0
         avg_launch_s = (kern_ms / launches) * 1e-3 if launches else float("nan")
         sims_per_launch = h.n_local if args.proposal == "randomwalk" else h.n_local / 2
         achieved = bytes_per_sim * sims_per_launch / avg_launch_s / 1e9 if launches else float("nan")
@@ -572,6 +576,7 @@ def main():
             # kernels the library launched / collective calls it issued per population update in the timed region
             # (resamples included), and -- N > 1 -- what the step between two update kernels costs
             "launches_per_update": med["kernel_launches"] / K,
+            "persistent_launches": h.persistent_launches,      # > 0: small shard, the updates of a call in one launch
             "collective_calls_per_update": med["collective_calls"] / K,
             "exchange": exchange,
             "exchange_rccl": exchange_rccl,

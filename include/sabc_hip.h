@@ -371,6 +371,10 @@ SABC_API int64_t sabc_host_syncs(const sabc_handle *h);
    population update at world > 1 the RCCL transport takes k_update + k_reduce_partials + ncclAllReduce + k_control,
    the peer-to-peer transport k_update + ONE launch */
 SABC_API int64_t sabc_kernel_launches(const sabc_handle *h);
+/* launches of the one-launch form of small shards so far (k_update_persistent: one shard of <= 65 536 particles with a
+   device-coded simulator runs the population updates between two resamples in ONE launch; SABC_PERSISTENT=0 switches it
+   off): 0 on a handle that takes the launch chain per update */
+SABC_API int64_t sabc_persistent_launches(const sabc_handle *h);
 SABC_API int64_t sabc_collective_calls(const sabc_handle *h);
 
 #ifdef __cplusplus

@@ -348,6 +348,12 @@ class SabcHandle:
     def collective_calls(self):
         return int(self._L.sabc_collective_calls(self._h))
 
+    @property
+    def persistent_launches(self):
+        """Launches of the one-launch form of small shards (k_update_persistent) so far; 0 = the launch chain per update."""
+        fn = getattr(self._L, "sabc_persistent_launches", None)
+        return int(fn(self._h)) if fn is not None else 0
+
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))
 
