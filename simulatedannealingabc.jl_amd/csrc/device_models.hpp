@@ -7,11 +7,6 @@
 #include "kernels.hpp"
 #include "sabc_types.hpp"
 
-// two simulated pairs per loop trip: independent Philox / Box-Muller chains for the scheduler (k_update<1,1,1,0>: 92 -> 62
-// VGPRs, 246 -> ~240 us at n = 1e6); the sums are still added in draw order
-#ifndef SABC_SIM_UNROLL
-#define SABC_SIM_UNROLL 2
-#endif
 // g-and-k: order statistics at multiples of 16 from block maxima instead of the last four steps of the sort (A/B switch)
 #ifndef SABC_GK_BLOCKMAX
 #define SABC_GK_BLOCKMAX 1
@@ -312,21 +307,18 @@ struct Sim;
 template <int D, int S>
 struct Sim<SABC_MODEL_GAUSS_IID, D, S> {
   static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
-                                             double *rho) {
+                                             double *rho, int coop = 0) {
     const int n_obs = (int)m.p[0];
     const double mu = th[0];
     const double sd = (D >= 2) ? th[1] : m.p[1];
-    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter, coop);
     // x_i = mu + sd z_i: the loop sums z and z^2 only; sum x = n mu + sd sum z, sum x^2 = n mu^2 + 2 mu sd sum z + sd^2 sum z^2
     double sz = 0.0, szz = 0.0;
     const int n_pairs = n_obs >> 1;
-#pragma unroll SABC_SIM_UNROLL
-    for (int k = 0; k < n_pairs; ++k) {
-      double z0, z1;
-      ns.pair(z0, z1);
+    ns.for_pairs(n_pairs, [&](const double z0, const double z1) {
       sz += z0; if (S >= 2) szz = fma(z0, z0, szz);
       sz += z1; if (S >= 2) szz = fma(z1, z1, szz);
-    }
+    });
     if (n_obs & 1) {
       double z0, z1;
       ns.pair(z0, z1);
@@ -342,18 +334,15 @@ struct Sim<SABC_MODEL_GAUSS_IID, D, S> {
 template <int D, int S>
 struct Sim<SABC_MODEL_GAUSS2D, D, S> {
   static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
-                                             double *rho) {
+                                             double *rho, int coop = 0) {
     const int n_obs = (int)m.p[0];
     const double r = m.p[1], c = sqrt(1.0 - r * r);
-    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter, coop);
     // e1 = za, e2 = r za + c zb: the loop sums the raw moments of (za, zb); the correlated ones follow by linearity
     double A = 0, B = 0, AA = 0, BB = 0, AB = 0;
-#pragma unroll SABC_SIM_UNROLL
-    for (int k = 0; k < n_obs; ++k) {
-      double za, zb;
-      ns.pair(za, zb);
+    ns.for_pairs(n_obs, [&](const double za, const double zb) {
       A += za; B += zb; AA = fma(za, za, AA); BB = fma(zb, zb, BB); AB = fma(za, zb, AB);
-    }
+    });
     const double S1 = A, S2 = r * A + c * B;
     const double Q11 = AA, Q22 = r * r * AA + 2.0 * r * c * AB + c * c * BB, Q12 = r * AA + c * AB;
     const double m1 = S1 / n_obs, m2 = S2 / n_obs;
@@ -738,17 +727,14 @@ __device__ __forceinline__ void gk_simulate_rows4(const ModelDesc &m, const doub
 template <int D, int S>
 struct Sim<SABC_MODEL_LV, D, S> {
   static __device__ __forceinline__ void run(const ModelDesc &m, const double *th, uint64_t pid, uint64_t iter,
-                                             double *rho) {
+                                             double *rho, int coop = 0) {
     const int n_steps = (int)m.p[0];
     const double dt = m.p[1], sg = m.p[2];
     double X = m.p[3], Y = m.p[4];
     const double sdt = sg * sqrt(dt);
-    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter);
+    NormalStream ns(m.seed, pid, PURPOSE_SIM, iter, coop);
     double SX = 0, QX = 0, SY = 0, QY = 0;
-#pragma unroll SABC_SIM_UNROLL
-    for (int t = 0; t < n_steps; ++t) {
-      double z1, z2;
-      ns.pair(z1, z2);
+    ns.for_pairs(n_steps, [&](const double z1, const double z2) {
       // dX = (aX - bXY) dt + sigma X sqrt(dt) z1 = X ((a - bY) dt + sigma sqrt(dt) z1): the factored form (14 instead
       // of 21 operations per step), both species from the OLD state
       const double fx = fma(sdt, z1, fma(-th[1], Y, th[0]) * dt);
@@ -756,7 +742,7 @@ struct Sim<SABC_MODEL_LV, D, S> {
       X = fmax(fma(X, fx, X), 0.0);
       Y = fmax(fma(Y, fy, Y), 0.0);
       SX += X; QX += X * X; SY += Y; QY += Y * Y;
-    }
+    });
     const double mX = SX / n_steps, mY = SY / n_steps;
     const double vX = (QX - SX * mX) / (n_steps - 1), vY = (QY - SY * mY) / (n_steps - 1);
     const double st[4] = {mX, sqrt(fmax(vX, 0.0)), mY, sqrt(fmax(vY, 0.0))};

@@ -188,13 +188,7 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
     partial_rows_ = 2 * per_half > whole ? 2 * per_half : whole;
     if (partial_rows_ < n_blocks(sh.cap)) partial_rows_ = n_blocks(sh.cap);
     // (k_update_persistent double-buffers one row per workgroup by the update's parity)
-    // (a simulator from source is registered after this: sized as if its compiled unit has the form)
-    RtcKernels assume;
-    assume.persistent[0] = assume.persistent[1] = assume.persistent[2] = (hipFunction_t)(uintptr_t)1;
-    for (int prop = 0; prop < 3; ++prop) {
-      const int64_t wg = persistent_workgroups(m, prop, sh.cap, &assume);
-      if (2 * wg > partial_rows_) partial_rows_ = 2 * wg;
-    }
+    if (2 * persistent_workgroups_bound(m, sh.cap) > partial_rows_) partial_rows_ = 2 * persistent_workgroups_bound(m, sh.cap);
     partial_rows_ += 4;
   }
   HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");

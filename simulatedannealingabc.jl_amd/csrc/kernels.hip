@@ -1712,30 +1712,78 @@ static int64_t persist_max_workgroups() {
   static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 256; return x < 0 ? 0 : x > 256 ? 256 : x; }();
   return v;
 }
-int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc) {
+// lanes per particle of the persistent form: 4 (a quad shares a particle's generator work: update_kernel.hpp, LANES) while four
+// times the workgroups still fit the launch -- the device is then so empty that the extra waves run on idle SIMDs and a
+// particle's serial chain is what an update waits for --, else 1.  SABC_PERSISTENT_LANES = 1 | 4 overrides (4: where it fits).
+static int persist_lanes_env() {                     // (read at every call: a process may run both forms side by side)
+  const char *e = std::getenv("SABC_PERSISTENT_LANES");
+  const int x = e ? std::atoi(e) : 0;
+  return x == 1 || x == 4 ? x : 0;
+}
+static int64_t persist_lanes4_max_particles() {      // per launch (a half batch for DifferentialEvolution / StretchMove)
+  const char *e = std::getenv("SABC_PERSISTENT_LANES4_MAX");
+  const long long x = e ? std::atoll(e) : 16384;
+  return x < 0 ? 0 : x;
+}
+int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc, int *lanes_out, int *active_out) {
+  const int64_t B = update_block_threads(m.s);
+  if (lanes_out) *lanes_out = 1;
+  if (active_out) *active_out = (int)B;
   if (prop_kind < 0 || prop_kind > 2 || act_n < 2) return 0;
+  bool have4 = true;
   if (m.model_id == SABC_MODEL_USER) {                 // a simulator from source: compiled with it (rtc.cpp), where its shape fits
     if (!rtc || !rtc->persistent[prop_kind]) return 0;
+    have4 = rtc->persistent4[prop_kind] != nullptr;
   } else if (!(m.model_id == SABC_MODEL_GAUSS_IID || m.model_id == SABC_MODEL_GAUSS2D || m.model_id == SABC_MODEL_LV)) {
     return 0;
   }
   if (!persistent_fits(m.d, m.s)) return 0;
-  const int64_t B = update_block_threads(m.s);
   const int64_t per_launch = prop_kind == SABC_PROP_RANDOMWALK ? act_n : act_n - act_n / 2;     // the larger half batch
-  const int64_t wg = (per_launch + B - 1) / B;
-  return wg <= persist_max_workgroups() ? wg : 0;
+  const int64_t thin = B < 256 ? B : 256;              // a wave per SIMD
+  const bool may4 = have4 && persist_lanes_env() != 1 && (persist_lanes_env() == 4 || per_launch <= persist_lanes4_max_particles());
+  // the thinnest spread whose workgroups fit the launch: a quad per particle before a lane per particle, a wave per SIMD before
+  // the whole block
+  const int64_t lanes_try[4] = {4, 4, 1, 1}, active_try[4] = {thin, B, thin, B};
+  for (int i = 0; i < 4; ++i) {
+    if (lanes_try[i] == 4 && !may4) continue;
+    const int64_t wg = (lanes_try[i] * per_launch + active_try[i] - 1) / active_try[i];
+    if (wg > persist_max_workgroups()) continue;
+    if (lanes_out) *lanes_out = (int)lanes_try[i];
+    if (active_out) *active_out = (int)active_try[i];
+    return wg;
+  }
+  return 0;
 }
 
-int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
+#ifdef SABC_PERSIST_TRACE
+extern "C" __attribute__((visibility("default"))) int sabc_debug_persist_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_persist_trace), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
+
+// the most workgroups a persistent launch over a shard of at most `cap` particles can have (sizes the partial rows)
+int64_t persistent_workgroups_bound(const ModelDesc &m, int64_t cap) {
+  if (!persistent_fits(m.d, m.s)) return 0;
+  const int64_t A = update_block_threads(m.s) < 256 ? update_block_threads(m.s) : 256, wg4 = (4 * cap + A - 1) / A;
+  return wg4 < persist_max_workgroups() ? wg4 : persist_max_workgroups();
+}
+
+int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa_in, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
                              PartnerView pv_a, PartnerView pv_b, double *partials, double *hist, Mailbox *mbox, double *stage,
                              hipStream_t stream, const RtcKernels *rtc) {
-  const int64_t wg = persistent_workgroups(m, prop_kind, pa.act_n, rtc);
+  int lanes = 1, active = 0;
+  const int64_t wg = persistent_workgroups(m, prop_kind, pa_in.act_n, rtc, &lanes, &active);
   if (wg <= 0) return (int)hipErrorInvalidValue;
+  PersistArgs pa = pa_in;
+  pa.active = active;
   const dim3 grid((unsigned)wg), block((unsigned)update_block_threads(m.s));
   if (m.model_id == SABC_MODEL_USER)
-    return module_launch(rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist,
-                         mbox, stage);
-#define PCALLP(M, D, S, P) hipLaunchKernelGGL((k_update_persistent<M, D, S, P>), grid, block, 0, stream, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage)
+    return module_launch(lanes == 4 ? rtc->persistent4[prop_kind] : rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa,
+                         cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage);
+#define PCALLL(M, D, S, P, L) hipLaunchKernelGGL((k_update_persistent<M, D, S, P, L>), grid, block, 0, stream, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage)
+#define PCALLP(M, D, S, P)                      \
+  if (lanes == 4) PCALLL(M, D, S, P, 4);        \
+  else PCALLL(M, D, S, P, 1)
 #define PCALL(M, D, S)                                                          \
   switch (prop_kind) {                                                          \
     case SABC_PROP_RANDOMWALK: PCALLP(M, D, S, SABC_PROP_RANDOMWALK); break;     \
@@ -1754,6 +1802,7 @@ int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArg
   }
 #undef PCALL
 #undef PCALLP
+#undef PCALLL
   return SABC_LAUNCH_RC();
 }
 

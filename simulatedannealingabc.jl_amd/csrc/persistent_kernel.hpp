@@ -81,7 +81,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const uns
   return *stop == 0;
 }
 
-template <int MODEL, int D, int S, int PROP>
+// LANES = 4: a particle per QUAD of lanes (update_particle) -- four times the waves, each with a chain of generator blocks a
+// quarter as long; chosen while the device has the idle SIMDs for it (kernels.hip: persistent_lanes).
+template <int MODEL, int D, int S, int PROP, int LANES = 1>
 __global__ void __launch_bounds__(update_block_threads(S))
 k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, const PopPtrs pp, const CdfPtrs cdf, const PartnerView pv_a,
                     const PartnerView pv_b, double *__restrict__ partials, double *hist, Mailbox *ring, double *__restrict__ stage) {
@@ -102,7 +104,11 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   if (threadIdx.x == 0) stop = 0;
   __syncthreads();
   const int nwg = (int)gridDim.x;
-  const int64_t t = (int64_t)blockIdx.x * B + threadIdx.x;
+  // the first pa.active threads of a workgroup carry particles: a 512-thread workgroup (two or more statistics) is two waves
+  // per SIMD of ONE compute unit, each at half the issue rate, while the device has 255 idle ones -- spread thinner (256: a
+  // wave per SIMD) while the workgroups fit the launch; the other waves only take part in the barriers and the sums
+  const bool carries = (int)threadIdx.x < pa.active;
+  const int64_t t = ((int64_t)blockIdx.x * pa.active + threadIdx.x) / LANES;
   unsigned long long target = 0;
   int done = 0;
   bool barrier_failed = __hip_atomic_load(&pa.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;   // (uniform)
@@ -111,11 +117,12 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     double acc[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+    SABC_TRACE(iter, 0);
     if (PROP == SABC_PROP_RANDOMWALK) {
       // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
-      if (t < pa.act_n) update_particle<MODEL, D, S, PROP>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+      if (carries && t < pa.act_n) update_particle<MODEL, D, S, PROP, false, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
     } else {
-      if (t < pa.half) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+      if (carries && t < pa.half) update_particle<MODEL, D, S, PROP, true, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
       // half batch B reads what half batch A wrote -- in every workgroup (:300-304); the particles other workgroups read go past
       // the caches (update_kernel.hpp: PAST_CACHES), so the barrier needs no fence
       target += (unsigned long long)nwg;
@@ -124,18 +131,21 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
-      if (li < pa.act_n) update_particle<MODEL, D, S, PROP, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
+      if (carries && li < pa.act_n) update_particle<MODEL, D, S, PROP, true, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
     }
     // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead writes the row of update
     // u + 1 while a slow one still reads those of update u (it cannot get two ahead: the barrier of u + 1 needs everybody)
     double *rows = partials + (int64_t)(u & 1) * nwg * NP;
+    SABC_TRACE(iter, 1);
     block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out with agent-scope stores, past the caches)
     __syncthreads();
     if ((int)threadIdx.x < NP) __hip_atomic_store(rows + (int64_t)blockIdx.x * NP + threadIdx.x, my_row[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     target += (unsigned long long)nwg;
+    SABC_TRACE(iter, 2);
     if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
+    SABC_TRACE(iter, 3);
     // every workgroup: the sum over all rows, thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
     // order -- the same bits in every workgroup
     {
@@ -165,6 +175,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       }
       __syncthreads();
     }
+    SABC_TRACE(iter, 4);
     // the control step (control.hpp) on this workgroup's copy of the control block; the history cadence of engine.cpp
     ControlArgs a = pa.ctrl;
     a.notify_seq = 0;
@@ -184,6 +195,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     }
     if (threadIdx.x == 0) (void)control_step(lcb, a, blockIdx.x == 0 ? hist : nullptr, sums, multi ? &cand : nullptr);
     __syncthreads();
+    SABC_TRACE(iter, 5);
     done = u + 1;
     if (lcb.halt || lcb.error) break;                  // the resample test fired (:340), or the step raised an error: the host's turn
   }

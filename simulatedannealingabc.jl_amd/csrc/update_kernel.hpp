@@ -111,6 +111,15 @@ __device__ __forceinline__ void load_coarse_index(const CdfPtrs &cdf, double (&c
   for (int q = 0; q < kPasses; ++q) dst[threadIdx.x + q * kUpdateBlock] = tmp[q];
 }
 
+// -DSABC_PERSIST_TRACE (tools/persist_trace.py, a variant library -- not the product): workgroup 0's first lane stamps the
+// phases of a population update (row iter % 64) with the 100 MHz wall clock
+#ifdef SABC_PERSIST_TRACE
+__device__ unsigned long long g_persist_trace[64 * 16];
+#define SABC_TRACE(iter, i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_persist_trace[((iter) & 63) * 16 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define SABC_TRACE(iter, i) do { } while (0)
+#endif
+
 // The per-particle body, :308-331, for local particle li (global id gid) at population update `iter`; eps, the Cholesky
 // factor and the pivot come from *cb -- the control block in memory (k_update: scalar loads) or a workgroup's LDS copy of it
 // (k_update_persistent); the particle's moment terms go to acc.
@@ -128,7 +137,10 @@ __device__ __forceinline__ void particle_store(double *p, double v) {
   else *p = v;
 }
 
-template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, class CB>
+// LANES = 4 (k_update_persistent on an under-filled device): the four lanes of a quad run THIS particle together -- the same
+// loads, the same arithmetic, the same decisions -- and share the generator's work (device_rng.hpp: NormalStream, coop); the
+// quad's first lane alone writes the particle back and reports its moment terms.
+template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, class CB>
 __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
                                                 const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
                                                 const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
@@ -143,11 +155,12 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
 #pragma unroll
   for (int j = 0; j < S; ++j) { u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li]; drho[j] = 0.0; }
 
+  SABC_TRACE(iter, 6);
   // ---- proposal (:311) ----
   double thp[D];
   double logf = 0.0;
   if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
-    NormalStream ns(m.seed, gid, PURPOSE_PROP, iter);
+    NormalStream ns(m.seed, gid, PURPOSE_PROP, iter, LANES == 4 ? 4 : 0);
     double z[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) z[k] = ns.next();
@@ -189,6 +202,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     logf = log(z) * (double)(D - 1);                                       // :146
   }
 
+  SABC_TRACE(iter, 7);
   // ---- acceptance probability (:314-322) ----
   const double lpp = prior_logpdf<D>(m, thp);
   double log_accept = -INFINITY;
@@ -196,7 +210,9 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
 #pragma unroll
   for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
   if (lpp > -INFINITY) {
-    Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);                          // :315
+    if (LANES == 4) Sim<MODEL, D, S>::run(m, thp, gid, iter, rp, 4);       // :315
+    else Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);
+    SABC_TRACE(iter, 8);
     double a = 0.0;
 #pragma unroll
     for (int j = 0; j < S; ++j) {
@@ -208,21 +224,34 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
   }
 
+  SABC_TRACE(iter, 9);
   // ---- accept / store (:324-329) ----
   const u32x4 wa = stream_block(m.seed, gid, PURPOSE_ACCEPT, iter, 0);
   const bool accepted = -0.5 * neg2_log_tab(u52(wa.x, wa.y)) < log_accept;      // log(U) < log alpha, :324
+  const bool writer = LANES == 1 || (threadIdx.x & (LANES - 1)) == 0;
   if (accepted) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) { th[k] = thp[k]; particle_store<PAST_CACHES>(pp.pop + (int64_t)k * pp.cap + li, thp[k]); }   // (partners read theta)
+    for (int j = 0; j < S; ++j) drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      u[j] = up[j];
-      drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
-      pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
-      pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+    for (int k = 0; k < D; ++k) th[k] = thp[k];
+#pragma unroll
+    for (int j = 0; j < S; ++j) u[j] = up[j];
+    if (writer) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) particle_store<PAST_CACHES>(pp.pop + (int64_t)k * pp.cap + li, thp[k]);   // (partners read theta)
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
+        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+      }
     }
   }
+  SABC_TRACE(iter, 10);
   moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
+  if (!writer) {
+#pragma unroll
+    for (int q = 0; q < n_partials(D, S); ++q) acc[q] = 0.0;
+  }
 }
 
 template <int MODEL, int D, int S, int PROP>
