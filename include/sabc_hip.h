@@ -194,8 +194,13 @@ SABC_API int64_t     sabc_host_callback_calls(const sabc_handle *h);
        __device__ void sabc_user_simulate(const double *theta,        // the d parameters
                                           const double *params,       // sabc_config::model_params
                                           sabc::NormalStream &rng,    // rng.next() / rng.pair(z0, z1): N(0,1) draws;
-                                                                      // rng.uniform_pair(u0, u1): U(0,1) draws
+                                                                      // rng.uniform_pair(u0, u1): U(0,1) draws;
+                                                                      // rng.for_pairs(n, [&](double z0, double z1) {...}):
+                                                                      // the next n pairs, in stream order
                                           double *rho_out);           // the s non-negative distances
+   (a function of its arguments and its draws alone.  for_pairs is the loop to draw the bulk of a simulation with: a small
+   population runs a call's updates in one launch with a QUAD of lanes per particle, which then generate sixteen pairs at a
+   time, four blocks per lane -- csrc/device_rng.hpp; the stream is the same stream however it is drawn.)
    With sabc_config::prior_joint = 3 the same source also defines the PRIOR -- any distribution, evaluated inside the fused
    kernel (SimulatedAnnealingABC.jl:151 takes any Distributions.Distribution):
        __device__ void   sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);
@@ -375,6 +380,11 @@ SABC_API int64_t sabc_kernel_launches(const sabc_handle *h);
    device-coded simulator runs the population updates between two resamples in ONE launch; SABC_PERSISTENT=0 switches it
    off): 0 on a handle that takes the launch chain per update */
 SABC_API int64_t sabc_persistent_launches(const sabc_handle *h);
+/* lanes per particle of the handle's last such launch: 4 while four times the workgroups fit the launch (<= 16 384 particles
+   per launch: the device is so empty that a particle's chain of generator blocks is what an update waits for -- the four
+   lanes of a quad run the particle side by side and share the blocks, same streams), else 1; 0 before the first.
+   SABC_PERSISTENT_LANES = 1 | 4 overrides, SABC_PERSISTENT_LANES4_MAX moves the bound */
+SABC_API int32_t sabc_persistent_lanes(const sabc_handle *h);
 SABC_API int64_t sabc_collective_calls(const sabc_handle *h);
 
 #ifdef __cplusplus

@@ -30,11 +30,15 @@ SABC_HD inline void control_take_sum(ControlBlock &cb, const ControlArgs &a, con
 // returns false when the step was a no-op (guarded and halted): nothing must be posted then
 // `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
 // control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
+// DD, SS: the shape as compile-time constants where the caller has them (k_update_persistent: the offsets into the sums are then
+// constants, the loops straight-line code and the d == 1 branch the only one compiled -- the step is a chain of dependent LDS
+// round trips on one lane, and every address the compiler can resolve is one it can batch); 0: from the arguments
+template <int DD = 0, int SS = 0>
 SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in,
                                  const EpsCandidates *pre = nullptr) {
   if ((a.mode & CTRL_GUARDED) && cb.halt) return false;
   if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
-  const int d = a.d, s = a.s;
+  const int d = DD > 0 ? DD : a.d, s = SS > 0 ? SS : a.s;
   if (!(a.mode & CTRL_KEEP_SUMS))
     for (int q = 0; q < n_partials(d, s); ++q) control_take_sum(cb, a, sums_in, q);
   SABC_CTRL_MARK(9);

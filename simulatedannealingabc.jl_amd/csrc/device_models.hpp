@@ -231,6 +231,91 @@ __device__ __forceinline__ double cdf_apply_3level(const double *__restrict__ T,
   return cdf_interp(T, len, lo, x);
 }
 
+// The S lookups of ONE particle (one per statistic, each into its own table), step by step together: where a wave has the SIMD
+// to itself (k_update_persistent: small shards) a lookup is a chain of ~11 LDS and 2-6 memory round trips that nothing hides,
+// and the S chains are independent -- in flight together they cost one chain, not S.  Every step tests the predicate of
+// cdf_apply_3level: the same ranks, the same u.
+template <int S, int COARSE>
+__device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, const double (&C)[S][COARSE], const double *x, double *u) {
+  const double *T[S], *M[S];
+  double first[S], last[S];
+  int c[S];
+  bool same = true;
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    T[j] = cdf.knots + (int64_t)j * cdf.stride;
+    M[j] = cdf.mid + (int64_t)j * cdf.mid_stride;
+    first[j] = T[j][0];
+    last[j] = T[j][cdf.len[j] - 1];
+    c[j] = 0;
+    same = same && cdf.shift[j] == cdf.shift[0];
+  }
+#pragma unroll
+  for (int step = COARSE >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+    for (int j = 0; j < S; ++j) c[j] += C[j][c[j] + step - 1] < x[j] ? step : 0;
+  }
+  int64_t a[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    c[j] += C[j][c[j]] < x[j] ? 1 : 0;
+    a[j] = c[j] > 0 ? (int64_t)(c[j] - 1) << cdf.shift[j] : 0;       // (c = 0: nothing below x, the steps below are not taken)
+  }
+  if (same) {                                                         // (uniform: the tables of a population have one length)
+    const int sh = cdf.shift[0];
+    if (sh > kCdfLineShift) {
+      int64_t mm[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) mm[j] = a[j] >> kCdfLineShift;
+      for (int step = 1 << (sh - kCdfLineShift) >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) mm[j] += (c[j] > 0 && M[j][mm[j] + step] < x[j]) ? step : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) a[j] = mm[j] << kCdfLineShift;
+#pragma unroll
+      for (int step = 1 << kCdfLineShift >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) a[j] += (c[j] > 0 && T[j][a[j] + step] < x[j]) ? step : 0;
+      }
+    } else {
+      for (int step = 1 << sh >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) a[j] += (c[j] > 0 && T[j][a[j] + step] < x[j]) ? step : 0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      if (c[j] > 0) {
+        if (cdf.shift[j] > kCdfLineShift) {
+          const int64_t m = cdf_advance(M[j], a[j] >> kCdfLineShift, cdf.shift[j] - kCdfLineShift, x[j]);
+          a[j] = cdf_advance(T[j], m << kCdfLineShift, kCdfLineShift, x[j]);
+        } else {
+          a[j] = cdf_advance(T[j], a[j], cdf.shift[j], x[j]);
+        }
+      }
+    }
+  }
+  double k0[S], k1[S];
+  int64_t i0[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    const int64_t lo = c[j] > 0 ? a[j] + 1 : 0;
+    i0[j] = lo > 0 ? lo - 1 : 0;
+    k0[j] = T[j][i0[j]];
+    k1[j] = T[j][i0[j] + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {                                        // cdf_interp, on the knots in hand
+    const double L1 = (double)(cdf.len[j] - 1);
+    const double y0 = (double)i0[j] / L1, y1 = (double)(i0[j] + 1) / L1;
+    const double t = (x[j] - k0[j]) / (k1[j] - k0[j]);
+    const double v = y0 + t * (y1 - y0);
+    u[j] = !(x[j] >= first[j]) ? ((x[j] != x[j]) ? x[j] : 0.0) : (x[j] > last[j] ? 1.0 : v);
+  }
+}
+
 // mid -> line, for callers without the LDS copy of the coarse level (one lookup per lane, g-and-k / host mode)
 __device__ __forceinline__ double cdf_apply_mid(const double *__restrict__ T, int64_t len, const double *__restrict__ M,
                                                 double x) {

@@ -66,6 +66,7 @@ class Backend {
   // last of them the one that halted), halted / error from the control block.  persistent_supported: this backend has such a
   // form for this proposal on its shard (the engine then takes it instead of a launch chain per update).
   virtual bool persistent_supported(int /*prop_kind*/) const { return false; }
+  virtual int persistent_lanes() const { return 0; }   // lanes per particle of the last such launch (1 | 4), 0: none yet
   virtual int update_persistent(const StepArgs &, const ControlArgs &, const PartnerView &, const PartnerView &, int64_t /*ix0*/,
                                 int64_t /*phase*/, int64_t /*cph*/, int64_t /*count*/, int64_t * /*done*/, int * /*halted*/,
                                 int * /*error*/) { return -1; }
@@ -167,6 +168,7 @@ class Engine {
   // how often update() had to wait for the device (one per run-ahead window), for measurement
   int64_t host_syncs() const { return host_syncs_; }
   int64_t persistent_launches() const { return persistent_launches_; }
+  int persistent_lanes() const { return be_->persistent_lanes(); }
   // bytes that landed in this shard's receive buffers through collectives so far (allreduce: the vector; allgather: all
   // blocks; alltoallv: what arrived)
   int64_t comm_bytes() const { return comm_bytes_; }

@@ -656,6 +656,7 @@ int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, co
   pa.sync = persist_sync_;
   pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
   if (const char *e = std::getenv("SABC_PERSISTENT_TEST_ABSENT_WG")) pa.test_absent_wg = std::atoi(e);     // (tests/test_persistent.py)
+  (void)persistent_workgroups(m_, c.prop_kind, pa.act_n, rtc(), &persist_lanes_);
   prof_begin(SABC_KERNEL_UPDATE);
   HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, partials_, hist_dev_, mbox_dev_,
                                      sums_stage_, stream_, rtc()), "k_update_persistent");

@@ -40,6 +40,7 @@ class HipBackend : public Backend {
   int update_range(const StepArgs &c, const PartnerView &pv, int64_t lo, int64_t cnt, int64_t row0,
                    int64_t *rows_out) override;
   bool persistent_supported(int prop_kind) const override;
+  int persistent_lanes() const override { return persist_lanes_; }
   int update_persistent(const StepArgs &c, const ControlArgs &ctrl, const PartnerView &pv_a, const PartnerView &pv_b, int64_t ix0,
                         int64_t phase, int64_t cph, int64_t count, int64_t *done, int *halted, int *error) override;
   int stats(int64_t *rows_out) override;
@@ -231,6 +232,7 @@ class HipBackend : public Backend {
   int64_t launches_ = 0;
   int64_t persist_max_ = 65536;                           // shards up to this many particles run their updates in one launch (0: never)
   unsigned long long *persist_sync_ = nullptr;            // the grid barrier's counter and abort flag
+  int persist_lanes_ = 0;                                 // lanes per particle of the last one-launch update (0: none yet)
   int prof_ = 0, prof_open_ = -1;
   unsigned prof_tick_ = 0;
   struct EvPair { hipEvent_t a, b; };

@@ -120,9 +120,9 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     SABC_TRACE(iter, 0);
     if (PROP == SABC_PROP_RANDOMWALK) {
       // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
-      if (carries && t < pa.act_n) update_particle<MODEL, D, S, PROP, false, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+      if (carries && t < pa.act_n) update_particle<MODEL, D, S, PROP, false, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
     } else {
-      if (carries && t < pa.half) update_particle<MODEL, D, S, PROP, true, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+      if (carries && t < pa.half) update_particle<MODEL, D, S, PROP, true, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
       // half batch B reads what half batch A wrote -- in every workgroup (:300-304); the particles other workgroups read go past
       // the caches (update_kernel.hpp: PAST_CACHES), so the barrier needs no fence
       target += (unsigned long long)nwg;
@@ -131,7 +131,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
-      if (carries && li < pa.act_n) update_particle<MODEL, D, S, PROP, true, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
+      if (carries && li < pa.act_n) update_particle<MODEL, D, S, PROP, true, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
     }
@@ -183,6 +183,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     for (int q = threadIdx.x; q < NP; q += B) control_take_sum(lcb, a, sums, q);
     a.mode |= CTRL_KEEP_SUMS;
     __syncthreads();
+    SABC_TRACE(iter, 11);
     const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
     if (multi) {
       if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = lcb.sums[1 + threadIdx.x] / a.n_global;
@@ -193,7 +194,9 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) (void)control_step(lcb, a, blockIdx.x == 0 ? hist : nullptr, sums, multi ? &cand : nullptr);
+    SABC_TRACE(iter, 12);
+    if (threadIdx.x == 0) (void)control_step<D, S>(lcb, a, blockIdx.x == 0 ? hist : nullptr, sums, multi ? &cand : nullptr);
+    SABC_TRACE(iter, 13);
     __syncthreads();
     SABC_TRACE(iter, 5);
     done = u + 1;

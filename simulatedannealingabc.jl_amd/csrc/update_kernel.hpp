@@ -140,7 +140,9 @@ __device__ __forceinline__ void particle_store(double *p, double v) {
 // LANES = 4 (k_update_persistent on an under-filled device): the four lanes of a quad run THIS particle together -- the same
 // loads, the same arithmetic, the same decisions -- and share the generator's work (device_rng.hpp: NormalStream, coop); the
 // quad's first lane alone writes the particle back and reports its moment terms.
-template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, class CB>
+// LATENCY (k_update_persistent): the wave has its SIMD to itself -- the ECDF lookups of the S statistics step together
+// (device_models.hpp: cdf_apply_3level_lockstep) instead of one after the other.
+template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, bool LATENCY = false, class CB>
 __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
                                                 const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
                                                 const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
@@ -214,10 +216,12 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     else Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);
     SABC_TRACE(iter, 8);
     double a = 0.0;
+    if (LATENCY && S >= 2) cdf_apply_3level_lockstep<S, kCoarse>(cdf, cidx, rp, up);                         // :316
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
-                               cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                                 // :316
+      if (!(LATENCY && S >= 2))
+        up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
+                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                               // :316
       const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
       a += (u[j] - up[j]) / e;                                             // :319
     }

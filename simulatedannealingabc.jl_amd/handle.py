@@ -354,6 +354,12 @@ class SabcHandle:
         fn = getattr(self._L, "sabc_persistent_launches", None)
         return int(fn(self._h)) if fn is not None else 0
 
+    @property
+    def persistent_lanes(self):
+        """Lanes per particle of the last one-launch update: 4 = a quad of lanes runs a particle and shares its generator
+        blocks (<= 16 384 particles per launch), 1 = a lane per particle, 0 = none yet."""
+        return int(self._L.sabc_persistent_lanes(self._h))
+
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))
 

@@ -819,6 +819,7 @@ int64_t sabc_host_syncs(const sabc_handle *h) { return h->eng->host_syncs(); }
 int64_t sabc_collective_calls(const sabc_handle *h) { return h->eng->collective_calls(); }
 int64_t sabc_kernel_launches(const sabc_handle *) { return 0; }
 int64_t sabc_persistent_launches(const sabc_handle *h) { return h->eng->persistent_launches(); }
+int32_t sabc_persistent_lanes(const sabc_handle *h) { return h->eng->persistent_lanes(); }
 
 // the peer-to-peer entry points, over the in-process emulation above (shards = host threads of this process)
 int sabc_comm_p2p_descriptor(sabc_handle *h, void *out) {

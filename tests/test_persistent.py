@@ -28,7 +28,7 @@ def run(S, name, alg, prop, n, k, monkeypatch, persistent, calls=1, resample=Non
     for _ in range(calls):
         h.update(n_simulation=k * n, proposal=hip_proposal(S, prop, d), resample=resample or n // 3, checkpoint_history=3)
     out = dict(zip(("theta", "u", "rho"), h.get_population()), eps=h.eps, counters=dict(h.counters), hist=h.history,
-               launches=h.kernel_launches - l0, sigma=h.proposal_sigma)
+               launches=h.kernel_launches - l0, sigma=h.proposal_sigma, lanes=h.persistent_lanes)
     h.close()
     return out
 
@@ -46,6 +46,10 @@ def test_one_launch_equals_the_launch_chain(S, gpu, monkeypatch, name, alg, prop
     a = run(S, name, alg, prop, n, k, monkeypatch, persistent=False, calls=2)
     b = run(S, name, alg, prop, n, k, monkeypatch, persistent=True, calls=2, lanes=lanes)
     assert a["counters"] == b["counters"] and a["counters"]["n_resampling"] >= 3
+    per_launch = n if prop == "rw" else n - n // 2
+    block = 256 if b["rho"].shape[0] == 1 else 512          # threads of a workgroup (one statistic | more: kernels.hpp)
+    fits4 = -(-4 * per_launch // 256) <= 256 or -(-4 * per_launch // block) <= 256
+    assert a["lanes"] == 0 and b["lanes"] == (4 if lanes == 4 and fits4 else 1), (b["lanes"], per_launch)
     tol = 1e-10 if prop == "rw" else 1e-6                 # (DE / Stretch compound an ulp by ~(1 + 2 gamma) per update)
     for key in ("theta", "u", "rho", "eps", "sigma"):
         np.testing.assert_allclose(b[key], a[key], rtol=tol, atol=tol * 1e-2)
@@ -66,7 +70,7 @@ def test_a_quad_per_particle_is_the_same_run_as_a_lane_per_particle(S, gpu, monk
     differently in each: a 1-ulp difference in 2 % of the particles, as between k_update and either of them)."""
     a = run(S, name, "single_eps", prop, n, 1, monkeypatch, persistent=True, lanes=1, resample=10 ** 9)
     b = run(S, name, "single_eps", prop, n, 1, monkeypatch, persistent=True, lanes=4, resample=10 ** 9)
-    assert a["counters"] == b["counters"] and a["counters"]["n_accept"] > 0
+    assert a["counters"] == b["counters"] and a["counters"]["n_accept"] > 0 and (a["lanes"], b["lanes"]) == (1, 4)
     for key in ("theta", "u", "rho"):
         np.testing.assert_allclose(b[key], a[key], rtol=1e-13, atol=1e-15)
 

@@ -31,6 +31,19 @@ __device__ void sabc_user_simulate(const double *theta, const double *p, sabc::N
 }
 """
 
+# the same simulator drawing its bulk through NormalStream::for_pairs -- the loop the built-in simulators use: the same stream,
+# and where a quad of lanes runs the particle (small shards) sixteen pairs at a time
+GAUSS_IID_FOR_PAIRS_SRC = r"""
+__device__ void sabc_user_simulate(const double *theta, const double *p, sabc::NormalStream &rng, double *rho) {
+  const int n_obs = (int)p[0];
+  const double mu = theta[0], sd = p[1];
+  double sz = 0.0;
+  rng.for_pairs(n_obs >> 1, [&](const double z0, const double z1) { sz += z0; sz += z1; });
+  if (n_obs & 1) { double z0, z1; rng.pair(z0, z1); sz += z0; }
+  rho[0] = fabs(p[2] - (mu + sd * sz / (double)n_obs));
+}
+"""
+
 # a model nothing else in the repository knows: exponential decay observed with noise at 8 times, 2 parameters
 # (amplitude, rate), 2 statistics (mean absolute residual, absolute error of the last point); uses normals AND uniforms
 DECAY_SRC = r"""
@@ -57,6 +70,7 @@ DECAY_OBS = [3.0 * np.exp(-0.7 * 0.5 * k) for k in range(8)]
 
 def test_source_compiles_without_a_device(S):
     assert S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, 1.5, 0.0]).compile_check()
+    assert S.DeviceSource(GAUSS_IID_FOR_PAIRS_SRC, 1, 1, [100, 1.0, 1.5, 0.0]).compile_check()
     assert S.DeviceSource(DECAY_SRC, 2, 2, [0.1] + DECAY_OBS).compile_check()
 
 
@@ -73,14 +87,19 @@ def test_compiler_errors_are_reported(S):
 @pytest.mark.gpu
 @pytest.mark.parametrize("persistent", ["0", "1"])
 @pytest.mark.parametrize("prop", ["rw", "de", "stretch"])
-def test_gauss_iid_from_source_is_bit_identical_to_the_built_in(S, gpu, monkeypatch, prop, persistent):
+@pytest.mark.parametrize("src,n,n_obs", [("pair", 20_000, 100), ("for_pairs", 3000, 100), ("for_pairs", 3000, 75), ("pair", 3000, 75)])
+def test_gauss_iid_from_source_is_bit_identical_to_the_built_in(S, gpu, monkeypatch, prop, persistent, src, n, n_obs):
     """The same kernel templates, compiled at build time for the built-in simulator and at run time for the one from source:
-    the launch chain (k_update) and the one-launch form of small shards (k_update_persistent) alike."""
+    the launch chain (k_update) and the one-launch form of small shards (k_update_persistent) alike -- at n = 3000 with a quad
+    of lanes per particle, where a simulator that draws through for_pairs takes sixteen pairs at a time (37 pairs: two groups
+    of sixteen, a group of four, one pair of a last group, and the odd draw through pair()) and one that loops over pair()
+    a group of four at a time: the same stream either way."""
     monkeypatch.setenv("SABC_PERSISTENT", persistent)
-    n, k, ybar = 20_000, 12, 1.4
+    k, ybar = 12, 1.4
     prior = S.Normal(0.0, 2.0)
     runs = []
-    for model in (S.GaussianIID(n_obs=100, sd=1.0, obs_mean=ybar), S.DeviceSource(GAUSS_IID_SRC, 1, 1, [100, 1.0, ybar, 0.0])):
+    source = GAUSS_IID_SRC if src == "pair" else GAUSS_IID_FOR_PAIRS_SRC
+    for model in (S.GaussianIID(n_obs=n_obs, sd=1.0, obs_mean=ybar), S.DeviceSource(source, 1, 1, [n_obs, 1.0, ybar, 0.0])):
         res = S.sabc(model, prior, n_particles=n, n_simulation=(k + 1) * n, proposal=hip_proposal(S, prop, 1), resample=n // 2, seed=SEED)
         runs.append(res)
     a, b = runs
