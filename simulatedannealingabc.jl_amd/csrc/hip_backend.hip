@@ -105,6 +105,7 @@ HipBackend::~HipBackend() {
   if (totals_host_) (void)hipHostFree(totals_host_);
   rtc_release(&rtc_);
   if (persist_sync_) (void)hipFree(persist_sync_);
+  if (persist_rows_) (void)hipFree(persist_rows_);
   if (slots_) (void)hipFree(slots_);
   if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
   if (snap_pop_) (void)hipFree(snap_pop_);
@@ -656,10 +657,20 @@ int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, co
   pa.sync = persist_sync_;
   pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
   if (const char *e = std::getenv("SABC_PERSISTENT_TEST_ABSENT_WG")) pa.test_absent_wg = std::atoi(e);     // (tests/test_persistent.py)
-  (void)persistent_workgroups(m_, c.prop_kind, pa.act_n, rtc(), &persist_lanes_);
+  const int64_t wg = persistent_workgroups(m_, c.prop_kind, pa.act_n, rtc(), &persist_lanes_);
+  if (wg <= 0) return check(hipErrorInvalidValue, "k_update_persistent: no one-launch form for this shard");
+  // the rows travel as tagged words (two per value, two parities), zeroed before every launch: its tags start at 1
+  const size_t row_bytes = (size_t)np_ * 2 * sizeof(unsigned long long);
+  if (!persist_rows_ || persist_rows_wg_ < wg) {
+    if (persist_rows_) (void)hipFree(persist_rows_);
+    persist_rows_ = nullptr;
+    persist_rows_wg_ = persistent_workgroups_bound(m_, sh_.cap) > wg ? persistent_workgroups_bound(m_, sh_.cap) : wg;
+    HB_CHECK(hipMalloc((void **)&persist_rows_, 2 * (size_t)persist_rows_wg_ * row_bytes), "hipMalloc(partial rows of the one-launch form)");
+  }
+  HB_CHECK(hipMemsetAsync(persist_rows_, 0, 2 * (size_t)wg * row_bytes, stream_), "hipMemset(partial rows of the one-launch form)");
   prof_begin(SABC_KERNEL_UPDATE);
-  HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, partials_, hist_dev_, mbox_dev_,
-                                     sums_stage_, stream_, rtc()), "k_update_persistent");
+  HB_LAUNCH(launch_update_persistent(m_, c.prop_kind, pa, cb_dev_, pop_ptrs(cur_), cdf_ptrs(), pv_a, pv_b, reinterpret_cast<double *>(persist_rows_),
+                                     hist_dev_, mbox_dev_, sums_stage_, stream_, rtc()), "k_update_persistent");
   prof_end(SABC_KERNEL_UPDATE);
   ControlBlock cb;
   if (read_control(&cb)) return -1;

@@ -232,6 +232,8 @@ class HipBackend : public Backend {
   int64_t launches_ = 0;
   int64_t persist_max_ = 65536;                           // shards up to this many particles run their updates in one launch (0: never)
   unsigned long long *persist_sync_ = nullptr;            // the grid barrier's counter and abort flag
+  unsigned long long *persist_rows_ = nullptr;            // the workgroups' partial rows as tagged words, two parities (persistent_kernel.hpp)
+  int64_t persist_rows_wg_ = 0;                           // workgroups it holds rows for
   int persist_lanes_ = 0;                                 // lanes per particle of the last one-launch update (0: none yet)
   int prof_ = 0, prof_open_ = -1;
   unsigned prof_tick_ = 0;

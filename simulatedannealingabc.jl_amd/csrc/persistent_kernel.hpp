@@ -41,8 +41,8 @@ __device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a
 // in LDS for the whole call and loops over the updates itself:
 //   body (k_update's own, update_particle) -> partial row -> GRID BARRIER -> every workgroup sums ALL partial rows in the
 //   same fixed order and runs the control step on its own copy (the same numbers everywhere: nothing to broadcast) -> next
-// -- one barrier per update (two for DifferentialEvolution / StretchMove, whose second half batch reads what the first
-// wrote in other workgroups), no launch, no host.  Workgroup 0 appends the history rows and writes the control block back
+// -- one exchange of rows per update (and a barrier for DifferentialEvolution / StretchMove, whose second half batch reads what
+// the first wrote in other workgroups), no launch, no host.  Workgroup 0 appends the history rows and writes the control block back
 // at the end.  The loop stops where the host has to act: the resample test of :340 fires (ControlBlock::halt), or an error.
 // Same Philox streams, same per-particle arithmetic, the same control step: the parity suites are the test.
 //
@@ -58,7 +58,8 @@ __device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a
 template <bool FENCE>
 __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const unsigned long long target, const uint64_t ticks, int *stop) {
   if (FENCE) __threadfence();                          // release: this thread's stores to the population
-  __syncthreads();                                     // (every wave's stores have been acknowledged: s_waitcnt before s_barrier)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): this wave's stores (past the caches) have been acknowledged
+  __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(&sync[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint64_t t0 = (uint64_t)wall_clock64();
@@ -78,6 +79,82 @@ __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const uns
   }
   __syncthreads();
   if (FENCE) __threadfence();                          // acquire: what the other workgroups released
+  return *stop == 0;
+}
+
+// The workgroups' partial rows, exchanged WITHOUT a barrier: a value travels as two 8-byte words, each a half of the double
+// under the update's tag (the low-latency words of the peer-to-peer transport, p2p.hpp) -- an 8-byte store is atomic, so a
+// word whose tag is the awaited one carries its half; nothing has to be ordered against anything.  A workgroup posts its row
+// and polls everybody's: one trip through the memory instead of store -> counter increment -> counter poll -> load (~1 us
+// of a ~10 us update at n = 1000, and no single word that every workgroup hammers).  The words are zeroed before the launch
+// (tags start at 1), rows are double-buffered by the update's parity exactly as before.  The poll is bounded like the
+// barrier's: on a timeout the abort flag goes up for everyone.
+__device__ __forceinline__ void row_word_post(unsigned long long *w, const double v, const uint32_t tag) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+  __hip_atomic_store(w, t | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(w + 1, t | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every workgroup: the sum over all rows; thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
+// order -- the same bits in every workgroup.  my_row: this workgroup's row (LDS); false: a row never came (abort flag raised)
+template <int NP, int B>
+__device__ __forceinline__ bool exchange_rows(unsigned long long *words, const int nwg, const double *my_row, const uint32_t tag, double *sm,
+                                              double *sums, unsigned long long *sync, const uint64_t ticks, int *stop) {
+  if ((int)threadIdx.x < NP) row_word_post(words + ((int64_t)blockIdx.x * NP + threadIdx.x) * 2, my_row[threadIdx.x], tag);
+  constexpr int G = B / NP;
+  const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
+  double v = 0.0;
+  if (g < G) {
+    const uint64_t t0 = (uint64_t)wall_clock64();
+    // eight rows in flight per trip (each load goes to memory: issued one after the other, a thread's rows were as many
+    // dependent round trips); added in row order
+    for (int r0 = g; r0 < nwg; r0 += 8 * G) {
+      double xx[8];
+      unsigned pending = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { xx[e] = 0.0; if (r0 + e * G < nwg) pending |= 1u << e; }
+      for (uint32_t polls = 1; pending; ++polls) {
+        unsigned long long lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (pending >> e & 1u) {
+            const unsigned long long *w = words + ((int64_t)(r0 + e * G) * NP + c) * 2;
+            lo[e] = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi[e] = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if ((pending >> e & 1u) && (uint32_t)(lo[e] >> 32) == tag && (uint32_t)(hi[e] >> 32) == tag) {
+            xx[e] = __longlong_as_double((long long)((lo[e] & 0xffffffffull) | (hi[e] << 32)));
+            pending &= ~(1u << e);
+          }
+        }
+        if (pending) {
+          if ((polls & 15u) == 0) {
+            if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { *stop = 1; break; }
+            if ((uint64_t)wall_clock64() - t0 > ticks) {
+              __hip_atomic_store(&sync[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              *stop = 1;
+              break;
+            }
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (pending) break;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v += xx[e];
+    }
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  if ((int)threadIdx.x < NP) {
+    double a = sm[threadIdx.x];
+    for (int gg = 1; gg < G; ++gg) a += sm[gg * NP + threadIdx.x];
+    sums[threadIdx.x] = a;
+  }
+  __syncthreads();
   return *stop == 0;
 }
 
@@ -135,46 +212,18 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
 #pragma unroll
       for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
     }
-    // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead writes the row of update
-    // u + 1 while a slow one still reads those of update u (it cannot get two ahead: the barrier of u + 1 needs everybody)
-    double *rows = partials + (int64_t)(u & 1) * nwg * NP;
+    // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead posts the row of update
+    // u + 1 while a slow one still polls those of update u (it cannot get two ahead: the rows of u + 1 need everybody's)
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(partials) + (int64_t)(u & 1) * nwg * NP * 2;
     SABC_TRACE(iter, 1);
-    block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out with agent-scope stores, past the caches)
+    block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out as tagged words, past the caches)
+    // DifferentialEvolution / StretchMove: the rows are also what tells the others that this workgroup's particles of the update
+    // are in memory -- every wave's stores have to be acknowledged before the row is posted (vmcnt(0); stores count there)
+    if (PROP != SABC_PROP_RANDOMWALK) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if ((int)threadIdx.x < NP) __hip_atomic_store(rows + (int64_t)blockIdx.x * NP + threadIdx.x, my_row[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    target += (unsigned long long)nwg;
     SABC_TRACE(iter, 2);
-    if (!grid_barrier<false>(pa.sync, target, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
     SABC_TRACE(iter, 3);
-    // every workgroup: the sum over all rows, thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
-    // order -- the same bits in every workgroup
-    {
-      constexpr int G = B / NP;
-      const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
-      double v = 0.0;
-      if (g < G) {
-        // eight rows in flight per trip (each load goes to memory: issued one after the other, a thread's rows were as many
-        // dependent round trips -- what made a step of this loop cost ~1 us per 50 workgroups); added in row order
-        for (int r0 = g; r0 < nwg; r0 += 8 * G) {
-          double xx[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int r = r0 + e * G;
-            xx[e] = r < nwg ? __hip_atomic_load(rows + (int64_t)r * NP + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v += xx[e];
-        }
-      }
-      sm[threadIdx.x] = v;
-      __syncthreads();
-      if ((int)threadIdx.x < NP) {
-        double a = sm[threadIdx.x];
-        for (int gg = 1; gg < G; ++gg) a += sm[gg * NP + threadIdx.x];
-        sums[threadIdx.x] = a;
-      }
-      __syncthreads();
-    }
+    if (!exchange_rows<NP, B>(rows, nwg, my_row, (uint32_t)u + 1u, sm, sums, pa.sync, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
     SABC_TRACE(iter, 4);
     // the control step (control.hpp) on this workgroup's copy of the control block; the history cadence of engine.cpp
     ControlArgs a = pa.ctrl;

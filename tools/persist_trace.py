@@ -29,7 +29,7 @@ try:
         t = np.array(buf, dtype=np.float64).reshape(64, 16) * 0.01      # us, row = iter % 64
         t = t[np.argsort(t[:, 0])][-30:]                                # the last 30 updates, in time order
         seq = [0, 6, 7, 8, 9, 10, 1, 2, 3, 4, 11, 12, 13, 5]
-        names = ["loads issued", "proposal", "prior+simulate", "ecdf+log alpha", "accept+store", "moments", "reduce+row", "barrier", "row sums",
+        names = ["loads issued", "proposal", "prior+simulate", "ecdf+log alpha", "accept+store", "moments", "reduce", "(post)", "row exchange",
                  "take sums", "multi-eps lanes", "control step", "publish"]
         d = np.diff(t[:, seq], axis=1)
         med = np.median(d, axis=0)
