@@ -256,24 +256,24 @@ __device__ __forceinline__ void box_muller(const u32x4 w, double &z0, double &z1
   z1 = r * sn;
 }
 
-// value of lane (quad base + j) for every lane of the quad: DPP quad_perm broadcast, no LDS
-__device__ __forceinline__ double quad_pick(double v, uint32_t j) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  switch (j & 3u) {
-    case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xF, 0xF, true); break;
-    case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xF, 0xF, true); break;
-    case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xF, 0xF, true); break;
-    default: lo = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xF, 0xF, true); break;
-  }
+// A TEAM of W = 4 or 16 lanes (a quad | a row of the wave) that run one particle side by side: the value lane (team base + J)
+// holds, on every lane of the team -- one DPP move per 32-bit half, no LDS (quad_perm [J, J, J, J] | row_newbcast:J).
+template <int W, int J>
+__device__ __forceinline__ double team_pick_ct(const double v) {
+  static_assert((W == 4 || W == 16) && J >= 0 && J < W, "a quad or a row of 16 lanes");
+  constexpr int ctrl = W == 4 ? J * 0x55 : 0x150 + J;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
-
-template <int J>
-__device__ __forceinline__ double quad_pick_ct(double v) {
-  constexpr int ctrl = J * 0x55;                       // quad_perm [J, J, J, J]
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
+// ... with the lane chosen at run time (uniform over the team): a branch per bit of j
+template <int W, int J0 = 0, int N = W>
+__device__ __forceinline__ double team_pick(const double v, const uint32_t j) {
+  if constexpr (N == 1) {
+    return team_pick_ct<W, J0>(v);
+  } else {
+    return (j & (uint32_t)(N / 2)) ? team_pick<W, J0 + N / 2, N / 2>(v, j) : team_pick<W, J0, N / 2>(v, j);
+  }
 }
 
 // simulated pairs per loop trip of NormalStream::for_pairs with a lane per particle: independent Philox / Box-Muller chains for
@@ -282,76 +282,61 @@ __device__ __forceinline__ double quad_pick_ct(double v) {
 #define SABC_SIM_UNROLL 2
 #endif
 
+template <int... J> struct lane_seq {};
+template <int N, int... J> struct make_lane_seq : make_lane_seq<N - 1, N - 1, J...> {};
+template <int... J> struct make_lane_seq<0, J...> { using type = lane_seq<J...>; };
+
 // Sequential N(0,1) stream of one (particle, purpose, iteration): block k yields normals 2k, 2k+1.
 //
-// coop = 4 (k_update_persistent on small shards, persistent_kernel.hpp): the FOUR lanes of a quad run the same particle --
-// the same code on the same data -- and share the generator: on every fourth request each lane turns ITS block (k + lane & 3)
-// into a pair (the 99 of a simulator's ~105 instructions per pair that are Philox + Box-Muller), and the quad consumes the
-// four pairs in stream order through DPP broadcasts.  The stream a simulator sees is the same stream, pair for pair and bit
-// for bit; a particle's chain of draws is a quarter as long.  (Worth it only while the device is under-filled: per particle
-// the quad issues ~25 % more instructions than one lane.)  All four lanes must make the same requests -- they do: their
-// control flow depends on the particle's data only.
+// coop = 4 | 16 (k_update_persistent on small shards, persistent_kernel.hpp): the lanes of a TEAM -- a quad, or a row of 16 --
+// run the same particle -- the same code on the same data -- and share the generator: each lane turns ITS blocks into pairs
+// (the 99 of a simulator's ~105 instructions per pair that are Philox + Box-Muller), and the team consumes the pairs in stream
+// order through DPP broadcasts.  The stream a simulator sees is the same stream, pair for pair and bit for bit (counter-based:
+// block k is block k whoever computes it); a particle's chain of draws is a quarter | a sixteenth as long.  (Worth it only
+// while the device is under-filled: the team issues more instructions per particle than one lane.)  All lanes of a team must
+// make the same requests -- they do: their control flow depends on the particle's data only.
 //
 // for_pairs(n, f) -- f(z0, z1) for the next n pairs of the stream, in stream order -- is the loop a simulator should draw its
-// bulk with.  A lane per particle: the plain loop over pair(), two trips unrolled.  A quad per particle: SIXTEEN pairs at a
-// time, four blocks per lane side by side (a single block per lane is a chain of ~100 dependent instructions: with one wave on
-// the SIMD its latency, not its issue, is what the quad would wait for), handed out through DPP broadcasts whose lane is a
-// compile-time constant.  pair() / uniform_pair() / next() keep working in either mode, one group of four at a time, the
-// lane picked by a branch on the stream position.
+// bulk with.  A lane per particle: the plain loop over pair(), two trips unrolled.  A team per particle: 4 W pairs at a time,
+// FOUR blocks per lane side by side (a single block per lane is a chain of ~100 dependent instructions: with one wave on the
+// SIMD its latency, not its issue, is what the team would wait for), handed out through DPP broadcasts whose lane is a
+// compile-time constant; the rest -- fewer than 4 W pairs -- in one more group of as many blocks per lane as it takes.  pair() / uniform_pair() / next() keep working in either mode, one
+// group of W at a time, the lane picked by branches on the stream position.
 struct NormalStream {
   uint64_t seed, pid, iter;
   uint32_t purpose, k;
   double spare;
   bool have;
-  int coop;                      // 0: every lane its own stream | 4: the lanes of a quad share one (see above)
-  int buf_block;                 // coop: first block of the group of four this lane holds one block of (-1: none) ...
+  int coop;                      // 0: every lane its own stream | 4, 16: the lanes of a team share one (see above)
+  int buf_block;                 // coop: first block of the group of W this lane holds one block of (-1: none) ...
   bool buf_uniform;              // ... as uniforms (uniform_pair) or as a Box-Muller pair
   double b0, b1;
   __device__ __forceinline__ NormalStream(uint64_t seed_, uint64_t pid_, uint32_t purpose_, uint64_t iter_, int coop_ = 0)
       : seed(seed_), pid(pid_), iter(iter_), purpose(purpose_), k(0), spare(0.0), have(false), coop(coop_), buf_block(-1),
         buf_uniform(false), b0(0.0), b1(0.0) {}
   __device__ __forceinline__ void pair(double &z0, double &z1) {  // consumes one whole block
-    if (coop) { fetch(k++, false, z0, z1); return; }
+    if (coop == 4) { fetch<4>(k++, false, z0, z1); return; }
+    if (coop == 16) { fetch<16>(k++, false, z0, z1); return; }
     box_muller(stream_block(seed, pid, purpose, iter, k++), z0, z1);
   }
   // two U(0,1) draws from one whole block (the 52-bit uniforms the Box-Muller pair would have been made of)
   __device__ __forceinline__ void uniform_pair(double &u0, double &u1) {
-    if (coop) { fetch(k++, true, u0, u1); return; }
+    if (coop == 4) { fetch<4>(k++, true, u0, u1); return; }
+    if (coop == 16) { fetch<16>(k++, true, u0, u1); return; }
     const u32x4 w = stream_block(seed, pid, purpose, iter, k++);
     u0 = u52(w.x, w.y);
     u1 = u52(w.z, w.w);
   }
   template <class F>
   __device__ __forceinline__ void for_pairs(const int n, F &&f) {
-    if (!coop) {
+    if (coop == 4) { for_pairs_team<4>(n, f); return; }
+    if (coop == 16) { for_pairs_team<16>(n, f); return; }
 #pragma unroll SABC_SIM_UNROLL
-      for (int i = 0; i < n; ++i) {
-        double z0, z1;
-        pair(z0, z1);
-        f(z0, z1);
-      }
-      return;
+    for (int i = 0; i < n; ++i) {
+      double z0, z1;
+      pair(z0, z1);
+      f(z0, z1);
     }
-    const uint32_t q = threadIdx.x & 3u;
-    int c = 0;
-    for (; c + 16 <= n; c += 16) {                     // whole groups of sixteen: blocks k + c + 4 a + q, a = 0..3, on lane q
-      double g0[4], g1[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) box_muller(stream_block(seed, pid, purpose, iter, k + (uint32_t)(c + 4 * a) + q), g0[a], g1[a]);
-      hand_out<0>(g0[0], g1[0], f); hand_out<1>(g0[0], g1[0], f); hand_out<2>(g0[0], g1[0], f); hand_out<3>(g0[0], g1[0], f);
-      hand_out<0>(g0[1], g1[1], f); hand_out<1>(g0[1], g1[1], f); hand_out<2>(g0[1], g1[1], f); hand_out<3>(g0[1], g1[1], f);
-      hand_out<0>(g0[2], g1[2], f); hand_out<1>(g0[2], g1[2], f); hand_out<2>(g0[2], g1[2], f); hand_out<3>(g0[2], g1[2], f);
-      hand_out<0>(g0[3], g1[3], f); hand_out<1>(g0[3], g1[3], f); hand_out<2>(g0[3], g1[3], f); hand_out<3>(g0[3], g1[3], f);
-    }
-    for (; c < n; c += 4) {                            // the rest, a group of four at a time
-      double g0, g1;
-      box_muller(stream_block(seed, pid, purpose, iter, k + (uint32_t)c + q), g0, g1);
-      hand_out<0>(g0, g1, f);
-      if (c + 1 < n) hand_out<1>(g0, g1, f);
-      if (c + 2 < n) hand_out<2>(g0, g1, f);
-      if (c + 3 < n) hand_out<3>(g0, g1, f);
-    }
-    k += (uint32_t)n;
   }
   __device__ __forceinline__ double next() {
     if (have) { have = false; return spare; }
@@ -362,24 +347,61 @@ struct NormalStream {
   }
 
  private:
-  template <int J, class F>
-  __device__ __forceinline__ void hand_out(const double g0, const double g1, F &&f) {
-    f(quad_pick_ct<J>(g0), quad_pick_ct<J>(g1));
+  template <int W, class F, int... J>
+  __device__ __forceinline__ void hand_out(const double g0, const double g1, F &f, lane_seq<J...>) {
+    (f(team_pick_ct<W, J>(g0), team_pick_ct<W, J>(g1)), ...);
   }
-  // coop: block kk of the stream, from the lane of the quad that holds it; a group of four blocks is (re)generated -- one block
+  template <int W, class F, int... J>
+  __device__ __forceinline__ void hand_out_first(const int m, const double g0, const double g1, F &f, lane_seq<J...>) {   // the first m < W pairs
+    ((J < m ? f(team_pick_ct<W, J>(g0), team_pick_ct<W, J>(g1)) : (void)0), ...);      // (m = W: all of them)
+  }
+  template <int W, int NB, class F>
+  __device__ __forceinline__ void tail(const int c, const int r, F &f) {      // (NB - 1) W < r <= NB W pairs from block k + c on
+    using lanes = typename make_lane_seq<W>::type;
+    const uint32_t q = threadIdx.x & (uint32_t)(W - 1);
+    double g0[NB], g1[NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a) box_muller(stream_block(seed, pid, purpose, iter, k + (uint32_t)(c + W * a) + q), g0[a], g1[a]);
+#pragma unroll
+    for (int a = 0; a < NB - 1; ++a) hand_out<W>(g0[a], g1[a], f, lanes{});
+    hand_out_first<W>(r - (NB - 1) * W, g0[NB - 1], g1[NB - 1], f, lanes{});
+  }
+  template <int W, class F>
+  __device__ __forceinline__ void for_pairs_team(const int n, F &f) {
+    using lanes = typename make_lane_seq<W>::type;
+    const uint32_t q = threadIdx.x & (uint32_t)(W - 1);
+    int c = 0;
+    for (; c + 4 * W <= n; c += 4 * W) {               // whole groups of 4 W: blocks k + c + W a + q, a = 0..3, on lane q
+      double g0[4], g1[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) box_muller(stream_block(seed, pid, purpose, iter, k + (uint32_t)(c + W * a) + q), g0[a], g1[a]);
+      hand_out<W>(g0[0], g1[0], f, lanes{});
+      hand_out<W>(g0[1], g1[1], f, lanes{});
+      hand_out<W>(g0[2], g1[2], f, lanes{});
+      hand_out<W>(g0[3], g1[3], f, lanes{});
+    }
+    const int r = n - c;                               // the rest, < 4 W pairs: ceil(r / W) blocks per lane, again side by side
+    if (r > 3 * W) tail<W, 4>(c, r, f);
+    else if (r > 2 * W) tail<W, 3>(c, r, f);
+    else if (r > W) tail<W, 2>(c, r, f);
+    else if (r > 0) tail<W, 1>(c, r, f);
+    k += (uint32_t)n;
+  }
+  // coop: block kk of the stream, from the lane of the team that holds it; a group of W blocks is (re)generated -- one block
   // per lane -- when the request leaves the buffered group or asks for the other kind (a simulator that mixes pair() and
   // uniform_pair() inside a group pays a refill for it, the stream it sees is still the stream)
+  template <int W>
   __device__ __forceinline__ void fetch(uint32_t kk, bool uniform, double &x0, double &x1) {
-    const int base = (int)(kk & ~3u);
+    const int base = (int)(kk & ~(uint32_t)(W - 1));
     if (buf_block != base || buf_uniform != uniform) {
-      const u32x4 w = stream_block(seed, pid, purpose, iter, (uint32_t)base + (threadIdx.x & 3u));
+      const u32x4 w = stream_block(seed, pid, purpose, iter, (uint32_t)base + (threadIdx.x & (uint32_t)(W - 1)));
       if (uniform) { b0 = u52(w.x, w.y); b1 = u52(w.z, w.w); }
       else box_muller(w, b0, b1);
       buf_block = base;
       buf_uniform = uniform;
     }
-    x0 = quad_pick(b0, kk);
-    x1 = quad_pick(b1, kk);
+    x0 = team_pick<W>(b0, kk);
+    x1 = team_pick<W>(b1, kk);
   }
 };
 

@@ -1712,17 +1712,18 @@ static int64_t persist_max_workgroups() {
   static const int64_t v = [] { const char *e = std::getenv("SABC_PERSISTENT_WG"); const long long x = e ? std::atoll(e) : 256; return x < 0 ? 0 : x > 256 ? 256 : x; }();
   return v;
 }
-// lanes per particle of the persistent form: 4 (a quad shares a particle's generator work: update_kernel.hpp, LANES) while four
-// times the workgroups still fit the launch -- the device is then so empty that the extra waves run on idle SIMDs and a
-// particle's serial chain is what an update waits for --, else 1.  SABC_PERSISTENT_LANES = 1 | 4 overrides (4: where it fits).
-static int persist_lanes_env() {                     // (read at every call: a process may run both forms side by side)
+// lanes per particle of the persistent form: a TEAM of 16 (a row of the wave) or 4 (a quad) shares a particle's generator work
+// (update_kernel.hpp, LANES) while that many times the workgroups still fit the launch -- the device is then so empty that the
+// extra waves run on idle SIMDs and a particle's serial chain is what an update waits for --, else 1.
+// SABC_PERSISTENT_LANES = 1 | 4 | 16 overrides (a team: where it fits, else the next smaller).
+static int persist_lanes_env() {                     // (read at every call: a process may run the forms side by side)
   const char *e = std::getenv("SABC_PERSISTENT_LANES");
   const int x = e ? std::atoi(e) : 0;
-  return x == 1 || x == 4 ? x : 0;
+  return x == 1 || x == 4 || x == 16 ? x : 0;
 }
-static int64_t persist_lanes4_max_particles() {      // per launch (a half batch for DifferentialEvolution / StretchMove)
-  const char *e = std::getenv("SABC_PERSISTENT_LANES4_MAX");
-  const long long x = e ? std::atoll(e) : 16384;
+static int64_t persist_team_max_particles(int lanes) {   // per launch (a half batch for DifferentialEvolution / StretchMove)
+  const char *e = std::getenv(lanes == 16 ? "SABC_PERSISTENT_LANES16_MAX" : "SABC_PERSISTENT_LANES4_MAX");
+  const long long x = e ? std::atoll(e) : (lanes == 16 ? 2048 : 16384);
   return x < 0 ? 0 : x;
 }
 int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc, int *lanes_out, int *active_out) {
@@ -1730,22 +1731,25 @@ int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, 
   if (lanes_out) *lanes_out = 1;
   if (active_out) *active_out = (int)B;
   if (prop_kind < 0 || prop_kind > 2 || act_n < 2) return 0;
-  bool have4 = true;
+  bool have4 = true, have16 = true;
   if (m.model_id == SABC_MODEL_USER) {                 // a simulator from source: compiled with it (rtc.cpp), where its shape fits
     if (!rtc || !rtc->persistent[prop_kind]) return 0;
     have4 = rtc->persistent4[prop_kind] != nullptr;
+    have16 = rtc->persistent16[prop_kind] != nullptr;
   } else if (!(m.model_id == SABC_MODEL_GAUSS_IID || m.model_id == SABC_MODEL_GAUSS2D || m.model_id == SABC_MODEL_LV)) {
     return 0;
   }
   if (!persistent_fits(m.d, m.s)) return 0;
   const int64_t per_launch = prop_kind == SABC_PROP_RANDOMWALK ? act_n : act_n - act_n / 2;     // the larger half batch
   const int64_t thin = B < 256 ? B : 256;              // a wave per SIMD
-  const bool may4 = have4 && persist_lanes_env() != 1 && (persist_lanes_env() == 4 || per_launch <= persist_lanes4_max_particles());
-  // the thinnest spread whose workgroups fit the launch: a quad per particle before a lane per particle, a wave per SIMD before
+  const int want = persist_lanes_env();
+  const bool may16 = have16 && (want == 16 || (want == 0 && per_launch <= persist_team_max_particles(16)));
+  const bool may4 = have4 && (want == 4 || want == 16 || (want == 0 && per_launch <= persist_team_max_particles(4)));
+  // the thinnest spread whose workgroups fit the launch: a row per particle before a quad before a lane, a wave per SIMD before
   // the whole block
-  const int64_t lanes_try[4] = {4, 4, 1, 1}, active_try[4] = {thin, B, thin, B};
-  for (int i = 0; i < 4; ++i) {
-    if (lanes_try[i] == 4 && !may4) continue;
+  const int64_t lanes_try[6] = {16, 16, 4, 4, 1, 1}, active_try[6] = {thin, B, thin, B, thin, B};
+  for (int i = 0; i < 6; ++i) {
+    if ((lanes_try[i] == 16 && !may16) || (lanes_try[i] == 4 && !may4)) continue;
     const int64_t wg = (lanes_try[i] * per_launch + active_try[i] - 1) / active_try[i];
     if (wg > persist_max_workgroups()) continue;
     if (lanes_out) *lanes_out = (int)lanes_try[i];
@@ -1764,8 +1768,8 @@ extern "C" __attribute__((visibility("default"))) int sabc_debug_persist_trace(u
 // the most workgroups a persistent launch over a shard of at most `cap` particles can have (sizes the partial rows)
 int64_t persistent_workgroups_bound(const ModelDesc &m, int64_t cap) {
   if (!persistent_fits(m.d, m.s)) return 0;
-  const int64_t A = update_block_threads(m.s) < 256 ? update_block_threads(m.s) : 256, wg4 = (4 * cap + A - 1) / A;
-  return wg4 < persist_max_workgroups() ? wg4 : persist_max_workgroups();
+  const int64_t A = update_block_threads(m.s) < 256 ? update_block_threads(m.s) : 256, wg16 = (16 * cap + A - 1) / A;
+  return wg16 < persist_max_workgroups() ? wg16 : persist_max_workgroups();
 }
 
 int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArgs &pa_in, ControlBlock *cb, PopPtrs pp, CdfPtrs cdf,
@@ -1778,11 +1782,12 @@ int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArg
   pa.active = active;
   const dim3 grid((unsigned)wg), block((unsigned)update_block_threads(m.s));
   if (m.model_id == SABC_MODEL_USER)
-    return module_launch(lanes == 4 ? rtc->persistent4[prop_kind] : rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa,
+    return module_launch(lanes == 16 ? rtc->persistent16[prop_kind] : lanes == 4 ? rtc->persistent4[prop_kind] : rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa,
                          cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage);
 #define PCALLL(M, D, S, P, L) hipLaunchKernelGGL((k_update_persistent<M, D, S, P, L>), grid, block, 0, stream, m, pa, cb, pp, cdf, pv_a, pv_b, partials, hist, mbox, stage)
 #define PCALLP(M, D, S, P)                      \
-  if (lanes == 4) PCALLL(M, D, S, P, 4);        \
+  if (lanes == 16) PCALLL(M, D, S, P, 16);      \
+  else if (lanes == 4) PCALLL(M, D, S, P, 4);   \
   else PCALLL(M, D, S, P, 1)
 #define PCALL(M, D, S)                                                          \
   switch (prop_kind) {                                                          \

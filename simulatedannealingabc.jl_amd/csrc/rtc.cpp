@@ -67,7 +67,7 @@ void anchor() {}
 // sabc() call makes one) loads the module without paying the ~2 s of compilation again
 struct CachedModule {
   std::vector<char> code;
-  std::string lowered[13];
+  std::string lowered[16];
 };
 std::mutex g_cache_mutex;
 std::map<std::string, CachedModule> g_cache;
@@ -203,8 +203,8 @@ int rtc_build(const char *user_source, int d, int s, const std::string &csrc_dir
 // out == nullptr: compile only (needs no device); code_size (optional) receives the size of the code object
 int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_dir, RtcKernels *out, std::string *log,
                 size_t *code_size, bool user_prior, bool with_persistent) {
-  constexpr int kMaxKernels = 13;
-  const int kKernels = with_persistent ? 13 : 7;
+  constexpr int kMaxKernels = 16;
+  const int kKernels = with_persistent ? 16 : 7;
   HiprtcApi *api = hiprtc_api();
   if (!api) { *log = "libhiprtc.so could not be loaded: simulators from source need the hipRTC of ROCm"; return -1; }
   if (d < 1 || d > SABC_MAX_PARA || s < 1 || s > SABC_MAX_SOURCE_STATS) { *log = "n_para / n_stats out of range (a simulator from source: d <= 16, s <= 16)"; return -1; }
@@ -232,6 +232,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
   std::snprintf(name[6], sizeof(name[6]), "sabc::k_prior_op_t<%d>", d);
   for (int p = 0; p < 3; ++p) std::snprintf(name[7 + p], sizeof(name[7 + p]), "sabc::k_update_persistent<%d, %d, %d, %d>", SABC_MODEL_USER, d, s, p);
   for (int p = 0; p < 3; ++p) std::snprintf(name[10 + p], sizeof(name[10 + p]), "sabc::k_update_persistent<%d, %d, %d, %d, 4>", SABC_MODEL_USER, d, s, p);
+  for (int p = 0; p < 3; ++p) std::snprintf(name[13 + p], sizeof(name[13 + p]), "sabc::k_update_persistent<%d, %d, %d, %d, 16>", SABC_MODEL_USER, d, s, p);
   // extra compiler flags (e.g. -DSABC_NO_BITOP3: the two-instruction form of the Philox round's three-input XOR)
   const char *extra_env = std::getenv("SABC_RTC_EXTRA_FLAGS");
   const std::string extra = extra_env ? extra_env : "";
@@ -243,7 +244,7 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
                                 SABC_RTC_STR(SABC_CDF_COARSE_MS) "," SABC_RTC_STR(SABC_UPDATE_MIN_WAVES) "," SABC_RTC_STR(SABC_UPDATE_MIN_WAVES_MS);
 #undef SABC_RTC_STR
 #undef SABC_RTC_STR2
-  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + (with_persistent ? ",1L4" : "") + "," + extra + "," +
+  const std::string cache_key = std::to_string(d) + "," + std::to_string(s) + (user_prior ? ",P" : "") + (with_persistent ? ",1L4L16" : "") + "," + extra + "," +
                                 geometry + "\n" + user_source;
   if (out) {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -253,7 +254,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       k.d = d; k.s = s;
       if (hipModuleLoadData(&k.module, hit->second.code.data()) != hipSuccess) { *log = "hipModuleLoadData of the cached simulator failed"; return -1; }
       hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
-                                        &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2]};
+                                        &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2],
+                                        &k.persistent16[0], &k.persistent16[1], &k.persistent16[2]};
       for (int i = 0; i < kKernels; ++i)
         if (hipModuleGetFunction(slots[i], k.module, hit->second.lowered[i].c_str()) != hipSuccess) {
           *log = std::string("kernel not found in the cached module: ") + name[i];
@@ -273,7 +275,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
       k.d = d; k.s = s;
       bool ok = hipModuleLoadData(&k.module, entry.code.data()) == hipSuccess;
       hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
-                                           &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2]};
+                                           &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2],
+                                        &k.persistent16[0], &k.persistent16[1], &k.persistent16[2]};
       for (int i = 0; ok && i < kKernels; ++i) ok = hipModuleGetFunction(slots[i], k.module, entry.lowered[i].c_str()) == hipSuccess;
       if (ok) {
         if (code_size) *code_size = entry.code.size();
@@ -349,7 +352,8 @@ int rtc_compile(const char *user_source, int d, int s, const std::string &csrc_d
     return -1;
   }
   hipFunction_t *slots[kMaxKernels] = {&k.prior_simulate, &k.update[0], &k.update[1], &k.update[2], &k.simulate_batch, &k.stats, &k.prior_op,
-                                        &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2]};
+                                        &k.persistent[0], &k.persistent[1], &k.persistent[2], &k.persistent4[0], &k.persistent4[1], &k.persistent4[2],
+                                        &k.persistent16[0], &k.persistent16[1], &k.persistent16[2]};
   CachedModule entry;
   for (int i = 0; i < kKernels; ++i) {
     const char *lowered = nullptr;

@@ -15,6 +15,7 @@ struct RtcKernels {
   hipFunction_t prior_op = nullptr;            // k_prior_op_t<D>
   hipFunction_t persistent[3] = {nullptr, nullptr, nullptr};   // k_update_persistent<USER, D, S, PROP> (persistent_kernel.hpp)
   hipFunction_t persistent4[3] = {nullptr, nullptr, nullptr};  // ... <USER, D, S, PROP, 4>: a particle per quad of lanes
+  hipFunction_t persistent16[3] = {nullptr, nullptr, nullptr}; // ... <USER, D, S, PROP, 16>: a particle per row of 16 lanes
   int d = 0, s = 0;
 };
 

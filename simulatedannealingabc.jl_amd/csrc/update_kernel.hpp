@@ -137,9 +137,9 @@ __device__ __forceinline__ void particle_store(double *p, double v) {
   else *p = v;
 }
 
-// LANES = 4 (k_update_persistent on an under-filled device): the four lanes of a quad run THIS particle together -- the same
-// loads, the same arithmetic, the same decisions -- and share the generator's work (device_rng.hpp: NormalStream, coop); the
-// quad's first lane alone writes the particle back and reports its moment terms.
+// LANES = 4 | 16 (k_update_persistent on an under-filled device): the lanes of a team -- a quad, a row of 16 -- run THIS particle
+// together -- the same loads, the same arithmetic, the same decisions -- and share the generator's work (device_rng.hpp:
+// NormalStream, coop); the team's first lane alone writes the particle back and reports its moment terms.
 // LATENCY (k_update_persistent): the wave has its SIMD to itself -- the ECDF lookups of the S statistics step together
 // (device_models.hpp: cdf_apply_3level_lockstep) instead of one after the other.
 template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, bool LATENCY = false, class CB>
@@ -162,7 +162,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
   double thp[D];
   double logf = 0.0;
   if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
-    NormalStream ns(m.seed, gid, PURPOSE_PROP, iter, LANES == 4 ? 4 : 0);
+    NormalStream ns(m.seed, gid, PURPOSE_PROP, iter, LANES > 1 ? LANES : 0);
     double z[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) z[k] = ns.next();
@@ -212,7 +212,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
 #pragma unroll
   for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
   if (lpp > -INFINITY) {
-    if (LANES == 4) Sim<MODEL, D, S>::run(m, thp, gid, iter, rp, 4);       // :315
+    if (LANES > 1) Sim<MODEL, D, S>::run(m, thp, gid, iter, rp, LANES);    // :315
     else Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);
     SABC_TRACE(iter, 8);
     double a = 0.0;

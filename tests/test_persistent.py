@@ -17,7 +17,7 @@ def run(S, name, alg, prop, n, k, monkeypatch, persistent, calls=1, resample=Non
     if lanes is None:
         monkeypatch.delenv("SABC_PERSISTENT_LANES", raising=False)
     else:
-        monkeypatch.setenv("SABC_PERSISTENT_LANES", str(lanes))      # 1: a lane per particle | 4: a quad of lanes per particle
+        monkeypatch.setenv("SABC_PERSISTENT_LANES", str(lanes))      # 1: a lane per particle | 4, 16: a quad, a row of lanes per particle
     monkeypatch.setenv("SABC_PERSISTENT_MAX", "65536")
     model, prior = hip_model_prior(S, name)
     d = len(MODELS[name]["prior"])
@@ -37,7 +37,7 @@ def run(S, name, alg, prop, n, k, monkeypatch, persistent, calls=1, resample=Non
                                              ("gauss2_2stats", "multi_eps", "stretch", 5000), ("gauss2d_cfg3", "multi_eps", "rw", 3000),
                                              ("gauss2d_cfg3", "single_eps", "de", 20_001), ("lv_cfg5", "single_eps", "rw", 700),
                                              ("gauss1_uniform", "single_eps", "de", 130), ("gauss2_meansd", "multi_eps", "rw", 40_000)])
-@pytest.mark.parametrize("lanes", [1, 4])
+@pytest.mark.parametrize("lanes", [1, 4, 16])
 def test_one_launch_equals_the_launch_chain(S, gpu, monkeypatch, name, alg, prop, n, lanes):
     """lanes = 4: the four lanes of a quad run one particle and share its generator work (device_rng.hpp: NormalStream, coop) --
     the same streams bit for bit, so the same run; where four times the workgroups do not fit the launch (n = 40 000, 20 001
@@ -48,8 +48,9 @@ def test_one_launch_equals_the_launch_chain(S, gpu, monkeypatch, name, alg, prop
     assert a["counters"] == b["counters"] and a["counters"]["n_resampling"] >= 3
     per_launch = n if prop == "rw" else n - n // 2
     block = 256 if b["rho"].shape[0] == 1 else 512          # threads of a workgroup (one statistic | more: kernels.hpp)
-    fits4 = -(-4 * per_launch // 256) <= 256 or -(-4 * per_launch // block) <= 256
-    assert a["lanes"] == 0 and b["lanes"] == (4 if lanes == 4 and fits4 else 1), (b["lanes"], per_launch)
+    fits = {w: -(-w * per_launch // 256) <= 256 or -(-w * per_launch // block) <= 256 for w in (4, 16)}
+    expect = 16 if lanes == 16 and fits[16] else 4 if lanes >= 4 and fits[4] else 1     # (a team that does not fit: the next smaller)
+    assert a["lanes"] == 0 and b["lanes"] == expect, (b["lanes"], per_launch)
     tol = 1e-10 if prop == "rw" else 1e-6                 # (DE / Stretch compound an ulp by ~(1 + 2 gamma) per update)
     for key in ("theta", "u", "rho", "eps", "sigma"):
         np.testing.assert_allclose(b[key], a[key], rtol=tol, atol=tol * 1e-2)
@@ -63,14 +64,15 @@ def test_one_launch_equals_the_launch_chain(S, gpu, monkeypatch, name, alg, prop
 
 
 @pytest.mark.parametrize("name,prop,n", [("gauss1_cfg2", "rw", 1000), ("gauss2d_cfg3", "de", 3001), ("lv_cfg5", "stretch", 700)])
-def test_a_quad_per_particle_is_the_same_run_as_a_lane_per_particle(S, gpu, monkeypatch, name, prop, n):
+@pytest.mark.parametrize("team", [4, 16])
+def test_a_quad_per_particle_is_the_same_run_as_a_lane_per_particle(S, gpu, monkeypatch, name, prop, n, team):
     """One update, no epsilon feedback in between: the quad-cooperative generator hands every simulator the stream the one-lane
     generator does, so the two forms make the same proposals, simulate the same distances and take the same decisions -- to
     the last bits only because they are two instantiations of the same source (the compiler is free to contract a*b + c
     differently in each: a 1-ulp difference in 2 % of the particles, as between k_update and either of them)."""
     a = run(S, name, "single_eps", prop, n, 1, monkeypatch, persistent=True, lanes=1, resample=10 ** 9)
-    b = run(S, name, "single_eps", prop, n, 1, monkeypatch, persistent=True, lanes=4, resample=10 ** 9)
-    assert a["counters"] == b["counters"] and a["counters"]["n_accept"] > 0 and (a["lanes"], b["lanes"]) == (1, 4)
+    b = run(S, name, "single_eps", prop, n, 1, monkeypatch, persistent=True, lanes=team, resample=10 ** 9)
+    assert a["counters"] == b["counters"] and a["counters"]["n_accept"] > 0 and (a["lanes"], b["lanes"]) == (1, team)
     for key in ("theta", "u", "rho"):
         np.testing.assert_allclose(b[key], a[key], rtol=1e-13, atol=1e-15)
 

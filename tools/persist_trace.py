@@ -18,7 +18,7 @@ try:
     prop = sys.argv[2] if len(sys.argv) > 2 else "rw"
     name = sys.argv[3] if len(sys.argv) > 3 else "gauss1_cfg2"
     lib = S._lib.lib()
-    for lanes in ("1", "4"):
+    for lanes in ("1", "4", "16"):
         os.environ["SABC_PERSISTENT"] = "1"; os.environ["SABC_PERSISTENT_LANES"] = lanes
         model, prior = hip_model_prior(S, name)
         h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=7)
