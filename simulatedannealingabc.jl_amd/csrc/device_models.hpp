@@ -231,6 +231,25 @@ __device__ __forceinline__ double cdf_apply_3level(const double *__restrict__ T,
   return cdf_interp(T, len, lo, x);
 }
 
+// A table that fits the coarse level whole (shift = 0: C[k] = T[k], +inf behind len -- populations of up to ~1000 particles with
+// one statistic, ~2000 with more): the lookup never leaves LDS.  The same steps as cdf_apply_3level at shift = 0 (its second and
+// third level are empty there), the same interpolation on the same knots: the same u.  (k_update_persistent only.)
+template <int COARSE>
+__device__ __forceinline__ double cdf_apply_lds(const double *C, const int64_t len, const double x) {
+  const double first = C[0], last = C[len - 1];
+  int c = 0;                               // c = #knots < x
+#pragma unroll
+  for (int step = COARSE >> 1; step >= 1; step >>= 1) c += C[c + step - 1] < x ? step : 0;
+  c += C[c] < x ? 1 : 0;
+  const int i0 = c > 0 ? c - 1 : 0, i1 = i0 + 1 < COARSE ? i0 + 1 : COARSE - 1;
+  const double k0 = C[i0], k1 = C[i1];
+  const double L1 = (double)(len - 1);
+  const double y0 = (double)i0 / L1, y1 = (double)(i0 + 1) / L1;
+  const double t = (x - k0) / (k1 - k0);
+  const double v = y0 + t * (y1 - y0);
+  return !(x >= first) ? ((x != x) ? x : 0.0) : (x > last ? 1.0 : v);
+}
+
 // The S lookups of ONE particle (one per statistic, each into its own table), step by step together: where a wave has the SIMD
 // to itself (k_update_persistent: small shards) a lookup is a chain of ~11 LDS and 2-6 memory round trips that nothing hides,
 // and the S chains are independent -- in flight together they cost one chain, not S.  Every step tests the predicate of
@@ -245,10 +264,14 @@ __device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, co
   for (int j = 0; j < S; ++j) {
     T[j] = cdf.knots + (int64_t)j * cdf.stride;
     M[j] = cdf.mid + (int64_t)j * cdf.mid_stride;
-    first[j] = T[j][0];
-    last[j] = T[j][cdf.len[j] - 1];
     c[j] = 0;
     same = same && cdf.shift[j] == cdf.shift[0];
+  }
+  const bool lds_knots = same && cdf.shift[0] == 0;                   // (the tables fit the coarse level whole: cdf_apply_lds)
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    first[j] = lds_knots ? C[j][0] : T[j][0];
+    last[j] = lds_knots ? C[j][cdf.len[j] - 1] : T[j][cdf.len[j] - 1];
   }
 #pragma unroll
   for (int step = COARSE >> 1; step >= 1; step >>= 1) {
@@ -303,8 +326,13 @@ __device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, co
   for (int j = 0; j < S; ++j) {
     const int64_t lo = c[j] > 0 ? a[j] + 1 : 0;
     i0[j] = lo > 0 ? lo - 1 : 0;
-    k0[j] = T[j][i0[j]];
-    k1[j] = T[j][i0[j] + 1];
+    if (lds_knots) {
+      k0[j] = C[j][i0[j]];
+      k1[j] = C[j][i0[j] + 1 < COARSE ? i0[j] + 1 : COARSE - 1];
+    } else {
+      k0[j] = T[j][i0[j]];
+      k1[j] = T[j][i0[j] + 1];
+    }
   }
 #pragma unroll
   for (int j = 0; j < S; ++j) {                                        // cdf_interp, on the knots in hand

@@ -219,7 +219,9 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     if (LATENCY && S >= 2) cdf_apply_3level_lockstep<S, kCoarse>(cdf, cidx, rp, up);                         // :316
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      if (!(LATENCY && S >= 2))
+      if (LATENCY && S == 1 && cdf.shift[0] == 0)
+        up[j] = cdf_apply_lds<kCoarse>(cidx[j], cdf.len[j], rp[j]);                                           // :316
+      else if (!(LATENCY && S >= 2))
         up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
                                  cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                               // :316
       const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];

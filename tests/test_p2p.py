@@ -23,6 +23,23 @@ pytestmark = pytest.mark.gpu
 TOL = {"rw": 1e-9, "stretch": 1e-7, "de": 1e-6}
 
 
+_shard_streams = {}
+
+
+def shard_stream(rank):
+    """A stream per in-process shard, each of another priority (created once, kept for the process)."""
+    import ctypes as C
+    if rank not in _shard_streams:
+        hip = C.CDLL("libamdhip64.so")
+        least, greatest = C.c_int(0), C.c_int(0)
+        assert hip.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) == 0
+        levels = list(range(greatest.value, least.value + 1)) or [0]           # numerically: greatest priority <= least
+        st = C.c_void_p()
+        assert hip.hipStreamCreateWithPriority(C.byref(st), C.c_uint(1), C.c_int(levels[rank % len(levels)])) == 0   # hipStreamNonBlocking
+        _shard_streams[rank] = st.value
+    return _shard_streams[rank]
+
+
 def run_shards_in_one_process(S, case, alg, prop, n, k, resample, world=2, timeout_ms=None, before_update=None, calls=1):
     """One host thread + one stream per shard; descriptors exchanged through a Python list.  before_update(rank, handle,
     call) may tamper with a shard; returns per-rank dicts (or the exception a shard's call raised)."""
@@ -38,10 +55,14 @@ def run_shards_in_one_process(S, case, alg, prop, n, k, resample, world=2, timeo
             model, prior = hip_model_prior(S, case)
             h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED, rank=rank, world=world,
                              algorithm=S._lib.ALG_MULTI_EPS if alg == "multi_eps" else S._lib.ALG_SINGLE_EPS)
-            if os.environ.get("SABC_TEST_STREAM_PRIO"):
-                # streams of different priorities never share a hardware queue (the runtime keeps a pool per priority)
-                keep_stream = torch.cuda.Stream(device=0, priority=-1 if rank % 2 else 0)
-                h.set_stream(keep_stream.cuda_stream)
+            if os.environ.get("SABC_TEST_STREAM_PRIO", "1") != "0":
+                # Shards of ONE device in ONE process (this test's arrangement, not a deployment's): their streams must not share
+                # a hardware queue -- the runtime hands its few queues (GPU_MAX_HW_QUEUES, 4) to the process's streams in turn
+                # and dispatches a queue's packets in order, so a shard's exchange kernel, waiting for its peer's words, can sit
+                # AHEAD of that peer's update in the same queue: the peer never posts, the wait runs into its bound
+                # (SABC_ERR_COMM after 5 s; seen in ~1 run of 20).  Streams of different priorities never share a queue (a
+                # pool per priority).
+                h.set_stream(shard_stream(rank))
 
             def setup():
                 descs[rank] = h.p2p_descriptor()
