@@ -576,8 +576,8 @@ def main():
             # kernels the library launched / collective calls it issued per population update in the timed region
             # (resamples included), and -- N > 1 -- what the step between two update kernels costs
             "launches_per_update": med["kernel_launches"] / K,
-            "persistent_launches": h.persistent_launches,
-            "persistent_lanes": h.persistent_lanes,            # 4: a quad of lanes per particle shares the generator's blocks      # > 0: small shard, the updates of a call in one launch
+            "persistent_launches": h.persistent_launches,      # > 0: small shard, the updates of a call in one launch
+            "persistent_lanes": h.persistent_lanes,            # ... with 16 | 4 | 1 lanes per particle (a team shares the generator's blocks)
             "collective_calls_per_update": med["collective_calls"] / K,
             "exchange": exchange,
             "exchange_rccl": exchange_rccl,

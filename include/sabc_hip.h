@@ -199,8 +199,8 @@ SABC_API int64_t     sabc_host_callback_calls(const sabc_handle *h);
                                                                       // the next n pairs, in stream order
                                           double *rho_out);           // the s non-negative distances
    (a function of its arguments and its draws alone.  for_pairs is the loop to draw the bulk of a simulation with: a small
-   population runs a call's updates in one launch with a QUAD of lanes per particle, which then generate sixteen pairs at a
-   time, four blocks per lane -- csrc/device_rng.hpp; the stream is the same stream however it is drawn.)
+   population runs a call's updates in one launch with a TEAM of 4 or 16 lanes per particle, which then generate 16 or 64
+   pairs at a time, four blocks per lane -- csrc/device_rng.hpp; the stream is the same stream however it is drawn.)
    With sabc_config::prior_joint = 3 the same source also defines the PRIOR -- any distribution, evaluated inside the fused
    kernel (SimulatedAnnealingABC.jl:151 takes any Distributions.Distribution):
        __device__ void   sabc_user_prior_sample(const double *params, sabc::NormalStream &rng, double *theta_out);
@@ -380,10 +380,11 @@ SABC_API int64_t sabc_kernel_launches(const sabc_handle *h);
    device-coded simulator runs the population updates between two resamples in ONE launch; SABC_PERSISTENT=0 switches it
    off): 0 on a handle that takes the launch chain per update */
 SABC_API int64_t sabc_persistent_launches(const sabc_handle *h);
-/* lanes per particle of the handle's last such launch: 4 while four times the workgroups fit the launch (<= 16 384 particles
-   per launch: the device is so empty that a particle's chain of generator blocks is what an update waits for -- the four
-   lanes of a quad run the particle side by side and share the blocks, same streams), else 1; 0 before the first.
-   SABC_PERSISTENT_LANES = 1 | 4 overrides, SABC_PERSISTENT_LANES4_MAX moves the bound */
+/* lanes per particle of the handle's last such launch: a TEAM of 16 (a row of the wave; <= 2048 particles per launch) or 4 (a
+   quad; <= 16 384) while that many times the workgroups fit the launch -- the device is then so empty that a particle's chain
+   of generator blocks is what an update waits for: the lanes of a team run the particle side by side and share the blocks,
+   same streams --, else 1; 0 before the first.  SABC_PERSISTENT_LANES = 1 | 4 | 16 overrides, SABC_PERSISTENT_LANES4_MAX /
+   SABC_PERSISTENT_LANES16_MAX move the bounds */
 SABC_API int32_t sabc_persistent_lanes(const sabc_handle *h);
 SABC_API int64_t sabc_collective_calls(const sabc_handle *h);
 

@@ -268,10 +268,12 @@ __device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, co
     same = same && cdf.shift[j] == cdf.shift[0];
   }
   const bool lds_knots = same && cdf.shift[0] == 0;                   // (the tables fit the coarse level whole: cdf_apply_lds)
+  if (lds_knots) {                                                    // (two loops, not a select: no LDS-or-memory pointer)
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    first[j] = lds_knots ? C[j][0] : T[j][0];
-    last[j] = lds_knots ? C[j][cdf.len[j] - 1] : T[j][cdf.len[j] - 1];
+    for (int j = 0; j < S; ++j) { first[j] = C[j][0]; last[j] = C[j][cdf.len[j] - 1]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < S; ++j) { first[j] = T[j][0]; last[j] = T[j][cdf.len[j] - 1]; }
   }
 #pragma unroll
   for (int step = COARSE >> 1; step >= 1; step >>= 1) {

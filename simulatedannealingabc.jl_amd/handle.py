@@ -356,8 +356,8 @@ class SabcHandle:
 
     @property
     def persistent_lanes(self):
-        """Lanes per particle of the last one-launch update: 4 = a quad of lanes runs a particle and shares its generator
-        blocks (<= 16 384 particles per launch), 1 = a lane per particle, 0 = none yet."""
+        """Lanes per particle of the last one-launch update: 16 | 4 = a row | a quad of lanes runs a particle and shares its
+        generator blocks (<= 2048 | 16 384 particles per launch), 1 = a lane per particle, 0 = none yet."""
         return int(self._L.sabc_persistent_lanes(self._h))
 
     def profile_enable(self, on=True):

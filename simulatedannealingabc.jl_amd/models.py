@@ -140,8 +140,8 @@ class DeviceSource(DeviceDistance):
 
     `rng.next()` / `rng.pair(z0, z1)` are N(0,1) draws, `rng.uniform_pair(u0, u1)` U(0,1) draws of the particle's
     simulation stream; `rng.for_pairs(n, [&](double z0, double z1) { ... })` hands the next n pairs to the lambda in stream
-    order -- the loop to draw the bulk of a simulation with: small populations (one launch per call, a quad of lanes per
-    particle) then generate sixteen pairs at a time on four lanes.  The simulator must be a function of its arguments and
+    order -- the loop to draw the bulk of a simulation with: small populations (one launch per call, a team of 4 or 16
+    lanes per particle) then generate 16 or 64 pairs at a time, four blocks per lane.  The simulator must be a function of its arguments and
     its draws alone (the lanes of a quad run it side by side).  `params` is the `params` list given here.  The source is compiled at run time (hipRTC, gfx950) into
     the same fused propose -> simulate -> ECDF -> accept kernel as the built-in simulators."""
     model_id = _lib.MODEL_USER

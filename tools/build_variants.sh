@@ -14,7 +14,8 @@ for spec in "$@"; do
   hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -x c++ $flags -c $src/engine.cpp -o $tmp/engine.o &
   hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -x c++ -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $flags -c $src/rtc.cpp -o $tmp/rtc.o &
   wait
-  hipcc --offload-arch=gfx950 -shared -o tools/exp_libs/lib_$name.so $tmp/*.o -ldl
+  for f in kernels sort hip_backend capi engine rtc; do [ -s $tmp/$f.o ] || { echo "lib_$name: $f did not compile"; exit 1; }; done
+  hipcc --offload-arch=gfx950 -shared -Wl,-z,defs -o tools/exp_libs/lib_$name.so $tmp/*.o -ldl
   rm -rf $tmp
   echo "built lib_$name.so ($flags)"
 done
