@@ -97,9 +97,11 @@ __device__ __forceinline__ void row_word_post(unsigned long long *w, const doubl
 
 // every workgroup: the sum over all rows; thread (g, c) takes rows g, g + G, ... of column c, the G partial sums are added in
 // order -- the same bits in every workgroup.  my_row: this workgroup's row (LDS); false: a row never came (abort flag raised)
+// (the sums go straight into the workgroup's control block too -- control_take_sum, one lane per component -- unless a row never came)
 template <int NP, int B>
 __device__ __forceinline__ bool exchange_rows(unsigned long long *words, const int nwg, const double *my_row, const uint32_t tag, double *sm,
-                                              double *sums, unsigned long long *sync, const uint64_t ticks, int *stop) {
+                                              double *sums, unsigned long long *sync, const uint64_t ticks, int *stop, ControlBlock &lcb,
+                                              const ControlArgs &args) {
   if ((int)threadIdx.x < NP) row_word_post(words + ((int64_t)blockIdx.x * NP + threadIdx.x) * 2, my_row[threadIdx.x], tag);
   constexpr int G = B / NP;
   const int g = threadIdx.x / NP, c = threadIdx.x - g * NP;
@@ -149,10 +151,12 @@ __device__ __forceinline__ bool exchange_rows(unsigned long long *words, const i
   }
   sm[threadIdx.x] = v;
   __syncthreads();
+  static_assert(NP <= B, "a lane per component of the sums");
   if ((int)threadIdx.x < NP) {
     double a = sm[threadIdx.x];
     for (int gg = 1; gg < G; ++gg) a += sm[gg * NP + threadIdx.x];
     sums[threadIdx.x] = a;
+    if (*stop == 0) control_take_sum(lcb, args, sums, threadIdx.x);
   }
   __syncthreads();
   return *stop == 0;
@@ -216,22 +220,21 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     // u + 1 while a slow one still polls those of update u (it cannot get two ahead: the rows of u + 1 need everybody's)
     unsigned long long *rows = reinterpret_cast<unsigned long long *>(partials) + (int64_t)(u & 1) * nwg * NP * 2;
     SABC_TRACE(iter, 1);
-    block_reduce_store<NP, B>(acc, my_row);            // (into LDS; the row goes out as tagged words, past the caches)
+    // (a team's moment terms sit on its first lane, zeros on the others: the shuffle steps below the team's width add nothing)
+    block_reduce_store<NP, B, LANES>(acc, my_row);     // (into LDS; the row goes out as tagged words, past the caches)
     // DifferentialEvolution / StretchMove: the rows are also what tells the others that this workgroup's particles of the update
     // are in memory -- every wave's stores have to be acknowledged before the row is posted (vmcnt(0); stores count there)
     if (PROP != SABC_PROP_RANDOMWALK) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     SABC_TRACE(iter, 2);
     SABC_TRACE(iter, 3);
-    if (!exchange_rows<NP, B>(rows, nwg, my_row, (uint32_t)u + 1u, sm, sums, pa.sync, pa.timeout_ticks, &stop)) { barrier_failed = true; break; }
-    SABC_TRACE(iter, 4);
     // the control step (control.hpp) on this workgroup's copy of the control block; the history cadence of engine.cpp
     ControlArgs a = pa.ctrl;
     a.notify_seq = 0;
     if ((pa.phase + pa.ix0 + (int64_t)u) % pa.cph == 0) a.mode |= CTRL_HISTORY;                           // :367
-    for (int q = threadIdx.x; q < NP; q += B) control_take_sum(lcb, a, sums, q);
+    if (!exchange_rows<NP, B>(rows, nwg, my_row, (uint32_t)u + 1u, sm, sums, pa.sync, pa.timeout_ticks, &stop, lcb, a)) { barrier_failed = true; break; }
+    SABC_TRACE(iter, 4);
     a.mode |= CTRL_KEEP_SUMS;
-    __syncthreads();
     SABC_TRACE(iter, 11);
     const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
     if (multi) {

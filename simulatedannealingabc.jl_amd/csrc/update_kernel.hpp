@@ -12,7 +12,9 @@ namespace sabc {
 // ------------------------------------------------------------------------------------------
 // block reduction of NP per-lane values: wave shuffles, then LDS across the 4 wavefronts
 // ------------------------------------------------------------------------------------------
-template <int NP, int BLOCK = kBlock>
+// FIRST: the smallest shuffle distance that carries anything (k_update_persistent with a team of lanes per particle: only every
+// FIRST-th lane holds terms, the others exact zeros -- adding them changes no bit)
+template <int NP, int BLOCK = kBlock, int FIRST = 1>
 __device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], double *__restrict__ out) {
   constexpr int NW = BLOCK / 64;
   __shared__ double sm[NW][NP];
@@ -23,7 +25,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&acc)[NP], doub
 #pragma unroll
   for (int c = 0; c < NP; ++c) v[c] = acc[c];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
+  for (int off = 32; off >= FIRST; off >>= 1) {
     double t[NP];
 #pragma unroll
     for (int c = 0; c < NP; ++c) t[c] = __shfl_down(v[c], off, 64);
