@@ -386,6 +386,10 @@ SABC_API int64_t sabc_persistent_launches(const sabc_handle *h);
    same streams --, else 1; 0 before the first.  SABC_PERSISTENT_LANES = 1 | 4 | 16 overrides, SABC_PERSISTENT_LANES4_MAX /
    SABC_PERSISTENT_LANES16_MAX move the bounds */
 SABC_API int32_t sabc_persistent_lanes(const sabc_handle *h);
+/* one-launch updates that found the device too full for all their workgroups to be resident at once (other handles' or
+   processes' kernels on it) and left without touching anything -- within SABC_PERSISTENT_RENDEZVOUS_MS, 20 ms --: the rest of
+   that call ran as the launch chain, no error */
+SABC_API int64_t sabc_persistent_fallbacks(const sabc_handle *h);
 SABC_API int64_t sabc_collective_calls(const sabc_handle *h);
 
 #ifdef __cplusplus

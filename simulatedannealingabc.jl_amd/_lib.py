@@ -192,6 +192,7 @@ def bind(L, strict=True):
         "sabc_kernel_launches": ([vp], C.c_int64),
         "sabc_persistent_launches": ([vp], C.c_int64),
         "sabc_persistent_lanes": ([vp], C.c_int32),
+        "sabc_persistent_fallbacks": ([vp], C.c_int64),
         "sabc_collective_calls": ([vp], C.c_int64),
         "sabc_comm_p2p_setup": ([vp], C.c_int),
         "sabc_comm_p2p_descriptor": ([vp, vp], C.c_int),

@@ -466,6 +466,7 @@ int sabc_comm_p2p_set_destroy_wait(sabc_handle *h, double milliseconds) {
 int64_t sabc_comm_p2p_parked_bytes(void) { return HipBackend::parked_bytes(); }
 int64_t sabc_persistent_launches(const sabc_handle *h) { return h ? h->eng->persistent_launches() : 0; }
 int32_t sabc_persistent_lanes(const sabc_handle *h) { return h ? h->eng->persistent_lanes() : 0; }
+int64_t sabc_persistent_fallbacks(const sabc_handle *h) { return h ? h->eng->persistent_fallbacks() : 0; }
 
 int sabc_initialize(sabc_handle *h, int64_t n_simulation) {
   if (!h) return SABC_ERR_STATE;

@@ -570,7 +570,10 @@ int Engine::enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarde
 // The loop of :294-375 on a small shard: the backend runs the updates in one launch (body -> sums -> control step, per update,
 // inside the kernel) until the resample test of :340 fires; the host then resamples (:341), finishes that update's control
 // step and launches the rest.  Same kernels' arithmetic, same control step, same history cadence as the chain below.
-int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase) {
+// *next_ix: the first update of the call this loop has NOT done -- n_pop + 1, or the update from which the launch chain has to
+// take over: a launch whose workgroups did not all become resident within the rendezvous' bound (a device shared with other
+// handles' or processes' kernels) has touched nothing and says so (done = -1)
+int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase, int64_t *next_ix) {
   const int32_t after_update = CTRL_PROPOSAL | CTRL_EPSILON | CTRL_PIVOT;   // :348-354
   StepArgs c;
   std::memset(&c, 0, sizeof(c));
@@ -593,6 +596,11 @@ int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int
     if (be_->update_persistent(c, ctrl, pv_a, pv_b, ix, phase, cph, n_pop - ix + 1, &done, &halted, &error))
       return fail(SABC_ERR_HIP, "persistent update kernel failed");
     host_syncs_ += 1;
+    if (done == -1) {
+      persistent_fallbacks_ += 1;
+      *next_ix = ix;
+      return 0;
+    }
     persistent_launches_ += 1;
     if (error) { cb_.error = error; return sync_control(); }
     if (done < 1 || done > n_pop - ix + 1) return fail(SABC_ERR_HIP, "persistent update kernel reported an impossible update count");
@@ -607,6 +615,7 @@ int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int
     }
     ix = last + 1;
   }
+  *next_ix = n_pop + 1;
   return 0;
 }
 
@@ -718,9 +727,11 @@ int Engine::update_loop(const sabc_update_args &a) {
 
   // Small shards with a device-coded simulator: the whole loop of :294-375 in ONE launch per stretch between two resamples
   // (kernels.hip: k_update_persistent) instead of a chain of launches per update
+  int64_t first_ix = 1;                                                     // the launch chain's first update of the call
   if (n_pop > 0 && !host_mode_ && sh_.world == 1 && be_->persistent_supported(a.proposal_kind)) {
-    if ((rc = update_loop_persistent(a, n_pop, cph, phase))) return rc;
-  } else {
+    if ((rc = update_loop_persistent(a, n_pop, cph, phase, &first_ix))) return rc;
+  }
+  if (first_ix <= n_pop) {
   // The loop of :294-375 with the host two updates ahead of the device.  Every update is enqueued as
   //   k_update (x1 or x2) -> k_reduce_partials -> [allreduce] -> k_control(ACCUMULATE | CHECK | ...)
   // where the control step evaluates the resample test of :340 ON THE DEVICE.  If it does not fire, the
@@ -732,7 +743,7 @@ int Engine::update_loop(const sabc_update_args &a) {
   constexpr int kMaxDepth = 2;
   const int kDepth = host_mode_ ? 1 : kMaxDepth;     // a host simulator leaves nothing to queue ahead
   int64_t seqs[kMaxDepth + 1] = {0};
-  int64_t next_enqueue = 1, next_confirm = 1;
+  int64_t next_enqueue = first_ix, next_confirm = first_ix;
   int64_t known_accept = cb_.n_accept, last_delta = 0;   // as of the last confirmed update
   auto hist_flag = [&](int64_t ix) { return ((phase + ix) % cph == 0) ? (int32_t)CTRL_HISTORY : 0; };   // :367
   // Queueing ahead of an update that then triggers the resample costs three no-op launches; the accept

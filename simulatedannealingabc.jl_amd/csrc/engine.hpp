@@ -168,6 +168,7 @@ class Engine {
   // how often update() had to wait for the device (one per run-ahead window), for measurement
   int64_t host_syncs() const { return host_syncs_; }
   int64_t persistent_launches() const { return persistent_launches_; }
+  int64_t persistent_fallbacks() const { return persistent_fallbacks_; }
   int persistent_lanes() const { return be_->persistent_lanes(); }
   // bytes that landed in this shard's receive buffers through collectives so far (allreduce: the vector; allgather: all
   // blocks; alltoallv: what arrived)
@@ -198,7 +199,7 @@ class Engine {
   int partner_source(int inactive_half, PartnerView *pv);
   int enqueue_update(const sabc_update_args &a, uint64_t iter, bool guarded);
   int update_loop(const sabc_update_args &a);       // update() minus the error contract
-  int update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase);   // small shards: one launch
+  int update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int64_t cph, int64_t phase, int64_t *next_ix);   // small shards: one launch
   int update_once(const sabc_update_args &a);       // update_loop + the error contract; update() adds the transport fallback
   int drain_history();
   PartnerView partner_view(const double *base, int64_t rank_stride, int inactive_half) const;
@@ -220,7 +221,7 @@ class Engine {
   int64_t hist_capacity_ = 0;
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
-  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0, persistent_launches_ = 0;
+  int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0, persistent_launches_ = 0, persistent_fallbacks_ = 0;
   ControlArgs control_args(int32_t mode, const sabc_update_args *a, double v, double threshold) const;
   int p2p_check_peers();                            // p2p: a peer has left the group? (entry of a call, nothing launched yet)
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)

@@ -37,6 +37,12 @@ static double persist_timeout_ms() {                 // (read per launch: tests 
   return v > 0 ? v : 2000.0;
 }
 
+static double persist_rendezvous_ms() {              // (the wait for every workgroup of a one-launch update to be resident)
+  const char *e = std::getenv("SABC_PERSISTENT_RENDEZVOUS_MS");
+  const double v = e ? std::atof(e) : 0.0;
+  return v > 0 ? v : 20.0;
+}
+
 HipBackend::HipBackend(int device) : device_(device) {
   // shards up to this many particles run the population updates of a call in ONE launch (kernels.hip: k_update_persistent);
   // SABC_PERSISTENT=0 (or SABC_PERSISTENT_MAX=0) keeps the launch chain per update at every size
@@ -649,8 +655,8 @@ bool HipBackend::persistent_supported(int prop_kind) const {
 int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, const PartnerView &pv_a, const PartnerView &pv_b, int64_t ix0,
                                   int64_t phase, int64_t cph, int64_t count, int64_t *done, int *halted, int *error) {
   if (pending_rows_ >= 0 && flush_reduce()) return -1;
-  if (!persist_sync_) HB_CHECK(hipMalloc((void **)&persist_sync_, 2 * sizeof(unsigned long long)), "hipMalloc(grid barrier)");
-  HB_CHECK(hipMemsetAsync(persist_sync_, 0, 2 * sizeof(unsigned long long), stream_), "hipMemset(grid barrier)");
+  if (!persist_sync_) HB_CHECK(hipMalloc((void **)&persist_sync_, 4 * sizeof(unsigned long long)), "hipMalloc(grid barrier)");
+  HB_CHECK(hipMemsetAsync(persist_sync_, 0, 4 * sizeof(unsigned long long), stream_), "hipMemset(grid barrier)");
   PersistArgs pa;
   std::memset(&pa, 0, sizeof(pa));
   pa.iter0 = c.iter;
@@ -661,6 +667,7 @@ int HipBackend::update_persistent(const StepArgs &c, const ControlArgs &ctrl, co
   pa.ctrl = ctrl;
   pa.sync = persist_sync_;
   pa.timeout_ticks = (uint64_t)(persist_timeout_ms() * (double)wall_clock_khz_);
+  pa.rendezvous_ticks = (uint64_t)(persist_rendezvous_ms() * (double)wall_clock_khz_);
   if (const char *e = std::getenv("SABC_PERSISTENT_TEST_ABSENT_WG")) pa.test_absent_wg = std::atoi(e);     // (tests/test_persistent.py)
   const int64_t wg = persistent_workgroups(m_, c.prop_kind, pa.act_n, rtc(), &persist_lanes_);
   if (wg <= 0) return check(hipErrorInvalidValue, "k_update_persistent: no one-launch form for this shard");

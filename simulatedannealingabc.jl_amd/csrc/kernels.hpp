@@ -92,12 +92,14 @@ struct PersistArgs {
   int64_t ix0, phase, cph;       // ... which is update ix0 of the call; update ix appends a history row iff (phase + ix) % cph == 0
   int64_t act_n, half;           // particles of the shard; size of the first half batch (DifferentialEvolution / StretchMove)
   int32_t count;                 // updates to run (the launch stops early when the resample test fires or an error is raised)
-  int32_t test_absent_wg;        // test hook: 1 + the index of a workgroup that leaves at once, as if it had never become resident
+  int32_t test_absent_wg;        // test hook: k > 0: workgroup k - 1 is lost after the rendezvous; k < 0: workgroup -k - 1 never becomes resident
   int32_t active, pad_;          // threads of a workgroup that carry particles (a multiple of 64 <= the block: persistent_workgroups)
   double prop_p0, prop_p1;
   ControlArgs ctrl;              // the control step of every update: ACCUMULATE | CHECK | PROPOSAL | EPSILON | PIVOT (history by cadence)
-  unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag; zeroed before the launch
-  uint64_t timeout_ticks;        // bound of a wait at the grid barrier (wall clock)
+  unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag, [2] arrivals at the rendezvous, [3] its decision
+                                 // (1 commit | 2 abort); zeroed before the launch
+  uint64_t timeout_ticks;        // bound of a wait at the grid barrier / for a row (wall clock)
+  uint64_t rendezvous_ticks;     // bound of the wait for everybody at the start of the launch
 };
 // does k_update_persistent<.., D, S, ..> fit the 160 KB of LDS of a CU?  (its static LDS: the ECDF coarse index, the generator
 // tables, the block reduction, a copy of the control block, the sums)  Shapes that do not keep the launch chain.

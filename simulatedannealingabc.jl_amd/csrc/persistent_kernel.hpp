@@ -82,6 +82,39 @@ __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const uns
   return *stop == 0;
 }
 
+// Before anything is touched: are ALL workgroups of the launch resident?  (They have to be, for the waits below to end -- and on a
+// device shared with other handles' or processes' kernels they may not be: a workgroup that waits for its slot while the others
+// spin.)  Every workgroup announces itself and waits for the others a short bound (PersistArgs::rendezvous_ticks, 20 ms); ONE
+// word decides for everybody, by compare-and-swap: COMMIT by whoever sees the last arrival, ABORT by whoever runs out of time
+// first -- whatever comes first holds, also for workgroups that only become resident after the others have left.  On ABORT
+// nobody has touched a particle or the control block: the launch reports persist_done = -1 and the engine runs the call's
+// remaining updates as the launch chain (engine.cpp), no error.
+__device__ __forceinline__ bool grid_rendezvous(unsigned long long *sync, const int nwg, const uint64_t ticks, int *flag) {
+  if (threadIdx.x == 0) {
+    unsigned long long *arrivals = sync + 2, *decision = sync + 3;
+    __hip_atomic_fetch_add(arrivals, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t t0 = (uint64_t)wall_clock64();
+    unsigned long long d = 0ull;
+    for (uint32_t polls = 1;; ++polls) {
+      d = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d != 0ull) break;
+      const bool all_here = __hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)nwg;
+      const bool late = (polls & 15u) == 0 && (uint64_t)wall_clock64() - t0 > ticks;
+      if (all_here || late) {
+        unsigned long long expected = 0ull;
+        (void)__hip_atomic_compare_exchange_strong(decision, &expected, all_here ? 1ull : 2ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+        d = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *flag = d == 1ull ? 1 : 0;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 // The workgroups' partial rows, exchanged WITHOUT a barrier: a value travels as two 8-byte words, each a half of the double
 // under the update's tag (the low-latency words of the peer-to-peer transport, p2p.hpp) -- an 8-byte store is atomic, so a
 // word whose tag is the awaited one carries its half; nothing has to be ordered against anything.  A workgroup posts its row
@@ -178,7 +211,13 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   __shared__ int stop;
   __shared__ EpsCandidates cand;
   __shared__ double ubar_s[kMaxStats];
-  if (pa.test_absent_wg != 0 && (int)blockIdx.x == pa.test_absent_wg - 1) return;   // (test hook: this workgroup never arrives)
+  if (pa.test_absent_wg < 0 && (int)blockIdx.x == -pa.test_absent_wg - 1) return;   // (test hook: this workgroup never becomes resident)
+  if (!grid_rendezvous(pa.sync, (int)gridDim.x, pa.rendezvous_ticks, &stop)) {
+    if (threadIdx.x == 0) __hip_atomic_store(&cb->persist_done, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (pa.test_absent_wg > 0 && (int)blockIdx.x == pa.test_absent_wg - 1) return;    // (test hook: this workgroup is lost after the rendezvous)
+  __syncthreads();
   rng_tables_load();
   load_coarse_index<S>(cdf, cidx);
   control_load(lcb, cb);

@@ -360,6 +360,12 @@ class SabcHandle:
         generator blocks (<= 2048 | 16 384 particles per launch), 1 = a lane per particle, 0 = none yet."""
         return int(self._L.sabc_persistent_lanes(self._h))
 
+    @property
+    def persistent_fallbacks(self):
+        """One-launch updates that found the device too full for all their workgroups at once and handed the rest of their
+        call to the launch chain (nothing touched, no error)."""
+        return int(self._L.sabc_persistent_fallbacks(self._h))
+
     def profile_enable(self, on=True):
         self._check(self._L.sabc_profile_enable(self._h, int(on)))
 

@@ -820,6 +820,7 @@ int64_t sabc_collective_calls(const sabc_handle *h) { return h->eng->collective_
 int64_t sabc_kernel_launches(const sabc_handle *) { return 0; }
 int64_t sabc_persistent_launches(const sabc_handle *h) { return h->eng->persistent_launches(); }
 int32_t sabc_persistent_lanes(const sabc_handle *h) { return h->eng->persistent_lanes(); }
+int64_t sabc_persistent_fallbacks(const sabc_handle *h) { return h->eng->persistent_fallbacks(); }
 
 // the peer-to-peer entry points, over the in-process emulation above (shards = host threads of this process)
 int sabc_comm_p2p_descriptor(sabc_handle *h, void *out) {

@@ -124,9 +124,46 @@ def test_a_simulator_from_source_takes_the_one_launch_form_too(S, O, gpu, monkey
     assert b["launches"] < a["launches"] and a["quiet"] >= 3 * k and b["quiet"] <= 6, (a["launches"], b["launches"], a["quiet"], b["quiet"])
 
 
-def test_a_workgroup_that_never_arrives_fails_the_call_within_the_bound(S, gpu, monkeypatch):
-    """The grid barrier's wait is bounded like every wait of this library.  Test hook: workgroup 1 of the launch leaves at once,
-    as if it had never become resident (a device full of somebody else's persistent kernels).  The others run into the bound
+def test_a_device_too_full_for_the_launch_hands_the_call_to_the_launch_chain(S, gpu, monkeypatch):
+    """All workgroups of a one-launch update have to be resident at once; on a device shared with other handles' or processes'
+    kernels they may not be.  Before anything is touched they meet at a rendezvous with a short bound; test hook: workgroup 1
+    never shows up.  The others decide ABORT (one word, by compare-and-swap), the launch reports that it has touched nothing,
+    and the engine runs the call as the launch chain: no error, the run of SABC_PERSISTENT=0 bit for bit."""
+    import time
+    name, n, k = "gauss1_cfg2", 2000, 6
+    model, prior = hip_model_prior(S, name)
+
+    def go(absent):
+        if absent:
+            monkeypatch.setenv("SABC_PERSISTENT_TEST_ABSENT_WG", "-2")
+        else:
+            monkeypatch.delenv("SABC_PERSISTENT_TEST_ABSENT_WG", raising=False)
+        h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=SEED)
+        h.initialize((2 * k + 1) * n)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            h.update(n_simulation=k * n, proposal=hip_proposal(S, "de", 1), resample=n // 3)
+        out = (dict(h.counters), h.eps.copy(), [a.copy() for a in h.get_population()], h.persistent_launches, h.persistent_fallbacks,
+               time.perf_counter() - t0)
+        h.close()
+        return out
+
+    monkeypatch.setenv("SABC_PERSISTENT", "0")
+    chain = go(False)
+    monkeypatch.setenv("SABC_PERSISTENT", "1")
+    full = go(True)
+    assert full[3] == 0 and full[4] == 2 and full[5] < 2.0, full[3:]          # one attempt per call, 20 ms each
+    assert full[0] == chain[0]
+    np.testing.assert_array_equal(full[1], chain[1])
+    for a, b in zip(full[2], chain[2]):
+        np.testing.assert_array_equal(a, b)
+    ok = go(False)
+    assert ok[3] > 0 and ok[4] == 0 and ok[0] == chain[0]
+
+
+def test_a_workgroup_that_is_lost_fails_the_call_within_the_bound(S, gpu, monkeypatch):
+    """The waits inside the launch are bounded like every wait of this library.  Test hook: workgroup 1 of the launch leaves right
+    after the rendezvous (every workgroup was resident; one is lost).  The others run into the bound
     (50 ms here), raise the abort flag, and the call returns SABC_ERR_HIP -- nothing hangs; the error contract of sabc_update
     holds (counters, epsilon as at entry; the handle refuses updates until the particles are restored), and after restoring
     them the same handle repeats the call to exactly the run of a fresh handle."""
