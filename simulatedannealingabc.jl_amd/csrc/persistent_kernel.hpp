@@ -39,22 +39,25 @@ __device__ __forceinline__ void mailbox_post(Mailbox *ring, const ControlArgs &a
 // reference's documentation works with (n_particles = 1000, 5000: docs/src/usage.md:39-45, example.md:190-198) the launch
 // chain is half of the time.  Here every workgroup keeps the control block, the ECDF coarse index and the generator tables
 // in LDS for the whole call and loops over the updates itself:
-//   body (k_update's own, update_particle) -> partial row -> GRID BARRIER -> every workgroup sums ALL partial rows in the
-//   same fixed order and runs the control step on its own copy (the same numbers everywhere: nothing to broadcast) -> next
-// -- one exchange of rows per update (and a barrier for DifferentialEvolution / StretchMove, whose second half batch reads what
-// the first wrote in other workgroups), no launch, no host.  Workgroup 0 appends the history rows and writes the control block back
-// at the end.  The loop stops where the host has to act: the resample test of :340 fires (ControlBlock::halt), or an error.
-// Same Philox streams, same per-particle arithmetic, the same control step: the parity suites are the test.
+//   rendezvous (once: is everybody resident?) ->
+//   body (k_update's own, update_particle; a team of 4 or 16 lanes per particle while the device is that empty) -> the
+//   workgroup's partial row -> EXCHANGE of the rows as tagged words -> every workgroup sums ALL rows in the same fixed order and
+//   runs the control step on its own copy (the same numbers everywhere: nothing to broadcast) -> next update
+// -- one exchange per update (and a barrier for DifferentialEvolution / StretchMove, whose second half batch reads what the
+// first wrote in other workgroups), no launch, no host.  Workgroup 0 appends the history rows and writes the control block
+// back at the end.  The loop stops where the host has to act: the resample test of :340 fires (ControlBlock::halt), or an
+// error.  Same Philox streams, same per-particle arithmetic, the same control step: the parity suites are the test.
 //
-// The barrier: an agent-scope release, one atomic increment of a monotone counter, a bounded poll, an agent-scope acquire
-// (the per-XCD L2s are not coherent with each other: what a workgroup on another XCD wrote is visible after its write-back
-// and this one's invalidate).  All workgroups have to be resident at once -- at most one per CU's worth of particles is
-// launched (persistent_workgroups) --; should they not be (a device full of somebody else's persistent kernels) the poll
-// runs into its bound, raises the abort flag for everyone and the call fails with SABC_ERR_HIP instead of hanging.
+// What crosses between workgroups goes past the caches (the per-XCD L2s are not coherent with each other; a fence per update --
+// a write-back and an invalidate of the L2 -- lost from 64 workgroups on): agent-scope loads and stores for the rows, the
+// DifferentialEvolution / StretchMove partners and the accepted particles.  Every wait is bounded: all workgroups have to be
+// resident at once -- at most 256 are launched (persistent_workgroups) --; a device too full for that is found out at the
+// rendezvous, before anything is touched, and the call goes on as the launch chain; a workgroup lost later makes the others'
+// polls run into their bound, raise the abort flag for everyone, and the call fails with SABC_ERR_HIP instead of hanging.
 // ------------------------------------------------------------------------------------------
-// FENCE: the workgroups also exchange PARTICLES through memory (DifferentialEvolution / StretchMove partners): a release
-// before and an acquire after -- a write-back and an invalidate of the XCD's L2.  The partial rows alone need neither: they are
-// written and read with agent-scope accesses, which go past the caches (a RandomWalk update keeps its L2 contents).
+// The counter barrier (between the half batches of DifferentialEvolution / StretchMove): one atomic increment of a monotone
+// counter and a bounded poll.  FENCE (unused since the particles go past the caches): an agent-scope release before and an
+// acquire after.
 template <bool FENCE>
 __device__ __forceinline__ bool grid_barrier(unsigned long long *sync, const unsigned long long target, const uint64_t ticks, int *stop) {
   if (FENCE) __threadfence();                          // release: this thread's stores to the population
@@ -195,8 +198,8 @@ __device__ __forceinline__ bool exchange_rows(unsigned long long *words, const i
   return *stop == 0;
 }
 
-// LANES = 4: a particle per QUAD of lanes (update_particle) -- four times the waves, each with a chain of generator blocks a
-// quarter as long; chosen while the device has the idle SIMDs for it (kernels.hip: persistent_lanes).
+// LANES = 4 | 16: a particle per TEAM of lanes (update_particle) -- that many times the waves, each with a chain of generator
+// blocks that much shorter; chosen while the device has the idle SIMDs for it (kernels.hip: persistent_workgroups).
 template <int MODEL, int D, int S, int PROP, int LANES = 1>
 __global__ void __launch_bounds__(update_block_threads(S))
 k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, const PopPtrs pp, const CdfPtrs cdf, const PartnerView pv_a,
