@@ -27,16 +27,19 @@ SABC_HD inline void control_take_sum(ControlBlock &cb, const ControlArgs &a, con
   cb.sums[q] = delta ? cb.sums[q] + sums_in[q] : sums_in[q];
 }
 
-// returns false when the step was a no-op (guarded and halted): nothing must be posted then
-// `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
-// control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
+// The step in two parts, so that k_update_persistent can start the next update's proposals and simulations as soon as the FIRST
+// is done (what they need of the state is the Cholesky factor) while one lane still works on the SECOND (persistent_kernel.hpp:
+// the control wave).  control_step() below is the two in sequence: the launch chain, the host engine and the tests call that.
+//
 // DD, SS: the shape as compile-time constants where the caller has them (k_update_persistent: the offsets into the sums are then
 // constants, the loops straight-line code and the d == 1 branch the only one compiled -- the step is a chain of dependent LDS
 // round trips on one lane, and every address the compiler can resolve is one it can batch); 0: from the arguments
+enum ControlFirst : int { CONTROL_NOOP = 0, CONTROL_HALTED = 1, CONTROL_GOES_ON = 2 };
+
+// the sums taken over, the accept count (:334), the resample test (:340), the proposal's covariance (update_proposal!, :348)
 template <int DD = 0, int SS = 0>
-SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in,
-                                 const EpsCandidates *pre = nullptr) {
-  if ((a.mode & CTRL_GUARDED) && cb.halt) return false;
+SABC_HD inline ControlFirst control_step_first(ControlBlock &cb, const ControlArgs &a, const double *sums_in) {
+  if ((a.mode & CTRL_GUARDED) && cb.halt) return CONTROL_NOOP;
   if (a.mode & CTRL_CLEAR_HALT) cb.halt = 0;
   const int d = DD > 0 ? DD : a.d, s = SS > 0 ? SS : a.s;
   if (!(a.mode & CTRL_KEEP_SUMS))
@@ -52,7 +55,7 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
   // the host has run the resample and cleared the flag
   if ((a.mode & CTRL_CHECK) && (double)cb.n_accept >= a.resample_threshold) {
     cb.halt = 1;
-    return true;
+    return CONTROL_HALTED;
   }
 
   if ((a.mode & CTRL_PROPOSAL) && a.prop_kind == SABC_PROP_RANDOMWALK && d >= 2 && d <= 4) {
@@ -76,10 +79,19 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
       if (!hostmath::cholesky(cb.sigma, d, cb.chol)) cb.error = SABC_ERR_NOT_POSDEF;   // MvNormal(...), :42
     }
   }
-
   SABC_CTRL_MARK(10);
+  return CONTROL_GOES_ON;
+}
+
+// epsilon (:350-354), the history row (:367-372), the pivot of the moment sums.  pre (valid iff pre_valid): the multi-eps
+// schedule's candidates, computed ahead by one lane per statistic
+template <int DD = 0, int SS = 0>
+SABC_HD inline void control_step_second(ControlBlock &cb, const ControlArgs &a, double *hist, const EpsCandidates *pre, const bool pre_valid) {
+  const int d = DD > 0 ? DD : a.d, s = SS > 0 ? SS : a.s;
+  const double n = a.n_global;
+  const double *S = &cb.sums[1 + 2 * s];
   if (a.mode & CTRL_EPSILON) {                                                       // :350-354
-    if (a.algorithm == SABC_ALG_MULTI_EPS && pre) {
+    if (a.algorithm == SABC_ALG_MULTI_EPS && pre_valid) {
       for (int j = 0; j < s; ++j) {                  // (a failing statistic stops the schedule where eps_multi would have)
         if (!pre->ok[j]) { cb.error = SABC_ERR_ZERO_MEAN_U; break; }                 // :107-109
         cb.eps[j] = pre->eps[j];
@@ -118,6 +130,18 @@ SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double 
   // keep the moment sums centred: the sums in hand are relative to the old pivot, so this goes last
   if (a.mode & CTRL_PIVOT)
     for (int k = 0; k < d; ++k) cb.pivot[k] += S[k] / n;
+}
+
+// returns false when the step was a no-op (guarded and halted): nothing must be posted then
+// `sums_in` is the staging buffer the reduction (and the allreduce) wrote; it is taken over into the
+// control block only by a step that really runs, so the collectives of an aborted step cannot touch state.
+template <int DD = 0, int SS = 0>
+SABC_HD inline bool control_step(ControlBlock &cb, const ControlArgs &a, double *hist, const double *sums_in,
+                                 const EpsCandidates *pre = nullptr, const bool pre_valid = true) {
+  const ControlFirst r = control_step_first<DD, SS>(cb, a, sums_in);
+  if (r == CONTROL_NOOP) return false;
+  if (r == CONTROL_HALTED) return true;
+  control_step_second<DD, SS>(cb, a, hist, pre, pre != nullptr && pre_valid);
   return true;
 }
 

@@ -234,8 +234,12 @@ __device__ __forceinline__ double cdf_apply_3level(const double *__restrict__ T,
 // A table that fits the coarse level whole (shift = 0: C[k] = T[k], +inf behind len -- populations of up to ~1000 particles with
 // one statistic, ~2000 with more): the lookup never leaves LDS.  The same steps as cdf_apply_3level at shift = 0 (its second and
 // third level are empty there), the same interpolation on the same knots: the same u.  (k_update_persistent only.)
+// (the table is addressed as LDS explicitly: where the optimiser merges this lookup's tail with cdf_apply_3level's -- the same
+// interpolation on knots from memory -- a pointer that is "LDS or memory" would need an aperture test per load)
+typedef const __attribute__((address_space(3))) double *lds_knots_ptr;
 template <int COARSE>
-__device__ __forceinline__ double cdf_apply_lds(const double *C, const int64_t len, const double x) {
+__device__ __forceinline__ double cdf_apply_lds(const double *C_generic, const int64_t len, const double x) {
+  const lds_knots_ptr C = (lds_knots_ptr)C_generic;
   const double first = C[0], last = C[len - 1];
   int c = 0;                               // c = #knots < x
 #pragma unroll
@@ -270,7 +274,11 @@ __device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, co
   const bool lds_knots = same && cdf.shift[0] == 0;                   // (the tables fit the coarse level whole: cdf_apply_lds)
   if (lds_knots) {                                                    // (two loops, not a select: no LDS-or-memory pointer)
 #pragma unroll
-    for (int j = 0; j < S; ++j) { first[j] = C[j][0]; last[j] = C[j][cdf.len[j] - 1]; }
+    for (int j = 0; j < S; ++j) {
+      const lds_knots_ptr Cj = (lds_knots_ptr)&C[j][0];
+      first[j] = Cj[0];
+      last[j] = Cj[cdf.len[j] - 1];
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < S; ++j) { first[j] = T[j][0]; last[j] = T[j][cdf.len[j] - 1]; }
@@ -329,8 +337,9 @@ __device__ __forceinline__ void cdf_apply_3level_lockstep(const CdfPtrs &cdf, co
     const int64_t lo = c[j] > 0 ? a[j] + 1 : 0;
     i0[j] = lo > 0 ? lo - 1 : 0;
     if (lds_knots) {
-      k0[j] = C[j][i0[j]];
-      k1[j] = C[j][i0[j] + 1 < COARSE ? i0[j] + 1 : COARSE - 1];
+      const lds_knots_ptr Cj = (lds_knots_ptr)&C[j][0];
+      k0[j] = Cj[i0[j]];
+      k1[j] = Cj[i0[j] + 1 < COARSE ? i0[j] + 1 : COARSE - 1];
     } else {
       k0[j] = T[j][i0[j]];
       k1[j] = T[j][i0[j] + 1];

@@ -620,7 +620,7 @@ __device__ __forceinline__ void control_on_copy(ControlBlock &lcb, int &ran, Con
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) ran = control_step(lcb, a_step, hist, sums, multi ? &cand : nullptr) ? 1 : 0;
+  if (threadIdx.x == 0) ran = control_step(lcb, a_step, hist, sums, &cand, multi) ? 1 : 0;
   __syncthreads();
   if (!ran) {                               // guarded and halted: nothing changed
     // ... and nothing is posted, unless the halt is a peer-to-peer wait that gave up (p2p.hpp): the host is waiting for
@@ -1741,7 +1741,8 @@ int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, 
   }
   if (!persistent_fits(m.d, m.s)) return 0;
   const int64_t per_launch = prop_kind == SABC_PROP_RANDOMWALK ? act_n : act_n - act_n / 2;     // the larger half batch
-  const int64_t thin = B < 256 ? B : 256;              // a wave per SIMD
+  // a wave per SIMD at most, and one wave of the workgroup without particles: the control wave (persistent_kernel.hpp)
+  const int64_t thin = B - 64 < 256 ? B - 64 : 256;
   const int want = persist_lanes_env();
   const bool may16 = have16 && (want == 16 || (want == 0 && per_launch <= persist_team_max_particles(16)));
   const bool may4 = have4 && (want == 4 || want == 16 || (want == 0 && per_launch <= persist_team_max_particles(4)));
@@ -1768,7 +1769,7 @@ extern "C" __attribute__((visibility("default"))) int sabc_debug_persist_trace(u
 // the most workgroups a persistent launch over a shard of at most `cap` particles can have (sizes the partial rows)
 int64_t persistent_workgroups_bound(const ModelDesc &m, int64_t cap) {
   if (!persistent_fits(m.d, m.s)) return 0;
-  const int64_t A = update_block_threads(m.s) < 256 ? update_block_threads(m.s) : 256, wg16 = (16 * cap + A - 1) / A;
+  const int64_t A = update_block_threads(m.s) - 64 < 256 ? update_block_threads(m.s) - 64 : 256, wg16 = (16 * cap + A - 1) / A;
   return wg16 < persist_max_workgroups() ? wg16 : persist_max_workgroups();
 }
 
@@ -1780,6 +1781,7 @@ int launch_update_persistent(const ModelDesc &m, int prop_kind, const PersistArg
   if (wg <= 0) return (int)hipErrorInvalidValue;
   PersistArgs pa = pa_in;
   pa.active = active;
+  pa.ctrl_wave = active < (int)update_block_threads(m.s) ? active / 64 : -1;
   const dim3 grid((unsigned)wg), block((unsigned)update_block_threads(m.s));
   if (m.model_id == SABC_MODEL_USER)
     return module_launch(lanes == 16 ? rtc->persistent16[prop_kind] : lanes == 4 ? rtc->persistent4[prop_kind] : rtc->persistent[prop_kind], grid.x, block.x, stream, nullptr, nullptr, m, pa,

@@ -93,7 +93,9 @@ struct PersistArgs {
   int64_t act_n, half;           // particles of the shard; size of the first half batch (DifferentialEvolution / StretchMove)
   int32_t count;                 // updates to run (the launch stops early when the resample test fires or an error is raised)
   int32_t test_absent_wg;        // test hook: k > 0: workgroup k - 1 is lost after the rendezvous; k < 0: workgroup -k - 1 never becomes resident
-  int32_t active, pad_;          // threads of a workgroup that carry particles (a multiple of 64 <= the block: persistent_workgroups)
+  int32_t active;                // threads of a workgroup that carry particles (a multiple of 64 <= the block: persistent_workgroups)
+  int32_t ctrl_wave;             // the wave without particles whose first lane runs the control step beside the next update's drafts
+                                 // (= active / 64), or -1: every wave carries particles, wave 0 runs the step between two updates
   double prop_p0, prop_p1;
   ControlArgs ctrl;              // the control step of every update: ACCUMULATE | CHECK | PROPOSAL | EPSILON | PIVOT (history by cadence)
   unsigned long long *sync;      // [0] arrivals at the grid barrier (monotone), [1] abort flag, [2] arrivals at the rendezvous, [3] its decision
@@ -120,8 +122,8 @@ int launch_update(const ModelDesc &m, const StepArgs &c, const ControlBlock *cb,
                   int64_t act_lo, int64_t act_n, double *partials, int64_t row0, hipStream_t stream,
                   hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const RtcKernels *rtc = nullptr);
 // workgroups of the launch (all of them have to be resident at once) or 0 when this model / shape has no persistent form
-// (*lanes_out: lanes per particle of that launch, 1 or 4; *active_out: threads of a workgroup that carry particles --
-// kernels.hip: persistent_workgroups)
+// (*lanes_out: lanes per particle of that launch, 1, 4 or 16; *active_out: threads of a workgroup that carry particles, fewer than
+// the block where the launch can spare a wave for the control step -- kernels.hip: persistent_workgroups)
 int64_t persistent_workgroups(const ModelDesc &m, int prop_kind, int64_t act_n, const RtcKernels *rtc = nullptr, int *lanes_out = nullptr,
                               int *active_out = nullptr);
 int64_t persistent_workgroups_bound(const ModelDesc &m, int64_t cap);

@@ -211,7 +211,7 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   __shared__ double sums[kMaxPartials];
   __shared__ double sm[B];
   __shared__ double my_row[NP];
-  __shared__ int stop;
+  __shared__ int stop, first;
   __shared__ EpsCandidates cand;
   __shared__ double ubar_s[kMaxStats];
   if (pa.test_absent_wg < 0 && (int)blockIdx.x == -pa.test_absent_wg - 1) return;   // (test hook: this workgroup never becomes resident)
@@ -232,6 +232,21 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   // wave per SIMD) while the workgroups fit the launch; the other waves only take part in the barriers and the sums
   const bool carries = (int)threadIdx.x < pa.active;
   const int64_t t = ((int64_t)blockIdx.x * pa.active + threadIdx.x) / LANES;
+  // THE CONTROL WAVE.  What the next update's proposals and simulations need of the state between two updates is the Cholesky
+  // factor alone (RandomWalk; DifferentialEvolution / StretchMove: nothing) -- epsilon and the pivot only enter where the
+  // acceptance is decided.  Where the launch can spare a wave without particles (pa.ctrl_wave >= 0: persistent_workgroups), its
+  // first lane runs the step's second part -- the root solve for epsilon, the history row, the pivot: a chain of dependent
+  // divisions on one lane, 1-1.5 us -- WHILE the other waves draft the next update (update_particle_draft); a draft made for an
+  // update that does not happen (the resample test fired, an error) is dropped: it has touched nothing.  Otherwise wave 0 runs
+  // the whole step and nothing is drafted ahead.
+  const bool overlap = pa.ctrl_wave >= 0;
+  const int ctrl_wave = overlap ? pa.ctrl_wave : 0;
+  const bool on_ctrl_wave = (int)(threadIdx.x >> 6) == ctrl_wave;
+  const int ctrl_lane = (int)threadIdx.x - ctrl_wave * 64;                 // (0..63 on the control wave)
+  const bool first_live = carries && t < (PROP == SABC_PROP_RANDOMWALK ? pa.act_n : pa.half);
+  constexpr bool kPast = PROP != SABC_PROP_RANDOMWALK;                      // (partners / accepted particles past the caches)
+  ParticleDraft<D, S> q;                               // the (first half batch's) draft of the update at hand, if made ahead
+  bool have_draft = false;                             // (uniform)
   unsigned long long target = 0;
   int done = 0;
   bool barrier_failed = __hip_atomic_load(&pa.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;   // (uniform)
@@ -239,13 +254,15 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     const uint64_t iter = pa.iter0 + (uint64_t)u;
     double acc[NP];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) acc[q] = 0.0;
+    for (int i = 0; i < NP; ++i) acc[i] = 0.0;
     SABC_TRACE(iter, 0);
-    if (PROP == SABC_PROP_RANDOMWALK) {
-      // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
-      if (carries && t < pa.act_n) update_particle<MODEL, D, S, PROP, false, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
-    } else {
-      if (carries && t < pa.half) update_particle<MODEL, D, S, PROP, true, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_a, cidx, t, (uint64_t)(pp.gid0 + t), acc);
+    // RandomWalk ignores the inactive half (proposals.jl:40,52): one pass over the shard is the same update (engine.cpp)
+    if (first_live) {
+      if (!have_draft) update_particle_draft<MODEL, D, S, PROP, kPast, LANES>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, pv_a, t, (uint64_t)(pp.gid0 + t), q);
+      update_particle_decide<D, S, kPast, LANES, true>(m, iter, &lcb, pp, cdf, cidx, t, (uint64_t)(pp.gid0 + t), q, acc);
+    }
+    have_draft = false;
+    if (PROP != SABC_PROP_RANDOMWALK) {
       // half batch B reads what half batch A wrote -- in every workgroup (:300-304); the particles other workgroups read go past
       // the caches (update_kernel.hpp: PAST_CACHES), so the barrier needs no fence
       target += (unsigned long long)nwg;
@@ -253,10 +270,10 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
       const int64_t li = pa.half + t;
       double acc_b[NP];                                // (update_particle ASSIGNS a particle's moment terms)
 #pragma unroll
-      for (int q = 0; q < NP; ++q) acc_b[q] = 0.0;
+      for (int i = 0; i < NP; ++i) acc_b[i] = 0.0;
       if (carries && li < pa.act_n) update_particle<MODEL, D, S, PROP, true, LANES, true>(m, iter, pa.prop_p0, pa.prop_p1, &lcb, pp, cdf, pv_b, cidx, li, (uint64_t)(pp.gid0 + li), acc_b);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) acc[q] += acc_b[q];
+      for (int i = 0; i < NP; ++i) acc[i] += acc_b[i];
     }
     // one partial row per workgroup, double-buffered by the update's parity: a workgroup that is ahead posts the row of update
     // u + 1 while a slow one still polls those of update u (it cannot get two ahead: the rows of u + 1 need everybody's)
@@ -269,7 +286,6 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     if (PROP != SABC_PROP_RANDOMWALK) __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     SABC_TRACE(iter, 2);
-    SABC_TRACE(iter, 3);
     // the control step (control.hpp) on this workgroup's copy of the control block; the history cadence of engine.cpp
     ControlArgs a = pa.ctrl;
     a.notify_seq = 0;
@@ -277,24 +293,31 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     if (!exchange_rows<NP, B>(rows, nwg, my_row, (uint32_t)u + 1u, sm, sums, pa.sync, pa.timeout_ticks, &stop, lcb, a)) { barrier_failed = true; break; }
     SABC_TRACE(iter, 4);
     a.mode |= CTRL_KEEP_SUMS;
+    // first part: accept count, resample test, the proposal's covariance
+    if (on_ctrl_wave && ctrl_lane == 0) first = (int)control_step_first<D, S>(lcb, a, sums);
+    __syncthreads();
     SABC_TRACE(iter, 11);
-    const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
-    if (multi) {
-      if ((int)threadIdx.x < a.s) ubar_s[threadIdx.x] = lcb.sums[1 + threadIdx.x] / a.n_global;
-      __syncthreads();
-      if ((int)threadIdx.x < a.s) {
-        const int i = threadIdx.x;
-        cand.ok[i] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), i, &cand.eps[i]) ? 1 : 0;
+    done = u + 1;
+    if (first != (int)CONTROL_GOES_ON) break;          // the resample test fired (:340): the host's turn
+    // second part on the control wave; the others draft update u + 1 meanwhile (when there is one, and nothing has gone wrong)
+    const bool ahead = overlap && lcb.error == 0 && u + 1 < pa.count;
+    if (on_ctrl_wave) {
+      const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
+      if (multi) {                                     // (one lane per statistic, all on this wave: s <= 64)
+        if (ctrl_lane < a.s) ubar_s[ctrl_lane] = lcb.sums[1 + ctrl_lane] / a.n_global;
+        __builtin_amdgcn_wave_barrier();
+        if (ctrl_lane < a.s) cand.ok[ctrl_lane] = hostmath::eps_multi_one(ubar_s, a.s, a.v, hostmath::eps_multi_cn(a.s), ctrl_lane, &cand.eps[ctrl_lane]) ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();
+      SABC_TRACE(iter, 12);
+      if (ctrl_lane == 0) control_step_second<D, S>(lcb, a, blockIdx.x == 0 ? hist : nullptr, &cand, multi);
+      SABC_TRACE(iter, 13);
     }
-    SABC_TRACE(iter, 12);
-    if (threadIdx.x == 0) (void)control_step<D, S>(lcb, a, blockIdx.x == 0 ? hist : nullptr, sums, multi ? &cand : nullptr);
-    SABC_TRACE(iter, 13);
+    if (ahead && first_live) update_particle_draft<MODEL, D, S, PROP, kPast, LANES>(m, iter + 1, pa.prop_p0, pa.prop_p1, &lcb, pp, pv_a, t, (uint64_t)(pp.gid0 + t), q);
+    have_draft = ahead;
     __syncthreads();
     SABC_TRACE(iter, 5);
-    done = u + 1;
-    if (lcb.halt || lcb.error) break;                  // the resample test fired (:340), or the step raised an error: the host's turn
+    if (lcb.halt || lcb.error) break;                  // the step raised an error: the host's turn
   }
   if (blockIdx.x == 0) {
     __syncthreads();

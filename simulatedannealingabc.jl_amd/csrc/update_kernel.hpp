@@ -144,25 +144,32 @@ __device__ __forceinline__ void particle_store(double *p, double v) {
 // NormalStream, coop); the team's first lane alone writes the particle back and reports its moment terms.
 // LATENCY (k_update_persistent): the wave has its SIMD to itself -- the ECDF lookups of the S statistics step together
 // (device_models.hpp: cdf_apply_3level_lockstep) instead of one after the other.
-template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, bool LATENCY = false, class CB>
-__device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
-                                                const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
-                                                const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
-                                                double (&acc)[n_partials(D, S)]) {
-  constexpr int kCoarse = cdf_coarse_entries(S);
+// The body in two halves, so that k_update_persistent can run the first of the NEXT update while one lane still solves for this
+// update's epsilon (persistent_kernel.hpp: the control wave): what a particle's proposal and simulation need of the algorithm's
+// state is the Cholesky factor alone (RandomWalk) -- epsilon and the pivot only enter where the acceptance is decided.
+template <int D, int S>
+struct ParticleDraft {
+  double th[D], u[S];            // the particle as it stands
+  double thp[D], rp[S];          // its proposal and the proposal's simulated distances (0 outside the prior's support)
+  double logf, lpp;              // log of the proposal's density ratio (StretchMove), log prior of the proposal
+};
+
+// loads, proposal (:311), prior gate and simulation (:314-315)
+template <int MODEL, int D, int S, int PROP, bool PAST_CACHES, int LANES, class CB>
+__device__ __forceinline__ void update_particle_draft(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
+                                                      const CB *__restrict__ cb, const PopPtrs &pp, const PartnerView &pv, const int64_t li,
+                                                      const uint64_t gid, ParticleDraft<D, S> &q) {
   // rho is NOT read here: an update step reports the CHANGE of sum(rho) (rho' - rho of the accepted particles, read where
   // they are overwritten); the control step adds it to the running sum (ControlArgs::rho_is_delta).  8 s n bytes less
   // read per launch: the old distance of a particle that is not accepted is never needed.
-  double th[D], u[S], drho[S];
 #pragma unroll
-  for (int k = 0; k < D; ++k) th[k] = pp.pop[(int64_t)k * pp.cap + li];
+  for (int k = 0; k < D; ++k) q.th[k] = pp.pop[(int64_t)k * pp.cap + li];
 #pragma unroll
-  for (int j = 0; j < S; ++j) { u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li]; drho[j] = 0.0; }
+  for (int j = 0; j < S; ++j) q.u[j] = pp.pop[(int64_t)(D + j) * pp.cap + li];
 
   SABC_TRACE(iter, 6);
   // ---- proposal (:311) ----
-  double thp[D];
-  double logf = 0.0;
+  q.logf = 0.0;
   if (PROP == SABC_PROP_RANDOMWALK) {            // proposals.jl:40-43,52-55: theta + L z
     NormalStream ns(m.seed, gid, PURPOSE_PROP, iter, LANES > 1 ? LANES : 0);
     double z[D];
@@ -173,7 +180,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
       double a = 0.0;
 #pragma unroll
       for (int l = 0; l <= k; ++l) a += cb->chol[k * D + l] * z[l];
-      thp[k] = th[k] + a;
+      q.thp[k] = q.th[k] + a;
     }
   } else if (PROP == SABC_PROP_DIFFEVO) {        // proposals.jl:101-114
     uint64_t i1 = 0, i2 = 0;
@@ -189,7 +196,7 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
     const double *p1 = partner_ptr(pv, i1), *p2 = partner_ptr(pv, i2);
 #pragma unroll
     for (int k = 0; k < D; ++k)
-      thp[k] = th[k] + gamma * (particle_load<PAST_CACHES>(p1 + (int64_t)k * pv.cap) - particle_load<PAST_CACHES>(p2 + (int64_t)k * pv.cap));
+      q.thp[k] = q.th[k] + gamma * (particle_load<PAST_CACHES>(p1 + (int64_t)k * pv.cap) - particle_load<PAST_CACHES>(p2 + (int64_t)k * pv.cap));
   } else {                                       // StretchMove, proposals.jl:137-148
     const u32x4 w = stream_block(m.seed, gid, PURPOSE_PROP, iter, 0);
     const uint64_t ip = mulhi64(pack64(w.x, w.y), (uint64_t)pv.m_total);   // :141
@@ -201,35 +208,47 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       const double pk = particle_load<PAST_CACHES>(p + (int64_t)k * pv.cap);
-      thp[k] = pk + z * (th[k] - pk);                                      // :147
+      q.thp[k] = pk + z * (q.th[k] - pk);                                  // :147
     }
-    logf = log(z) * (double)(D - 1);                                       // :146
+    q.logf = log(z) * (double)(D - 1);                                     // :146
   }
 
   SABC_TRACE(iter, 7);
-  // ---- acceptance probability (:314-322) ----
-  const double lpp = prior_logpdf<D>(m, thp);
-  double log_accept = -INFINITY;
-  double up[S], rp[S];
+  // ---- the prior's gate and the simulation (:314-315) ----
+  q.lpp = prior_logpdf<D>(m, q.thp);
 #pragma unroll
-  for (int j = 0; j < S; ++j) { up[j] = 0.0; rp[j] = 0.0; }
-  if (lpp > -INFINITY) {
-    if (LANES > 1) Sim<MODEL, D, S>::run(m, thp, gid, iter, rp, LANES);    // :315
-    else Sim<MODEL, D, S>::run(m, thp, gid, iter, rp);
-    SABC_TRACE(iter, 8);
+  for (int j = 0; j < S; ++j) q.rp[j] = 0.0;
+  if (q.lpp > -INFINITY) {
+    if (LANES > 1) Sim<MODEL, D, S>::run(m, q.thp, gid, iter, q.rp, LANES);    // :315
+    else Sim<MODEL, D, S>::run(m, q.thp, gid, iter, q.rp);
+  }
+  SABC_TRACE(iter, 8);
+}
+
+// ECDF transform, acceptance probability (:316-322), accept / store (:324-329), the particle's moment terms
+template <int D, int S, bool PAST_CACHES, int LANES, bool LATENCY, class CB>
+__device__ __forceinline__ void update_particle_decide(const ModelDesc &m, const uint64_t iter, const CB *__restrict__ cb, const PopPtrs &pp,
+                                                       const CdfPtrs &cdf, const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li,
+                                                       const uint64_t gid, ParticleDraft<D, S> &q, double (&acc)[n_partials(D, S)]) {
+  constexpr int kCoarse = cdf_coarse_entries(S);
+  double log_accept = -INFINITY;
+  double up[S], drho[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) { up[j] = 0.0; drho[j] = 0.0; }
+  if (q.lpp > -INFINITY) {
     double a = 0.0;
-    if (LATENCY && S >= 2) cdf_apply_3level_lockstep<S, kCoarse>(cdf, cidx, rp, up);                         // :316
+    if (LATENCY && S >= 2) cdf_apply_3level_lockstep<S, kCoarse>(cdf, cidx, q.rp, up);                       // :316
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       if (LATENCY && S == 1 && cdf.shift[0] == 0)
-        up[j] = cdf_apply_lds<kCoarse>(cidx[j], cdf.len[j], rp[j]);                                           // :316
+        up[j] = cdf_apply_lds<kCoarse>(cidx[j], cdf.len[j], q.rp[j]);                                         // :316
       else if (!(LATENCY && S >= 2))
         up[j] = cdf_apply_3level<kCoarse>(cdf.knots + (int64_t)j * cdf.stride, cdf.len[j], cdf.shift[j], cidx[j],
-                                 cdf.mid + (int64_t)j * cdf.mid_stride, rp[j]);                               // :316
+                                 cdf.mid + (int64_t)j * cdf.mid_stride, q.rp[j]);                             // :316
       const double e = (cb->eps_len == 1) ? cb->eps[0] : cb->eps[j];
-      a += (u[j] - up[j]) / e;                                             // :319
+      a += (q.u[j] - up[j]) / e;                                           // :319
     }
-    log_accept = lpp - prior_logpdf<D>(m, th) + a + logf;                  // :318-319
+    log_accept = q.lpp - prior_logpdf<D>(m, q.th) + a + q.logf;            // :318-319
   }
 
   SABC_TRACE(iter, 9);
@@ -239,27 +258,37 @@ __device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64
   const bool writer = LANES == 1 || (threadIdx.x & (LANES - 1)) == 0;
   if (accepted) {
 #pragma unroll
-    for (int j = 0; j < S; ++j) drho[j] = rp[j] - pp.rho[(int64_t)j * pp.cap + li];
+    for (int j = 0; j < S; ++j) drho[j] = q.rp[j] - pp.rho[(int64_t)j * pp.cap + li];
 #pragma unroll
-    for (int k = 0; k < D; ++k) th[k] = thp[k];
+    for (int k = 0; k < D; ++k) q.th[k] = q.thp[k];
 #pragma unroll
-    for (int j = 0; j < S; ++j) u[j] = up[j];
+    for (int j = 0; j < S; ++j) q.u[j] = up[j];
     if (writer) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) particle_store<PAST_CACHES>(pp.pop + (int64_t)k * pp.cap + li, thp[k]);   // (partners read theta)
+      for (int k = 0; k < D; ++k) particle_store<PAST_CACHES>(pp.pop + (int64_t)k * pp.cap + li, q.thp[k]);   // (partners read theta)
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         pp.pop[(int64_t)(D + j) * pp.cap + li] = up[j];
-        pp.rho[(int64_t)j * pp.cap + li] = rp[j];
+        pp.rho[(int64_t)j * pp.cap + li] = q.rp[j];
       }
     }
   }
   SABC_TRACE(iter, 10);
-  moment_terms<D, S>(cb->pivot, accepted, th, u, drho, acc);
+  moment_terms<D, S>(cb->pivot, accepted, q.th, q.u, drho, acc);
   if (!writer) {
 #pragma unroll
-    for (int q = 0; q < n_partials(D, S); ++q) acc[q] = 0.0;
+    for (int q2 = 0; q2 < n_partials(D, S); ++q2) acc[q2] = 0.0;
   }
+}
+
+template <int MODEL, int D, int S, int PROP, bool PAST_CACHES = false, int LANES = 1, bool LATENCY = false, class CB>
+__device__ __forceinline__ void update_particle(const ModelDesc &m, const uint64_t iter, const double prop_p0, const double prop_p1,
+                                                const CB *__restrict__ cb, const PopPtrs &pp, const CdfPtrs &cdf, const PartnerView &pv,
+                                                const double (&cidx)[S][cdf_coarse_entries(S)], const int64_t li, const uint64_t gid,
+                                                double (&acc)[n_partials(D, S)]) {
+  ParticleDraft<D, S> q;
+  update_particle_draft<MODEL, D, S, PROP, PAST_CACHES, LANES>(m, iter, prop_p0, prop_p1, cb, pp, pv, li, gid, q);
+  update_particle_decide<D, S, PAST_CACHES, LANES, LATENCY>(m, iter, cb, pp, cdf, cidx, li, gid, q, acc);
 }
 
 template <int MODEL, int D, int S, int PROP>

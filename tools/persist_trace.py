@@ -28,9 +28,10 @@ try:
         rc = lib.sabc_debug_persist_trace(buf)
         t = np.array(buf, dtype=np.float64).reshape(64, 16) * 0.01      # us, row = iter % 64
         t = t[np.argsort(t[:, 0])][-30:]                                # the last 30 updates, in time order
-        seq = [0, 6, 7, 8, 9, 10, 1, 2, 3, 4, 11, 12, 13, 5]
-        names = ["loads issued", "proposal", "prior+simulate", "ecdf+log alpha", "accept+store", "moments", "reduce", "(post)", "row exchange",
-                 "take sums", "multi-eps lanes", "control step", "publish"]
+        # (with a control wave the next update's proposal and simulation are drafted beside the step's second part: stamps 6-8 of
+        # an update fall into the previous one's tail, 12-13 are the control wave's -- not thread 0's)
+        seq = [0, 9, 10, 1, 2, 4, 11, 5]
+        names = ["ecdf+log alpha", "accept+store", "moments", "reduce", "row exchange", "control, first part", "draft of the next || second part"]
         d = np.diff(t[:, seq], axis=1)
         med = np.median(d, axis=0)
         print(f"n {n} {prop} {name} lanes {lanes}: " + "  ".join(f"{nm} {v:.2f}" for nm, v in zip(names, med)) +
