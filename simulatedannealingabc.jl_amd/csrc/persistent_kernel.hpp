@@ -239,7 +239,10 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
   // divisions on one lane, 1-1.5 us -- WHILE the other waves draft the next update (update_particle_draft); a draft made for an
   // update that does not happen (the resample test fired, an error) is dropped: it has touched nothing.  Otherwise wave 0 runs
   // the whole step and nothing is drafted ahead.
-  const bool overlap = pa.ctrl_wave >= 0;
+  // (DifferentialEvolution / StretchMove with two or more statistics: 512-thread workgroups, 256 registers a wave -- a draft kept
+  // across the second half batch's body would live in scratch memory; they run the step between two updates as before)
+  constexpr bool kDraftsAhead = PROP == SABC_PROP_RANDOMWALK || S == 1;
+  const bool overlap = kDraftsAhead && pa.ctrl_wave >= 0;
   const int ctrl_wave = overlap ? pa.ctrl_wave : 0;
   const bool on_ctrl_wave = (int)(threadIdx.x >> 6) == ctrl_wave;
   const int ctrl_lane = (int)threadIdx.x - ctrl_wave * 64;                 // (0..63 on the control wave)
