@@ -1,6 +1,7 @@
 // engine.cpp -- see engine.hpp.  Line references are to the reference checkout
 // (src/SimulatedAnnealingABC.jl unless a file is named).
 #include "engine.hpp"
+#include <chrono>
 
 #include <cmath>
 #include <cstdio>
@@ -597,7 +598,10 @@ int Engine::update_loop_persistent(const sabc_update_args &a, int64_t n_pop, int
       return fail(SABC_ERR_HIP, "persistent update kernel failed");
     host_syncs_ += 1;
     if (done == -1) {
+      // (a launch that left at its rendezvous has kept the workgroups that did arrive waiting for the bound: on a device that
+      // stays full, calls of a few updates each -- a wrapper's progress chunks -- would pay it every time.  Ten bounds' pause.)
       persistent_fallbacks_ += 1;
+      persistent_retry_at_ = std::chrono::steady_clock::now() + std::chrono::milliseconds(200);
       *next_ix = ix;
       return 0;
     }
@@ -728,7 +732,8 @@ int Engine::update_loop(const sabc_update_args &a) {
   // Small shards with a device-coded simulator: the whole loop of :294-375 in ONE launch per stretch between two resamples
   // (kernels.hip: k_update_persistent) instead of a chain of launches per update
   int64_t first_ix = 1;                                                     // the launch chain's first update of the call
-  if (n_pop > 0 && !host_mode_ && sh_.world == 1 && be_->persistent_supported(a.proposal_kind)) {
+  if (n_pop > 0 && !host_mode_ && sh_.world == 1 && be_->persistent_supported(a.proposal_kind) &&
+      std::chrono::steady_clock::now() >= persistent_retry_at_) {
     if ((rc = update_loop_persistent(a, n_pop, cph, phase, &first_ix))) return rc;
   }
   if (first_ix <= n_pop) {

@@ -7,6 +7,7 @@
 //                   to exercise this file without a GPU);
 //   Collectives  -- allreduce / allgather across shards (one process per GPU).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -222,6 +223,7 @@ class Engine {
   int64_t cdf_len_[kMaxStats] = {0};
   int64_t n_simulation_ = 0, n_resampling_ = 0, n_population_updates_ = 0;
   int64_t host_syncs_ = 0, notify_seq_ = 0, comm_bytes_ = 0, collective_calls_ = 0, p2p_fallbacks_ = 0, persistent_launches_ = 0, persistent_fallbacks_ = 0;
+  std::chrono::steady_clock::time_point persistent_retry_at_{};    // no one-launch update before this (after one that found the device too full)
   ControlArgs control_args(int32_t mode, const sabc_update_args *a, double v, double threshold) const;
   int p2p_check_peers();                            // p2p: a peer has left the group? (entry of a call, nothing launched yet)
   int p2p_commit_ok();                              // p2p: the end-of-call status exchange (success path)
