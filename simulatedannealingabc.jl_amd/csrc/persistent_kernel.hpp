@@ -297,13 +297,15 @@ k_update_persistent(const ModelDesc m, const PersistArgs pa, ControlBlock *cb, c
     SABC_TRACE(iter, 4);
     a.mode |= CTRL_KEEP_SUMS;
     // first part: accept count, resample test, the proposal's covariance
-    if (on_ctrl_wave && ctrl_lane == 0) first = (int)control_step_first<D, S>(lcb, a, sums);
+    // (the error flag as it stands after the first part travels with its outcome: the second part may raise it while the others
+    // are reading)
+    if (on_ctrl_wave && ctrl_lane == 0) first = (int)control_step_first<D, S>(lcb, a, sums) | (lcb.error != 0 ? 8 : 0);
     __syncthreads();
     SABC_TRACE(iter, 11);
     done = u + 1;
-    if (first != (int)CONTROL_GOES_ON) break;          // the resample test fired (:340): the host's turn
+    if ((first & 7) != (int)CONTROL_GOES_ON) break;    // the resample test fired (:340): the host's turn
     // second part on the control wave; the others draft update u + 1 meanwhile (when there is one, and nothing has gone wrong)
-    const bool ahead = overlap && lcb.error == 0 && u + 1 < pa.count;
+    const bool ahead = overlap && (first & 8) == 0 && u + 1 < pa.count;
     if (on_ctrl_wave) {
       const bool multi = (a.mode & CTRL_EPSILON) && a.algorithm == SABC_ALG_MULTI_EPS;
       if (multi) {                                     // (one lane per statistic, all on this wave: s <= 64)
