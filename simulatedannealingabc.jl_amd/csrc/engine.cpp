@@ -279,8 +279,8 @@ int Engine::sync_control() {
                     kind[k & 3], cb_.comm_where & 0xFFFFF, (cb_.comm_where >> 20) & 15);
       return fail(SABC_ERR_COMM, buf);
     }
-    case SABC_ERR_HIP: return fail(SABC_ERR_HIP, "the persistent update kernel's grid barrier ran into its bound (its workgroups were not all "
-                                                 "resident: is the device full of other persistent kernels?  SABC_PERSISTENT=0 takes the launch chain)");
+    case SABC_ERR_HIP: return fail(SABC_ERR_HIP, "a wait inside the persistent update kernel (row exchange / grid barrier) ran into its bound: a workgroup "
+                                                 "that was resident at the launch's rendezvous stopped taking part (SABC_PERSISTENT=0 takes the launch chain)");
     default: return fail(cb_.error, "error raised by the device-side control step");
   }
 }

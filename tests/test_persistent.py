@@ -1,6 +1,7 @@
 """Small shards run the population updates of a call in ONE launch (kernels.hip: k_update_persistent): every workgroup keeps
-the control block, the ECDF index and the generator tables in LDS and loops over the updates itself -- body, a grid barrier,
-the sums over all workgroups' rows, the control step on its own copy -- until the resample test fires.  Same Philox streams,
+the control block, the ECDF index and the generator tables in LDS and loops over the updates itself -- body (a lane, a quad or
+a row of 16 lanes per particle), the workgroups' rows exchanged as tagged words, their sums, the control step on its own copy
+(its second part on a wave of its own beside the next update's drafts) -- until the resample test fires.  Same Philox streams,
 same per-particle arithmetic, same control step as the launch chain (k_update -> k_reduce_control per update): the same
 accept and resample counts, particles and epsilon to rounding (the rows are summed in another order); and both equal the
 oracle (tests/test_gpu_parity.py runs at sizes that take the persistent form by default)."""
