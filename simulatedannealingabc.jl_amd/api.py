@@ -197,6 +197,21 @@ def progress_stops(n_pop, show_checkpoint, show_progressbar):
     return sorted(stops)
 
 
+def next_stop(stops, n_pop, show_checkpoint, done, rate):
+    """Where the next sabc_update call ends.  A call costs ~65 us beyond its updates (a launch, two host waits), and the
+    reference's progress bar redraws every 0.1 s at most (ProgressMeter's dt): a run of 999 updates at 10 us each is over before
+    its first redraw, and 50 calls would be a quarter of its time.  `rate` = population updates per second as measured on the
+    previous call (0: unknown): progress-bar stops closer than 0.1 s of work are passed over; multiples of `show_checkpoint`
+    (their log line carries the epsilon of that very update, :359-364) and n_pop never are.  Where the cuts fall changes
+    nothing in the results (history_phase / more_chunks_follow).  The Julia wrapper has the same function."""
+    target = done + (max(1, int(rate * 0.1)) if rate > 0 else 1)
+    chk = int(show_checkpoint) if math.isfinite(show_checkpoint) and show_checkpoint >= 1 else 0
+    for s in stops:
+        if s > done and (s >= target or s == n_pop or (chk and s % chk == 0)):
+            return s
+    return n_pop
+
+
 def initialization(f_dist, prior, *args, n_particles, n_simulation, v=1.0, δ=0.1, algorithm="single_eps",
                    seed=None, device=None, distributed=None, **kwargs):
     """SimulatedAnnealingABC.jl:151-227 -> SABCresult."""
@@ -303,11 +318,16 @@ def update_population_(population_state: SABCresult, f_dist, prior, *args, n_sim
         except ImportError:
             pbar = None
     done, t0 = 0, time.time()
-    for stop in progress_stops(n_pop, show_checkpoint, pbar is not None):
+    stops, rate, first = progress_stops(n_pop, show_checkpoint, pbar is not None), 0.0, True
+    while first or done < n_pop:                          # (n_pop = 0: one call, a top-up below one update is a no-op, :275)
+        first = False
+        stop = next_stop(stops, n_pop, show_checkpoint, done, rate)
         todo = stop - done
         budget = todo * n_global if n_pop > 0 else n_simulation
+        t_call = time.perf_counter()
         h.update(n_simulation=budget, proposal=proposal, v=v, delta=δ, resample=resample,
                  checkpoint_history=checkpoint_history, history_phase=done, more_chunks_follow=stop < n_pop)
+        rate = todo / max(time.perf_counter() - t_call, 1e-9)
         done = stop
         if pbar is not None:
             pbar.update(todo)

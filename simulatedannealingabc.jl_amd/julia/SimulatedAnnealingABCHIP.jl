@@ -421,6 +421,19 @@ function progress_stops(n_pop, show_checkpoint, show_progressbar)
     sort!(collect(stops))
 end
 
+# Where the next sabc_update call ends.  A call costs ~65 us beyond its updates, and ProgressMeter redraws every 0.1 s at most:
+# progress-bar stops closer than 0.1 s of work (rate = population updates per second on the previous call, 0: unknown) are
+# passed over; multiples of `show_checkpoint` and n_pop never are.  Same rule as next_stop() in ../api.py.
+function next_stop(stops, n_pop, show_checkpoint, done, rate)
+    target = done + (rate > 0 ? max(1, floor(Int, rate * 0.1)) : 1)
+    chk = (isfinite(show_checkpoint) && show_checkpoint >= 1) ? Int(show_checkpoint) : 0
+    for s in stops
+        s <= done && continue
+        (s >= target || s == n_pop || (chk > 0 && s % chk == 0)) && return s
+    end
+    n_pop
+end
+
 """
     close(res::SABCresult)
 
@@ -466,11 +479,17 @@ function update_population!(res::SABCresult, f_dist::DeviceDistance, prior::Dist
     pmeter = Progress(n_pop; desc="$n_pop population updates:", output=stderr, enabled=show_progressbar)   # :290-291
     t_start = Dates.now()
     done = 0
-    for stop in progress_stops(n_pop, show_checkpoint, show_progressbar)
+    stops = progress_stops(n_pop, show_checkpoint, show_progressbar)
+    rate, first = 0.0, true
+    while first || done < n_pop                                                    # (n_pop = 0: one call)
+        first = false
+        stop = next_stop(stops, n_pop, show_checkpoint, done, rate)
         todo = stop - done
         budget = n_pop > 0 ? todo * n_global : n_simulation                        # a top-up below one update is a no-op (:275)
         args = Ref(CUpdateArgs(budget, v, δ, resample, checkpoint_history, kind, stop < n_pop ? 1 : 0, p0, p1, done))
+        t_call = time()
         check(h, ccall((:sabc_update, libsabc), Cint, (Ptr{Cvoid}, Ref{CUpdateArgs}), h, args))
+        rate = todo / max(time() - t_call, 1e-9)
         done = stop
         if show_progressbar || (isfinite(show_checkpoint) && show_checkpoint >= 1)
             eps = Vector{Float64}(undef, MAX_STATS); len = Ref{Int32}(0)

@@ -223,6 +223,39 @@ def test_progress_chunking_rule():
     assert "stop < n_pop ? 1 : 0" in call and call.rstrip(")").endswith("done")     # more_chunks_follow, history_phase
 
 
+def test_progress_chunks_follow_the_pace_of_the_run():
+    """next_stop() (api.py and the Julia wrapper): a call of sabc_update costs ~65 us beyond its updates and the reference's
+    progress bar redraws every 0.1 s at most, so progress-bar stops closer than 0.1 s of work are passed over -- a run that is
+    over in 15 ms takes two calls, not fifty --; the stops a log line hangs on (multiples of show_checkpoint) and n_pop never are;
+    a slow run (a host simulator, seconds per update) still stops at every step of the bar."""
+    from sabc_amd.api import next_stop, progress_stops
+    inf = float("inf")
+
+    def calls(n_pop, chk, bar, rate_of):
+        stops, done, rate, out = progress_stops(n_pop, chk, bar), 0, 0.0, []
+        while done < n_pop:
+            s = next_stop(stops, n_pop, chk, done, rate)
+            assert s > done and s in stops
+            out.append(s)
+            rate, done = rate_of, s
+        return out
+
+    fast = calls(999, inf, True, 1e5)                    # 10 us per update: 0.1 s are 10 000 updates
+    assert fast == [19, 999]
+    slow = calls(999, inf, True, 2.0)                    # half a second per update: every step of the bar
+    assert slow == progress_stops(999, inf, True)
+    logged = calls(999, 100, False, 1e5)                 # log lines every 100 updates: all of them, whatever the pace
+    assert logged == [100, 200, 300, 400, 500, 600, 700, 800, 900, 999]
+    mixed = calls(100_000, 1000, True, 3e4)              # 0.1 s = 3000 updates: bar stops every 2000 -> every other one, plus the log's
+    assert all(x in mixed for x in range(1000, 100_000, 1000)) and mixed[-1] == 100_000
+    assert next_stop(progress_stops(0, inf, True), 0, inf, 0, 0.0) == 0
+    body = re.search(r"function next_stop\(.*?\nend", jl_source(), re.S).group(0)
+    for tok in ("done + (rate > 0 ? max(1, floor(Int, rate * 0.1)) : 1)", "s <= done && continue", "s >= target || s == n_pop || (chk > 0 && s % chk == 0)"):
+        assert tok in body
+    loop = jl_source()
+    assert "stop = next_stop(stops, n_pop, show_checkpoint, done, rate)" in loop and "rate = todo / max(time() - t_call, 1e-9)" in loop
+
+
 def test_every_capitalised_name_resolves():
     """Poor man's name resolution (no Julia here): every capitalised identifier in the wrapper's code -- types, modules,
     constructors -- is defined in the file, imported by a `using X: ...` / `import X` line, a type parameter, or one of the Base

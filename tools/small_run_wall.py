@@ -16,6 +16,14 @@ for n, nsim in ((1000, 1_000_000), (1000, 10_000_000), (5000, 5_000_000)):
     upd = nsim // n - 1
     print(f"n_particles {n} n_simulation {nsim}: sabc() wall first {ts[0]*1e3:.1f} ms, then {np.median(ts[1:])*1e3:.2f} ms "
           f"({upd} updates: {np.median(ts[1:]) / upd * 1e6:.2f} us per update all in; {res.state.n_resampling} resamples), posterior mean {res.population.mean():.4f}", flush=True)
+# the same with the progress bar a terminal user gets (50 steps; calls end where 0.1 s of work have passed: api.next_stop)
+for n, nsim in ((1000, 1_000_000),):
+    ts = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        res = S.sabc(model, prior, n_particles=n, n_simulation=nsim, seed=rep + 1, show_progressbar=True, show_checkpoint=float("inf"))
+        ts.append(time.perf_counter() - t0)
+    print(f"n_particles {n} n_simulation {nsim} with the progress bar: {np.median(ts[1:])*1e3:.2f} ms", flush=True)
 # where a call's time goes: the pieces, timed apart
 n, nsim = 1000, 1_000_000
 t0 = time.perf_counter(); h = S.SabcHandle(n_particles=n, model=model, prior=prior, seed=3); t1 = time.perf_counter()
