@@ -37,6 +37,35 @@ static double persist_timeout_ms() {                 // (read per launch: tests 
   return v > 0 ? v : 2000.0;
 }
 
+// Streams of closed handles are kept for the next handle on the same device: creating one costs ~0.4 ms, destroying one as much
+// -- a tenth of a whole sabc() call at the sizes the reference's documentation works with (17 ms for n_particles = 1000,
+// n_simulation = 1e6).  A stream goes back only after it has drained; streams the caller supplied (sabc_set_stream) are never
+// pooled.  (The pool is never torn down: at process exit the runtime may already be gone.)
+namespace {
+std::mutex g_stream_pool_mutex;
+std::vector<std::pair<int, hipStream_t>> *g_stream_pool = nullptr;       // (device, idle stream)
+constexpr size_t kStreamPoolMax = 32;
+
+hipStream_t pooled_stream_take(int device) {
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  if (!g_stream_pool) return nullptr;
+  for (size_t i = 0; i < g_stream_pool->size(); ++i)
+    if ((*g_stream_pool)[i].first == device) {
+      hipStream_t s = (*g_stream_pool)[i].second;
+      g_stream_pool->erase(g_stream_pool->begin() + (long)i);
+      return s;
+    }
+  return nullptr;
+}
+void pooled_stream_give(int device, hipStream_t s) {
+  if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(s); return; }
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  if (!g_stream_pool) g_stream_pool = new std::vector<std::pair<int, hipStream_t>>();
+  if (g_stream_pool->size() >= kStreamPoolMax) { (void)hipStreamDestroy(s); return; }
+  g_stream_pool->emplace_back(device, s);
+}
+}  // namespace
+
 static double persist_rendezvous_ms() {              // (the wait for every workgroup of a one-launch update to be resident)
   const char *e = std::getenv("SABC_PERSISTENT_RENDEZVOUS_MS");
   const double v = e ? std::atof(e) : 0.0;
@@ -106,9 +135,7 @@ HipBackend::~HipBackend() {
   if (sort_tmp_) (void)hipFree(sort_tmp_);
   if (meta_dev_) (void)hipFree(meta_dev_);
   if (cb_dev_) (void)hipFree(cb_dev_);
-  if (cb_host_) (void)hipHostFree(cb_host_);
-  if (mbox_host_) (void)hipHostFree(mbox_host_);
-  if (totals_host_) (void)hipHostFree(totals_host_);
+  if (pinned_block_) (void)hipHostFree(pinned_block_);     // (the control block's staging copy, the mailbox ring, the totals)
   rtc_release(&rtc_);
   if (persist_sync_) (void)hipFree(persist_sync_);
   if (persist_rows_) (void)hipFree(persist_rows_);
@@ -116,7 +143,7 @@ HipBackend::~HipBackend() {
   if (p2p_test_dev_) (void)hipFree(p2p_test_dev_);
   if (snap_pop_) (void)hipFree(snap_pop_);
   if (snap_rho_) (void)hipFree(snap_rho_);
-  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  if (own_stream_ && stream_) pooled_stream_give(device_, stream_);
 }
 
 int HipBackend::check(hipError_t e, const char *what) {
@@ -130,7 +157,7 @@ int HipBackend::check(hipError_t e, const char *what) {
 int HipBackend::set_stream(hipStream_t s) {
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
   if (stream_) HB_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
-  if (own_stream_ && stream_) (void)hipStreamDestroy(stream_);
+  if (own_stream_ && stream_) pooled_stream_give(device_, stream_);
   stream_ = s;
   own_stream_ = false;
   return 0;
@@ -163,7 +190,8 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   np_ = n_partials(m.d, m.s);
   HB_CHECK(hipSetDevice(device_), "hipSetDevice");
   if (!stream_) {
-    HB_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    stream_ = pooled_stream_take(device_);
+    if (!stream_) HB_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     own_stream_ = true;
   }
   const size_t cap = (size_t)sh.cap, N = (size_t)sh.n_global;
@@ -201,18 +229,24 @@ int HipBackend::allocate(const ModelDesc &m, const Shard &sh) {
   HB_CHECK(hipMalloc((void **)&partials_, (size_t)partial_rows_ * np_ * sizeof(double)), "hipMalloc(partials)");
   HB_CHECK(hipMalloc((void **)&cb_dev_, sizeof(ControlBlock)), "hipMalloc(control block)");
   HB_CHECK(hipMemsetAsync(cb_dev_, 0, sizeof(ControlBlock), stream_), "hipMemset(control block)");
-  HB_CHECK(hipHostMalloc((void **)&cb_host_, sizeof(ControlBlock)), "hipHostMalloc(control block)");
+  {   // ONE pinned block for the control block's staging copy, the mailbox ring and the totals (hipHostFree is 0.2 ms apiece)
+    const size_t off_mbox = (sizeof(ControlBlock) + 255) / 256 * 256, off_totals = off_mbox + (kMailboxRing * sizeof(Mailbox) + 255) / 256 * 256;
+    HB_CHECK(hipHostMalloc((void **)&pinned_block_, off_totals + 256, hipHostMallocMapped), "hipHostMalloc(control block, mailbox, totals)");
+    char *pinned_dev = nullptr;
+    HB_CHECK(hipHostGetDevicePointer((void **)&pinned_dev, pinned_block_, 0), "hipHostGetDevicePointer(pinned block)");
+    cb_host_ = reinterpret_cast<ControlBlock *>(pinned_block_);
+    mbox_host_ = reinterpret_cast<Mailbox *>(pinned_block_ + off_mbox);
+    mbox_dev_ = reinterpret_cast<Mailbox *>(pinned_dev + off_mbox);
+    totals_host_ = reinterpret_cast<double *>(pinned_block_ + off_totals);
+    totals_host_dev_ = reinterpret_cast<double *>(pinned_dev + off_totals);
+  }
   HB_CHECK(hipMalloc((void **)&sums_stage_, kMaxPartials * sizeof(double)), "hipMalloc(sums staging)");
   HB_CHECK(hipMemsetAsync(sums_stage_, 0, kMaxPartials * sizeof(double), stream_), "hipMemset(sums staging)");
-  HB_CHECK(hipHostMalloc((void **)&mbox_host_, kMailboxRing * sizeof(Mailbox), hipHostMallocMapped), "hipHostMalloc(mailbox)");
   for (int i = 0; i < kMailboxRing; ++i) { mbox_host_[i].w0 = kMailboxEmpty; mbox_host_[i].w1 = kMailboxEmpty; }
-  HB_CHECK(hipHostGetDevicePointer((void **)&mbox_dev_, mbox_host_, 0), "hipHostGetDevicePointer(mailbox)");
   HB_CHECK(hipMalloc((void **)&cum_, N * sizeof(double)), "hipMalloc(cum)");
   HB_CHECK(hipMalloc((void **)&block_sums_, (size_t)weight_scan_doubles((int64_t)N) * sizeof(double)), "hipMalloc(block_sums)");
   HB_CHECK(hipMalloc((void **)&totals_dev_, 2 * sizeof(double)), "hipMalloc(totals)");
-  HB_CHECK(hipHostMalloc((void **)&totals_host_, 2 * sizeof(double), hipHostMallocMapped), "hipHostMalloc(totals)");
   totals_host_[0] = totals_host_[1] = 0.0;
-  HB_CHECK(hipHostGetDevicePointer((void **)&totals_host_dev_, totals_host_, 0), "hipHostGetDevicePointer(totals)");
   HB_CHECK(hipMalloc((void **)&meta_dev_, 2 * kMaxStats * sizeof(int64_t)), "hipMalloc(meta)");
   int khz = 0;                                          // rate of the constant wall clock every bounded wait counts in
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device_) == hipSuccess && khz > 0) wall_clock_khz_ = khz;

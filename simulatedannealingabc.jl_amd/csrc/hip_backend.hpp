@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <string>
+#include <mutex>
+#include <utility>
 #include <vector>
 #include "engine.hpp"
 #include "kernels.hpp"
@@ -123,6 +125,7 @@ class HipBackend : public Backend {
   int device_ = 0;
   hipStream_t stream_ = nullptr;
   bool own_stream_ = false;
+  char *pinned_block_ = nullptr;                          // one pinned, mapped allocation behind cb_host_, mbox_host_, totals_host_
   std::string err_;
   ModelDesc m_{};
   Shard sh_{};
